@@ -1,0 +1,310 @@
+// gfx950 bf16/fp16 MFMA tile engine:  C[M,N] = A[M,K] * B[N,K]^T, fp32 accumulate.
+//
+// One workgroup (512 threads = 8 waves, 2 along M x 4 along N) computes one 256x256 output tile
+// with v_mfma_f32_16x16x32_{bf16,f16}.  K is walked in 64-deep steps through a 2 x 64 KiB LDS
+// ring filled by direct-to-LDS loads (global_load_lds_dwordx4) that stay in flight across raw
+// s_barriers (counted s_waitcnt vmcnt, never 0 in steady state).  Each K-step is cut into four
+// phases = four 64x32 accumulator quadrants per wave (16 MFMAs each); each phase also stages one
+// 16 KiB "half tile" seven half-tiles ahead.  Waves 4-7 run one barrier behind waves 0-3 so that on
+// every SIMD one wave is in its MFMA segment while its partner is in its LDS/DMA segment.
+//
+// LDS image of a half tile (128 rows x 64 k, 16-bit elements): sixteen 1-KiB sub-tiles of
+// [16 rows][32 k]; inside a sub-tile byte = row*64 + kbyte, with bit 5 XOR-ed by bit 9 (rows 8-15
+// swap their 32-byte halves) so one ds_read_b128 wave-instruction touches all 16 slots of the
+// 256-B bank row once.  The DMA destination is lane-linear, so the same XOR is applied to the
+// per-lane SOURCE address instead.
+//
+// Half-tile order inside a K-step buffer is B0, A0, B1, A1 where A0/A1 hold, for both wave rows,
+// the first/second 64 rows of that wave row's 128, and B0/B1 hold, for all four wave columns,
+// the first/second 32 columns of that wave column's 64.  The order is what makes the write-after-
+// read distances legal: a slot is restaged two phases after its last ds_read, or one phase after
+// when those reads were retired by an lgkmcnt wait before the reading phase's first barrier (B0).
+//
+// Role in the reference: the Triton `tl.dot` GEMM bodies of
+// python/triton_dist/kernels/amd/all_gather_gemm.py:127-245 and gemm_reduce_scatter.py:125-229
+// (tile 128x256x64, 3 stages, autotuned) - redesigned here for 64-wide waves / 160 KiB LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+namespace tdist {
+namespace gemm {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int BM = 256;
+constexpr int BN = 256;
+constexpr int BK = 64;
+constexpr int THREADS = 512;
+constexpr int HALF_BYTES = 16384;
+constexpr int BUF_BYTES = 65536;
+constexpr int OFF_B0 = 0;
+constexpr int OFF_A0 = 16384;
+constexpr int OFF_B1 = 32768;
+constexpr int OFF_A1 = 49152;
+constexpr int C_STRIDE = 528;                 // bytes per staged output row (512 + 16 pad)
+constexpr int LDS_BYTES = BM * C_STRIDE;      // 135168 >= 2 * BUF_BYTES
+
+#define TDIST_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define TDIST_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+template <bool IS_BF16>
+struct Frag;
+template <>
+struct Frag<true> {
+  using T = bf16x8;
+  static __device__ __forceinline__ f32x4 mfma(T a, T b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+  }
+};
+template <>
+struct Frag<false> {
+  using T = f16x8;
+  static __device__ __forceinline__ f32x4 mfma(T a, T b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+    f16x2 v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+  }
+};
+
+// Description of one 256x256 tile job.  A and B are 16-bit row-major with K contiguous.
+struct TileArgs {
+  const uint16_t* A;   // first row of the A operand this tile reads (row index 0 == tile row 0 .. clamp below)
+  const uint16_t* B;
+  long long lda;       // elements
+  long long ldb;
+  int a_rows;          // valid rows in A starting at A (rows >= a_rows are clamped, results masked)
+  int b_rows;          // valid rows in B starting at B
+  int K;               // multiple of 64, >= 128
+};
+
+// Accumulators of one wave: 8 (m) x 4 (n) tiles of 16x16, stored transposed (lane: m = lane&15,
+// n = 4*(lane>>4) + reg) because the MFMA is issued as B*A^T.
+template <bool IS_BF16>
+struct Acc {
+  f32x4 v[8][4];
+};
+
+template <bool IS_BF16>
+__device__ __forceinline__ void mainloop_256(const TileArgs& t, char* smem, Acc<IS_BF16>& acc) {
+  using F = Frag<IS_BF16>;
+  using V = typename F::T;
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63;
+  const int wr = w >> 2, wc = w & 3;
+  const bool late_group = w >= 4;
+
+  // ---- staging source addresses (per lane) ------------------------------------------------
+  const int hr = w * 16 + (l >> 2);                       // row inside a half tile, 0..127
+  const int kchunk = (l & 3) ^ (((l >> 5) & 1) << 1);     // 16-byte chunk inside the 64-byte row segment
+  int arow0 = (hr >> 6) * 128 + (hr & 63);                // A0 ; A1 = +64
+  int arow1 = arow0 + 64;
+  int brow0 = (hr >> 5) * 64 + (hr & 31);                 // B0 ; B1 = +32
+  int brow1 = brow0 + 32;
+  arow0 = arow0 < t.a_rows ? arow0 : t.a_rows - 1;
+  arow1 = arow1 < t.a_rows ? arow1 : t.a_rows - 1;
+  brow0 = brow0 < t.b_rows ? brow0 : t.b_rows - 1;
+  brow1 = brow1 < t.b_rows ? brow1 : t.b_rows - 1;
+  const uint16_t* pa0 = t.A + (long long)arow0 * t.lda + kchunk * 8;
+  const uint16_t* pa1 = t.A + (long long)arow1 * t.lda + kchunk * 8;
+  const uint16_t* pb0 = t.B + (long long)brow0 * t.ldb + kchunk * 8;
+  const uint16_t* pb1 = t.B + (long long)brow1 * t.ldb + kchunk * 8;
+
+  const int nt = t.K / BK;
+  const int stage_sub = w * 2048;  // this wave's two sub-tiles inside a half tile
+
+  // Stage half tile `kind` (0=B0 1=A0 2=B1 3=A1) of K-step `kt` into ring buffer kt&1.
+  auto stage = [&](int kt, auto kind_c) {
+    constexpr int kind = decltype(kind_c)::value;
+    if (kt < nt) {
+      const uint16_t* src = kind == 0 ? pb0 : (kind == 1 ? pa0 : (kind == 2 ? pb1 : pa1));
+      src += (long long)kt * BK;
+      char* dst = smem + (kt & 1) * BUF_BYTES + kind * HALF_BYTES + stage_sub;
+      __builtin_amdgcn_global_load_lds(TDIST_GLB_PTR(src), TDIST_LDS_PTR(dst), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(TDIST_GLB_PTR(src + 32), TDIST_LDS_PTR(dst + 1024), 16, 0, 0);
+    }
+  };
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+  using K2 = std::integral_constant<int, 2>;
+  using K3 = std::integral_constant<int, 3>;
+
+  // ---- fragment read addresses (per lane) -------------------------------------------------
+  const int lane_off = (((l & 15) * 64) + ((l >> 4) * 16)) ^ ((((l & 15) >> 3) & 1) << 5);
+  const char* a_rd = smem + wr * 8192 + lane_off;   // + OFF_A{0,1} + (mt*2+ks)*1024
+  const char* b_rd = smem + wc * 4096 + lane_off;   // + OFF_B{0,1} + (nt*2+ks)*1024
+
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc.v[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: 7 half tiles in flight, first K-step landed ------------------------------
+  stage(0, K0{}); stage(0, K1{}); stage(0, K2{}); stage(0, K3{});
+  stage(1, K0{}); stage(1, K1{}); stage(1, K2{});
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (late_group) __builtin_amdgcn_s_barrier();
+
+  V a[4][2], b0[2][2], b1[2][2];
+
+  for (int kt = 0; kt < nt; ++kt) {
+    const int boff = (kt & 1) * BUF_BYTES;
+    // ---------------- phase 0: quadrant (m0, n0) ----------------
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) b0[n][ks] = *(const V*)(b_rd + boff + OFF_B0 + (n * 2 + ks) * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) a[m][ks] = *(const V*)(a_rd + boff + OFF_A0 + (m * 2 + ks) * 1024);
+    stage(kt + 1, K3{});
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc.v[m][n] = F::mfma(b0[n][ks], a[m][ks], acc.v[m][n]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---------------- phase 1: quadrant (m0, n1) ----------------
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) b1[n][ks] = *(const V*)(b_rd + boff + OFF_B1 + (n * 2 + ks) * 1024);
+    stage(kt + 2, K0{});
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc.v[m][2 + n] = F::mfma(b1[n][ks], a[m][ks], acc.v[m][2 + n]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---------------- phase 2: quadrant (m1, n1) ----------------
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) a[m][ks] = *(const V*)(a_rd + boff + OFF_A1 + (m * 2 + ks) * 1024);
+    stage(kt + 2, K1{});
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc.v[4 + m][2 + n] = F::mfma(b1[n][ks], a[m][ks], acc.v[4 + m][2 + n]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---------------- phase 3: quadrant (m1, n0) ----------------
+    stage(kt + 2, K2{});
+    // Retire the next K-step: everything but the three newest half tiles (6 loads).  In the last
+    // two K-steps nothing new was issued, so drain completely / not at all.
+    if (kt + 2 < nt) {
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else if (kt + 2 == nt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc.v[4 + m][n] = F::mfma(b0[n][ks], a[m][ks], acc.v[4 + m][n]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  }
+  if (!late_group) __builtin_amdgcn_s_barrier();
+}
+
+// Convert the accumulators to 16-bit, stage the 256x256 tile in LDS and hand 16-byte row pieces to
+// `store(row_in_tile, col_in_tile, uint4)`; every thread calls store 16 times with rows
+// (pass*16 + tid/32) and columns (tid%32)*8.  Ends with a workgroup barrier so LDS may be reused.
+template <bool IS_BF16, class StoreFn>
+__device__ __forceinline__ void epilogue_256(const Acc<IS_BF16>& acc, char* smem, StoreFn&& store) {
+  using F = Frag<IS_BF16>;
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, l = tid & 63;
+  const int wr = w >> 2, wc = w & 3;
+  // all waves are past their last fragment read (mainloop ends on a barrier)
+  char* base = smem + (wr * 128 + (l & 15)) * C_STRIDE + (wc * 64 + (l >> 4) * 4) * 2;
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const f32x4 v = acc.v[m][n];
+      uint2 p;
+      p.x = F::pack2(v[0], v[1]);
+      p.y = F::pack2(v[2], v[3]);
+      *(uint2*)(base + m * 16 * C_STRIDE + n * 32) = p;
+    }
+  __syncthreads();
+  const int r0 = tid >> 5, cc = tid & 31;
+#pragma unroll 4
+  for (int pass = 0; pass < 16; ++pass) {
+    const int row = pass * 16 + r0;
+    const uint4 v = *(const uint4*)(smem + row * C_STRIDE + cc * 16);
+    store(row, cc * 8, v);
+  }
+  __syncthreads();
+}
+
+// Bijective remap of a linear workgroup id so that each group of ids that shares an XCD
+// (ids equal mod 8 under round-robin dispatch) owns one contiguous range of work.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + idx;
+}
+
+// Grouped (GROUP_M rows at a time) mapping of a linear tile id to (pid_m, pid_n).
+__device__ __forceinline__ void tile_coords(int id, int num_pid_m, int num_pid_n, int group_m, int& pid_m, int& pid_n) {
+  const int per_group = group_m * num_pid_n;
+  const int group = id / per_group;
+  const int first_m = group * group_m;
+  const int gsz = min(num_pid_m - first_m, group_m);
+  const int in = id - group * per_group;
+  pid_m = first_m + in % gsz;
+  pid_n = in / gsz;
+}
+
+}  // namespace gemm
+}  // namespace tdist

@@ -1,0 +1,50 @@
+"""Single-GPU 16-bit GEMM on the gfx950 MFMA tile engine:  C = A @ B^T.
+
+``gemm_nt(a, b)`` takes ``a [M, K]`` and ``b [N, K]`` (both K-contiguous - the layout every fused
+op in this package uses for weights) and returns ``[M, N]``.  Shapes the hand-written kernel does
+not cover (K % 64 != 0, K < 128, N % 8 != 0, other dtypes) and CPU tensors go to ``torch.matmul``.
+
+Role in the reference: Triton matmul of python/triton_dist/test/amd/test_matmul_amd.py and the
+GEMM halves of kernels/amd/all_gather_gemm.py / gemm_reduce_scatter.py.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from .. import _lib
+
+_DT = {torch.bfloat16: 0, torch.float16: 1}
+
+
+def gemm_supported(a: torch.Tensor, b: torch.Tensor) -> bool:
+    if not (a.is_cuda and b.is_cuda) or a.dtype not in _DT or a.dtype != b.dtype:
+        return False
+    if a.dim() != 2 or b.dim() != 2 or a.stride(1) != 1 or b.stride(1) != 1:
+        return False
+    M, K = a.shape
+    N = b.shape[0]
+    return (K >= 128 and K % 64 == 0 and N % 8 == 0 and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0
+            and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and M > 0 and N > 0)
+
+
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, group_m: int = 8,
+            force_native: bool = False) -> torch.Tensor:
+    assert a.shape[1] == b.shape[1], f"K mismatch: {tuple(a.shape)} vs {tuple(b.shape)}"
+    M, K = a.shape
+    N = b.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    if not gemm_supported(a, b) or out.stride(1) != 1 or out.stride(0) % 8 or out.data_ptr() % 16:
+        if force_native:
+            raise ValueError("shape/dtype not supported by the gfx950 GEMM kernel")
+        torch.matmul(a, b.t(), out=out)
+        return out
+    lib = _lib.hip()
+    _lib.check(
+        lib.tdist_gemm_nt(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), M, N, K, ctypes.c_longlong(a.stride(0)),
+                          ctypes.c_longlong(b.stride(0)), ctypes.c_longlong(out.stride(0)), _DT[a.dtype], group_m,
+                          _lib.stream_handle()), "tdist_gemm_nt")
+    return out

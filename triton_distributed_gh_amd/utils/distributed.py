@@ -1,0 +1,136 @@
+"""Process bootstrap: torch.distributed (RCCL + gloo) and the node-wide symmetric heap.
+
+One call - ``initialize_distributed()`` - does what the reference spreads over
+``triton_dist.utils.initialize_distributed`` (reference: python/triton_dist/utils.py:182-205) and the
+per-test AMD rocSHMEM bootstrap (python/triton_dist/test/amd/test_gemm_rs_intra_node.py:153-195):
+reads RANK / LOCAL_RANK / WORLD_SIZE, creates the process groups, seeds the RNGs and maps the
+symmetric heap of every rank.
+
+Backends
+* GPU, one rank per device: ``cpu:gloo,cuda:nccl`` (``nccl`` is RCCL on ROCm).
+* GPU, several ranks sharing a device (functional testing on a 1-GPU box): gloo only - RCCL refuses
+  duplicate devices - while the kernels still talk through hipIpc mappings.
+* no GPU: gloo + the shared-memory host heap.
+"""
+from __future__ import annotations
+
+import atexit
+import datetime
+import os
+import random
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .symm import SymmetricHeap
+
+
+@dataclass
+class DistEnv:
+    rank: int
+    local_rank: int
+    world_size: int
+    local_world_size: int
+    device: torch.device
+    backend: str                     # "hip" or "host"
+    tp_group: Optional[dist.ProcessGroup]
+    cpu_group: Optional[dist.ProcessGroup]
+    heap: SymmetricHeap
+    shared_gpu: bool = False         # several ranks on one device
+    has_rccl: bool = False
+
+    @property
+    def num_ranks(self) -> int:
+        return self.world_size
+
+
+_ENV: Optional[DistEnv] = None
+
+
+def init_seed(seed: int = 0) -> None:
+    """Deterministic seeding (reference: python/triton_dist/utils.py:77-96)."""
+    os.environ.setdefault("CUBLAS_WORKSPACE_CONFIG", ":4096:8")
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+
+
+def is_initialized() -> bool:
+    return _ENV is not None
+
+
+def get_env() -> DistEnv:
+    if _ENV is None:
+        raise RuntimeError("call initialize_distributed() first")
+    return _ENV
+
+
+def initialize_distributed(seed: Optional[int] = None, heap_bytes: Optional[int] = None,
+                           sig_bytes: Optional[int] = None, force_host: bool = False) -> DistEnv:
+    global _ENV
+    if _ENV is not None:
+        return _ENV
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", rank))
+    world_size = int(os.environ.get("WORLD_SIZE", 1))
+    local_world_size = int(os.environ.get("LOCAL_WORLD_SIZE", world_size))
+
+    use_gpu = torch.cuda.is_available() and not force_host
+    shared_gpu = False
+    if use_gpu:
+        ndev = torch.cuda.device_count()
+        shared_gpu = local_world_size > ndev
+        dev_index = local_rank % ndev
+        torch.cuda.set_device(dev_index)
+        device = torch.device("cuda", dev_index)
+    else:
+        device = torch.device("cpu")
+
+    has_rccl = use_gpu and not shared_gpu
+    tp_group = cpu_group = None
+    if world_size > 1 or "MASTER_ADDR" in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if not dist.is_initialized():
+            backend = "cpu:gloo,cuda:nccl" if has_rccl else "gloo"
+            kwargs = {}
+            if has_rccl:
+                kwargs["device_id"] = device
+            dist.init_process_group(backend=backend, world_size=world_size, rank=rank,
+                                    timeout=datetime.timedelta(seconds=1800), **kwargs)
+        tp_group = dist.new_group(ranks=list(range(world_size)), backend="nccl" if has_rccl else "gloo")
+        cpu_group = dist.new_group(ranks=list(range(world_size)), backend="gloo")
+        dist.barrier(group=cpu_group)
+
+    init_seed((seed if seed is not None else 0) + rank)
+    heap = SymmetricHeap(rank, world_size, cpu_group, "hip" if use_gpu else "host", heap_bytes, sig_bytes)
+    _ENV = DistEnv(rank, local_rank, world_size, local_world_size, device, "hip" if use_gpu else "host",
+                   tp_group, cpu_group, heap, shared_gpu, has_rccl)
+    atexit.register(finalize_distributed)
+    return _ENV
+
+
+def finalize_distributed() -> None:
+    """Tear down heap and process groups (reference: python/triton_dist/utils.py:145-148)."""
+    global _ENV
+    if _ENV is None:
+        return
+    env, _ENV = _ENV, None
+    try:
+        if env.backend == "hip":
+            torch.cuda.synchronize()
+        if dist.is_initialized() and env.cpu_group is not None:
+            dist.barrier(group=env.cpu_group)
+    except Exception:
+        pass
+    env.heap.close()
+    try:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    except Exception:
+        pass

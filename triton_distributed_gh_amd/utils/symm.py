@@ -1,0 +1,306 @@
+"""Symmetric heap: one arena per rank, mapped into every rank of the node.
+
+Design (MI355X-first): instead of one IPC handle exchange per tensor
+(reference: shmem/rocshmem_bind/pyrocshmem/src/pyrocshmem.cc:198-256 ``hipipc_create_tensor_list``;
+python/triton_dist/utils.py:114-136 ``nvshmem_create_tensor(s)``) each rank allocates ONE data
+arena and ONE small signal arena at start-up, the handles are exchanged once over
+``torch.distributed`` and symmetric tensors are carved at identical offsets on every rank.
+``symm_at(ptr, peer)`` on the device is then a base-pointer translation.
+
+Two backends share this file:
+* ``hip``  - ``hipMalloc`` / ``hipExtMallocWithFlags`` + ``hipIpcGet/OpenMemHandle``;
+* ``host`` - POSIX shared memory (``/dev/shm``) so the full stack runs on a CPU-only machine.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import uuid
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from .. import _lib
+
+MAX_RANKS = 16
+
+
+class SymmCtxStruct(ctypes.Structure):
+    """Mirror of ``tdist::SymmCtx`` (csrc/include/tdist/common.hpp); passed to kernels by value."""
+
+    _fields_ = [
+        ("rank", ctypes.c_int),
+        ("num_ranks", ctypes.c_int),
+        ("heap_base", ctypes.c_uint64 * MAX_RANKS),
+        ("sig_base", ctypes.c_uint64 * MAX_RANKS),
+        ("heap_bytes", ctypes.c_uint64),
+        ("sig_bytes", ctypes.c_uint64),
+    ]
+
+
+class _RawCuda:
+    """Minimal ``__cuda_array_interface__`` carrier so torch can wrap a raw device pointer."""
+
+    def __init__(self, ptr: int, nbytes: int, owner=None):
+        self.owner = owner
+        self.__cuda_array_interface__ = {
+            "shape": (nbytes,),
+            "typestr": "|u1",
+            "data": (ptr, False),
+            "version": 2,
+        }
+
+
+def _wrap_device(ptr: int, nbytes: int, owner) -> torch.Tensor:
+    return torch.as_tensor(_RawCuda(ptr, nbytes, owner), device=torch.device("cuda", torch.cuda.current_device()))
+
+
+def _wrap_host(ptr: int, nbytes: int, owner) -> torch.Tensor:
+    buf = (ctypes.c_ubyte * nbytes).from_address(ptr)
+    t = torch.frombuffer(buf, dtype=torch.uint8)
+    t._tdist_owner = owner  # keep the mapping alive
+    return t
+
+
+class _FreeList:
+    """First-fit allocator with coalescing; deterministic, so every rank computes equal offsets."""
+
+    def __init__(self, size: int):
+        self.size = size
+        self.free = [(0, size)]
+        self.used = {}
+
+    def alloc(self, nbytes: int, align: int) -> int:
+        nbytes = max(int(nbytes), 1)
+        for i, (off, sz) in enumerate(self.free):
+            start = (off + align - 1) // align * align
+            end = start + nbytes
+            if end <= off + sz:
+                pieces = []
+                if start > off:
+                    pieces.append((off, start - off))
+                if end < off + sz:
+                    pieces.append((end, off + sz - end))
+                self.free[i : i + 1] = pieces
+                self.used[start] = nbytes
+                return start
+        raise MemoryError(
+            f"symmetric arena exhausted: need {nbytes} bytes, arena {self.size}; raise TDIST_SYMM_HEAP_BYTES / "
+            "TDIST_SYMM_SIG_BYTES"
+        )
+
+    def release(self, off: int) -> None:
+        sz = self.used.pop(off)
+        self.free.append((off, sz))
+        self.free.sort()
+        merged = []
+        for o, s in self.free:
+            if merged and merged[-1][0] + merged[-1][1] == o:
+                merged[-1] = (merged[-1][0], merged[-1][1] + s)
+            else:
+                merged.append((o, s))
+        self.free = merged
+
+
+@dataclass
+class SymmTensorInfo:
+    arena: str
+    offset: int
+    nbytes: int
+
+
+class SymmetricHeap:
+    """Collective object: construct it on every rank of ``group`` in the same order."""
+
+    def __init__(
+        self,
+        rank: int,
+        world_size: int,
+        group: Optional[dist.ProcessGroup],
+        backend: str,
+        heap_bytes: Optional[int] = None,
+        sig_bytes: Optional[int] = None,
+    ):
+        assert world_size <= MAX_RANKS, f"at most {MAX_RANKS} ranks per node"
+        self.rank, self.world_size, self.group, self.backend = rank, world_size, group, backend
+        default_heap = (1 << 31) if backend == "hip" else (1 << 26)
+        self.heap_bytes = int(heap_bytes or os.environ.get("TDIST_SYMM_HEAP_BYTES", default_heap))
+        self.sig_bytes = int(sig_bytes or os.environ.get("TDIST_SYMM_SIG_BYTES", 1 << 22))
+        self._alloc = {"data": _FreeList(self.heap_bytes), "sig": _FreeList(self.sig_bytes)}
+        self._bases = {"data": [0] * world_size, "sig": [0] * world_size}
+        self._flat = {"data": [None] * world_size, "sig": [None] * world_size}
+        self._owned = []
+        self._shm_names: List[str] = []
+        self._closed = False
+        if backend == "hip":
+            self._init_hip()
+        else:
+            self._init_host()
+        self._tensor_info = {}
+
+    # ------------------------------------------------------------------ backends
+    def _exchange(self, obj):
+        if self.world_size == 1:
+            return [obj]
+        out = [None] * self.world_size
+        dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    def _init_hip(self) -> None:
+        lib = _lib.hip()
+        hsz = lib.tdist_ipc_handle_size()
+        sig_mode = int(os.environ.get("TDIST_SIG_ALLOC_MODE", "1"))  # 1 = fine-grained
+        data_mode = int(os.environ.get("TDIST_HEAP_ALLOC_MODE", "0"))  # 0 = hipMalloc
+        handles = {}
+        for arena, nbytes, mode in (("data", self.heap_bytes, data_mode), ("sig", self.sig_bytes, sig_mode)):
+            p = ctypes.c_void_p()
+            rc = lib.tdist_malloc(ctypes.byref(p), ctypes.c_size_t(nbytes), mode)
+            if rc != 0 and mode != 0:
+                rc = lib.tdist_malloc(ctypes.byref(p), ctypes.c_size_t(nbytes), 0)
+            _lib.check(rc, f"symmetric {arena} arena allocation ({nbytes} bytes)")
+            _lib.check(lib.tdist_memset(p, 0, ctypes.c_size_t(nbytes)), "arena memset")
+            self._owned.append(p.value)
+            self._bases[arena][self.rank] = p.value
+            if self.world_size > 1:
+                h = ctypes.create_string_buffer(hsz)
+                _lib.check(lib.tdist_ipc_get_handle(p, h), f"hipIpcGetMemHandle({arena})")
+                handles[arena] = bytes(h.raw)
+        all_handles = self._exchange((os.getpid(), handles))
+        self._opened = []
+        for r, (pid, hs) in enumerate(all_handles):
+            if r == self.rank:
+                continue
+            for arena in ("data", "sig"):
+                q = ctypes.c_void_p()
+                _lib.check(lib.tdist_ipc_open_handle(hs[arena], ctypes.byref(q)), f"hipIpcOpenMemHandle(rank {r}, {arena})")
+                self._bases[arena][r] = q.value
+                self._opened.append(q.value)
+        for arena, nbytes in (("data", self.heap_bytes), ("sig", self.sig_bytes)):
+            for r in range(self.world_size):
+                self._flat[arena][r] = _wrap_device(self._bases[arena][r], nbytes, self)
+
+    def _init_host(self) -> None:
+        lib = _lib.host()
+        token = self._exchange(uuid.uuid4().hex[:12] if self.rank == 0 else None)[0]
+        for arena, nbytes in (("data", self.heap_bytes), ("sig", self.sig_bytes)):
+            name = f"/tdist_{token}_{arena}_{self.rank}"
+            p = ctypes.c_void_p()
+            _lib.check_host(lib.tdh_shm_map(name.encode(), ctypes.c_uint64(nbytes), 1, ctypes.byref(p)), "shm create")
+            ctypes.memset(p.value, 0, nbytes)
+            self._bases[arena][self.rank] = p.value
+            self._shm_names.append(name)
+        self._exchange("created")  # everyone's arenas exist
+        for r in range(self.world_size):
+            if r == self.rank:
+                continue
+            for arena, nbytes in (("data", self.heap_bytes), ("sig", self.sig_bytes)):
+                name = f"/tdist_{token}_{arena}_{r}"
+                p = ctypes.c_void_p()
+                _lib.check_host(lib.tdh_shm_map(name.encode(), ctypes.c_uint64(nbytes), 0, ctypes.byref(p)), "shm open")
+                self._bases[arena][r] = p.value
+        self._exchange("mapped")
+        for name in self._shm_names:  # mappings stay valid after unlink; nothing leaks on a crash
+            lib.tdh_shm_unlink(name.encode())
+        for arena, nbytes in (("data", self.heap_bytes), ("sig", self.sig_bytes)):
+            for r in range(self.world_size):
+                self._flat[arena][r] = _wrap_host(self._bases[arena][r], nbytes, self)
+
+    # ------------------------------------------------------------------ allocation
+    def _carve(self, arena: str, shape: Sequence[int], dtype: torch.dtype, align: int):
+        numel = math.prod(shape) if len(shape) else 1
+        nbytes = numel * torch.empty((), dtype=dtype).element_size()
+        off = self._alloc[arena].alloc(nbytes, align)
+        return off, nbytes
+
+    def _view(self, arena: str, r: int, off: int, nbytes: int, shape, dtype) -> torch.Tensor:
+        flat = self._flat[arena][r][off : off + nbytes]
+        t = flat.view(dtype).view(*shape) if len(shape) else flat.view(dtype).view(())
+        return t
+
+    def create_tensor(self, shape, dtype, arena: str = "data", align: int = 256, zero: bool = True) -> torch.Tensor:
+        """Collective: returns this rank's tensor; ``peer_views`` gives the other ranks' copies."""
+        shape = tuple(int(s) for s in shape)
+        off, nbytes = self._carve(arena, shape, dtype, align)
+        t = self._view(arena, self.rank, off, max(nbytes, 0), shape, dtype)
+        self._tensor_info[t.data_ptr()] = SymmTensorInfo(arena, off, nbytes)
+        if zero and nbytes:
+            t.zero_()
+        return t
+
+    def create_tensor_list(self, shape, dtype, arena: str = "data", align: int = 256, zero: bool = True) -> List[torch.Tensor]:
+        """Collective: list over ranks of views of the same symmetric tensor (index ``rank`` is local)."""
+        t = self.create_tensor(shape, dtype, arena, align, zero)
+        return self.peer_views(t)
+
+    def info(self, t: torch.Tensor) -> SymmTensorInfo:
+        base = t.data_ptr()
+        for arena in ("data", "sig"):
+            b = self._bases[arena][self.rank]
+            size = self.heap_bytes if arena == "data" else self.sig_bytes
+            if b <= base < b + size:
+                return SymmTensorInfo(arena, base - b, t.numel() * t.element_size())
+        raise ValueError("tensor is not inside this rank's symmetric heap")
+
+    def peer_views(self, t: torch.Tensor) -> List[torch.Tensor]:
+        inf = self.info(t)
+        assert t.is_contiguous(), "symmetric views require a contiguous tensor"
+        nbytes = t.numel() * t.element_size()
+        out = []
+        for r in range(self.world_size):
+            if r == self.rank:
+                out.append(t)
+            else:
+                out.append(self._view(inf.arena, r, inf.offset, nbytes, tuple(t.shape), t.dtype))
+        return out
+
+    def peer_view(self, t: torch.Tensor, peer: int) -> torch.Tensor:
+        return self.peer_views(t)[peer]
+
+    def peer_ptr(self, t: torch.Tensor, peer: int) -> int:
+        inf = self.info(t)
+        return self._bases[inf.arena][peer] + inf.offset
+
+    def free_tensor(self, t: torch.Tensor) -> None:
+        inf = self._tensor_info.pop(t.data_ptr(), None)
+        if inf is not None:
+            self._alloc[inf.arena].release(inf.offset)
+
+    # ------------------------------------------------------------------ device ctx
+    def ctx_struct(self) -> SymmCtxStruct:
+        c = SymmCtxStruct()
+        c.rank, c.num_ranks = self.rank, self.world_size
+        for r in range(self.world_size):
+            c.heap_base[r] = self._bases["data"][r]
+            c.sig_base[r] = self._bases["sig"][r]
+        c.heap_bytes, c.sig_bytes = self.heap_bytes, self.sig_bytes
+        return c
+
+    def base(self, arena: str, r: int) -> int:
+        return self._bases[arena][r]
+
+    # ------------------------------------------------------------------ teardown
+    def close(self) -> None:
+        if self._closed:
+            return
+        self._closed = True
+        self._flat = {"data": [], "sig": []}
+        if self.backend == "hip":
+            lib = _lib.hip()
+            try:
+                lib.tdist_device_sync()
+                for p in getattr(self, "_opened", []):
+                    lib.tdist_ipc_close_handle(ctypes.c_void_p(p))
+                for p in self._owned:
+                    lib.tdist_free(ctypes.c_void_p(p))
+            except Exception:
+                pass
+        else:
+            lib = _lib.host()
+            for arena, nbytes in (("data", self.heap_bytes), ("sig", self.sig_bytes)):
+                for r in range(self.world_size):
+                    b = self._bases[arena][r]
+                    if b:
+                        lib.tdh_shm_unmap(ctypes.c_void_p(b), ctypes.c_uint64(nbytes))
