@@ -1,0 +1,51 @@
+"""gfx950 GEMM kernel vs an fp32 PyTorch reference (scenario of the reference's
+python/triton_dist/test/amd/test_matmul_amd.py)."""
+import pytest
+import torch
+
+from triton_distributed_gh_amd.ops.gemm import gemm_nt
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(256, 256, 128), (512, 768, 256), (300, 520, 192), (1000, 1032, 1024), (64, 4096, 512), (4096, 8192, 1024)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_nt_matches_fp32_reference(M, N, K, dtype):
+    torch.manual_seed(M * 7 + N * 3 + K)
+    a = (torch.rand(M, K, device="cuda") * 2 - 1).to(dtype)
+    b = (torch.rand(N, K, device="cuda") * 2 - 1).to(dtype)
+    c = gemm_nt(a, b, force_native=True)
+    ref = a.float() @ b.float().t()
+    rel = (c.float() - ref).abs().max().item() / ref.abs().max().item()
+    assert rel < 1e-2
+
+
+def test_gemm_nt_asymmetric_identity():
+    # A = I with an asymmetric B catches a transposed output or operand mapping.
+    K = 256
+    a = torch.eye(K, device="cuda", dtype=torch.bfloat16)
+    b = torch.arange(512 * K, device="cuda", dtype=torch.float32).reshape(512, K).remainder(251).bfloat16()
+    c = gemm_nt(a, b, force_native=True)
+    assert torch.equal(c, b.t().contiguous())
+
+
+def test_gemm_nt_strided_views():
+    big_a = (torch.rand(512, 1024, device="cuda") - 0.5).bfloat16()
+    big_b = (torch.rand(768, 1024, device="cuda") - 0.5).bfloat16()
+    a, b = big_a[:, :512], big_b[:, 256:768]
+    out = torch.zeros(512, 1024, device="cuda", dtype=torch.bfloat16)
+    gemm_nt(a, b, out=out[:, :768], force_native=True)
+    ref = a.float() @ b.float().t()
+    assert (out[:, :768].float() - ref).abs().max().item() < 0.5
+    assert out[:, 768:].abs().max().item() == 0
+
+
+def test_gemm_fallback_for_unsupported_shape():
+    a = torch.rand(17, 100, device="cuda").bfloat16()
+    b = torch.rand(24, 100, device="cuda").bfloat16()
+    c = gemm_nt(a, b)
+    assert torch.allclose(c.float(), a.float() @ b.float().t(), atol=0.5)
+    with pytest.raises(ValueError):
+        gemm_nt(a, b, force_native=True)

@@ -1,0 +1,160 @@
+"""CPU-only plumbing: symmetric heap, notify / wait, barrier and the fused-op protocols on the host
+backend (the "world_size=1 notify/wait + reference GEMM correctness on CPU" configuration, plus
+world_size 2..4 through threads and through real gloo processes)."""
+import ctypes
+import os
+import socket
+import subprocess
+import sys
+import threading
+import time
+from pathlib import Path
+
+import pytest
+import torch
+
+from triton_distributed_gh_amd import _lib
+from triton_distributed_gh_amd.ops.ag_gemm import ag_gemm_intra_node, create_ag_gemm_intra_node_context
+from triton_distributed_gh_amd.ops.gemm_rs import create_gemm_rs_intra_node_context, gemm_rs_intra_node
+from triton_distributed_gh_amd.utils.symm import SymmetricHeap, _FreeList
+from triton_distributed_gh_amd.utils.testing import VirtualCluster
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_freelist_alloc_release_coalesce():
+    fl = _FreeList(1024)
+    a = fl.alloc(100, 64)
+    b = fl.alloc(100, 64)
+    c = fl.alloc(100, 64)
+    assert (a, b, c) == (0, 128, 256)
+    fl.release(b)
+    assert fl.alloc(64, 64) == 128            # hole reused first-fit
+    fl.release(a)
+    fl.release(c)
+    with pytest.raises(MemoryError):
+        fl.alloc(4096, 64)
+
+
+def test_world1_heap_and_signals():
+    heap = SymmetricHeap(0, 1, None, "host", heap_bytes=1 << 20, sig_bytes=1 << 16)
+    t = heap.create_tensor([4, 8], torch.float32)
+    assert t.shape == (4, 8) and float(t.abs().sum()) == 0
+    views = heap.peer_views(t)
+    assert len(views) == 1 and views[0].data_ptr() == t.data_ptr()
+    sig = heap.create_tensor([8], torch.int32, arena="sig")
+    lib = _lib.host()
+    lib.tdh_notify32(ctypes.c_void_p(sig.data_ptr()), 5, 1)
+    lib.tdh_notify32(ctypes.c_void_p(sig.data_ptr()), 2, 2)
+    assert int(sig[0]) == 7
+    assert lib.tdh_wait32(ctypes.c_void_p(sig.data_ptr()), 1, 0, 7, ctypes.c_int64(100)) == 0
+    assert lib.tdh_wait32(ctypes.c_void_p(sig.data_ptr()), 1, 0, 8, ctypes.c_int64(50)) == 1   # timeout
+    c = heap.ctx_struct()
+    assert c.rank == 0 and c.num_ranks == 1 and c.heap_base[0] == heap.base("data", 0)
+    heap.free_tensor(t)
+    t2 = heap.create_tensor([4, 8], torch.float32)
+    assert t2.data_ptr() == t.data_ptr()
+    heap.close()
+
+
+def test_notify_wait_across_threads():
+    vc = VirtualCluster(2, heap_bytes=1 << 20, backend="host")
+    lib = _lib.host()
+    sig = vc.collective(lambda r, env: env.heap.create_tensor_list([4], torch.int32, arena="sig"))
+    data = vc.collective(lambda r, env: env.heap.create_tensor_list([16], torch.float32))
+
+    def fn(r, env):
+        if r == 0:
+            time.sleep(0.05)
+            data[0][1].fill_(3.5)                                        # store into rank 1's copy
+            lib.tdh_notify32(ctypes.c_void_p(sig[0][1].data_ptr()), 1, 1)   # then signal rank 1
+            return None
+        rc = lib.tdh_wait32(ctypes.c_void_p(sig[1][1].data_ptr()), 1, 0, 1, ctypes.c_int64(5000))
+        assert rc == 0
+        return float(data[1][1].sum())
+
+    outs = vc.run(fn)
+    assert outs[1] == 3.5 * 16
+    vc.close()
+
+
+@pytest.mark.parametrize("w", [1, 2, 4])
+def test_ag_gemm_host_protocol(w):
+    M, N, K = 64 * w, 32 * w, 48
+    vc = VirtualCluster(w, heap_bytes=1 << 22, backend="host")
+    ctxs = vc.collective(lambda r, env: create_ag_gemm_intra_node_context(
+        M, N // w, K, torch.float32, torch.float32, r, w, M_PER_CHUNK=16, env=env))
+    for it in range(3):
+        a = [torch.randn(M // w, K) for _ in range(w)]
+        b = [torch.randn(N // w, K) for _ in range(w)]
+        outs = vc.run(lambda r, env: ag_gemm_intra_node(a[r], b[r], False, ctxs[r]))
+        full = torch.cat(a)
+        for r in range(w):
+            assert torch.allclose(outs[r], full @ b[r].t(), atol=1e-4)
+    vc.close()
+
+
+@pytest.mark.parametrize("w", [1, 2, 4])
+def test_gemm_rs_host_protocol(w):
+    M, N, K = 32 * w, 40, 24 * w
+    vc = VirtualCluster(w, heap_bytes=1 << 22, backend="host")
+    ctxs = vc.collective(lambda r, env: create_gemm_rs_intra_node_context(M, N, torch.float32, r, w, env=env))
+    for it in range(3):
+        a = [torch.randn(M, K // w) for _ in range(w)]
+        b = [torch.randn(N, K // w) for _ in range(w)]
+        outs = vc.run(lambda r, env: gemm_rs_intra_node(a[r], b[r], ctxs[r]))
+        full = sum(a[r] @ b[r].t() for r in range(w))
+        Mr = M // w
+        for r in range(w):
+            assert torch.allclose(outs[r], full[r * Mr:(r + 1) * Mr], atol=1e-4)
+    vc.close()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+WORKER = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from triton_distributed_gh_amd.utils import initialize_distributed, finalize_distributed
+from triton_distributed_gh_amd.ops.ag_gemm import create_ag_gemm_intra_node_context, ag_gemm_intra_node
+from triton_distributed_gh_amd.ops.gemm_rs import create_gemm_rs_intra_node_context, gemm_rs_intra_node
+import torch.distributed as dist
+env = initialize_distributed(seed=1, heap_bytes=1 << 22, force_host=True)
+r, w = env.rank, env.world_size
+M, N, K = 32 * w, 16 * w, 24
+ctx = create_ag_gemm_intra_node_context(M, N // w, K, torch.float32, torch.float32, r, w, M_PER_CHUNK=8)
+a, b = torch.randn(M // w, K), torch.randn(N // w, K)
+c = ag_gemm_intra_node(a, b, False, ctx)
+parts = [torch.empty_like(a) for _ in range(w)]
+dist.all_gather(parts, a, group=env.cpu_group)
+assert torch.allclose(c, torch.cat(parts) @ b.t(), atol=1e-4)
+ctx2 = create_gemm_rs_intra_node_context(M, N, torch.float32, r, w)
+a2, b2 = torch.randn(M, K), torch.randn(N, K)
+out = gemm_rs_intra_node(a2, b2, ctx2)
+full = a2 @ b2.t()
+dist.all_reduce(full, group=env.cpu_group)
+assert torch.allclose(out, full[r * (M // w):(r + 1) * (M // w)], atol=1e-4)
+finalize_distributed()
+print("WORKER_OK", r)
+"""
+
+
+def test_two_process_gloo_shared_memory_heap(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % str(ROOT))
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", LOCAL_WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"WORKER_OK {r}" in o, o[-2000:]

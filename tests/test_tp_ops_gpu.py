@@ -1,0 +1,87 @@
+"""AG-GEMM and GEMM-RS on virtual ranks of one GPU vs fp32 references.
+
+Scenarios follow the reference's python/triton_dist/test/amd/test_ag_gemm_intra_node.py and
+test_gemm_rs_intra_node.py (--check loops with fresh random inputs, atol/rtol 1e-2) plus a straggler
+rank (reference: kernels/nvidia/allgather_gemm.py:602-603 straggler_option).
+"""
+import pytest
+import torch
+
+from triton_distributed_gh_amd.ops.ag_gemm import ag_gemm_intra_node, create_ag_gemm_intra_node_context
+from triton_distributed_gh_amd.ops.gemm_rs import create_gemm_rs_intra_node_context, gemm_rs_intra_node
+from triton_distributed_gh_amd.utils.testing import VirtualCluster
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctas(w):
+    return max(8, 200 // w)
+
+
+@pytest.mark.parametrize("w,M,N,K,chunk,producer", [
+    (2, 1024, 1024, 256, 256, "kernel"),
+    (2, 2048, 1024, 512, 256, "kernel"),
+    (4, 2048, 2048, 512, 256, "kernel"),
+    (4, 256, 2048, 256, 256, "kernel"),       # 64 rows per rank: tiles straddle ranks
+    (8, 4096, 2048, 256, 256, "kernel"),
+    (8, 2048, 1024, 128, 128, "kernel"),
+])
+def test_ag_gemm_virtual_ranks(w, M, N, K, chunk, producer):
+    vc = VirtualCluster(w, heap_bytes=1 << 27)
+    try:
+        ctxs = vc.collective(lambda r, env: create_ag_gemm_intra_node_context(
+            M, N // w, K, torch.bfloat16, torch.bfloat16, r, w, M_PER_CHUNK=chunk, num_ctas=_ctas(w),
+            producer=producer, env=env))
+        for it in range(3):
+            a = [(torch.rand(M // w, K, device="cuda") * 2 - 1).bfloat16() for _ in range(w)]
+            b = [(torch.rand(N // w, K, device="cuda") * 2 - 1).bfloat16() for _ in range(w)]
+            torch.cuda.synchronize()
+
+            def step(r, env):
+                if it == 1 and r == w - 1:
+                    torch.cuda._sleep(20_000_000)   # straggler: this rank's push and GEMM start late
+                return ag_gemm_intra_node(a[r], b[r], False, ctxs[r])
+
+            outs = vc.run(step)
+            a_full = torch.cat(a).float()
+            for r in range(w):
+                ctxs[r].check_error()
+                ref = a_full @ b[r].float().t()
+                rel = (outs[r].float() - ref).abs().max().item() / ref.abs().max().item()
+                assert rel < 1e-2, f"rank {r} iteration {it}: {rel}"
+    finally:
+        vc.close()
+
+
+@pytest.mark.parametrize("w,M,N,K,chunk", [
+    (2, 1024, 1024, 512, 256),
+    (4, 2048, 1024, 1024, 256),
+    (4, 4096, 2048, 512, 512),
+    (8, 4096, 1024, 1024, 256),
+    (8, 512, 768, 2048, 256),       # 64 rows per rank
+])
+def test_gemm_rs_virtual_ranks(w, M, N, K, chunk):
+    vc = VirtualCluster(w, heap_bytes=1 << 27)
+    try:
+        ctxs = vc.collective(lambda r, env: create_gemm_rs_intra_node_context(
+            M, N, torch.bfloat16, r, w, M_PER_CHUNK=chunk, num_ctas=_ctas(w), env=env))
+        for it in range(3):
+            a = [(torch.rand(M, K // w, device="cuda") * 2 - 1).bfloat16() for _ in range(w)]
+            b = [(torch.rand(N, K // w, device="cuda") * 2 - 1).bfloat16() for _ in range(w)]
+            torch.cuda.synchronize()
+
+            def step(r, env):
+                if it == 1 and r == 0:
+                    torch.cuda._sleep(20_000_000)
+                return gemm_rs_intra_node(a[r], b[r], ctxs[r])
+
+            outs = vc.run(step)
+            partial = sum((a[r].float() @ b[r].float().t()).bfloat16().float() for r in range(w))
+            Mr = M // w
+            for r in range(w):
+                ctxs[r].check_error()
+                ref = partial[r * Mr:(r + 1) * Mr]
+                rel = (outs[r].float() - ref).abs().max().item() / ref.abs().max().item()
+                assert rel < 1e-2, f"rank {r} iteration {it}: {rel}"
+    finally:
+        vc.close()

@@ -46,6 +46,9 @@ HIPCC_FLAGS = [
     f"-I{CSRC / 'include'}",
     "-D__HIP_PLATFORM_AMD__",
 ]
+if os.environ.get("TDIST_SPIN_TIMEOUT_MS"):
+    # device-side spin budget in 100 MHz ticks (default in common.hpp: 15 s)
+    HIPCC_FLAGS.append(f"-DTDIST_SPIN_TIMEOUT_TICKS={int(os.environ['TDIST_SPIN_TIMEOUT_MS']) * 100000}ull")
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-pthread", f"-I{CSRC / 'include'}"]
 
 

@@ -109,10 +109,13 @@ template <typename T>
 __device__ __forceinline__ int wait(const T* barrier_ptrs, int num_barriers, int scope, int semantic,
                                     T wait_value = 1, int* err_word = nullptr) {
   int failed = 0;
+  // Once any wait of this launch has timed out the error word is sticky and later waits give up
+  // at once, so a lost peer costs one spin budget, not one per tile.
+  const bool dead = err_word && load_relaxed_agent(err_word) != 0;
   for (int i = threadIdx.x; i < num_barriers; i += blockDim.x) {
-    if (!spin_until_eq(barrier_ptrs + i, wait_value, scope)) failed = 1;
+    if (dead || !spin_until_eq(barrier_ptrs + i, wait_value, scope)) failed = 1;
   }
-  if (failed && err_word) atomicOr(err_word, 1);
+  if (failed && err_word && !dead) atomicOr(err_word, 1);
   // Only waves that polled need the cache invalidate; it covers the whole CU's L1, and the
   // barrier below orders every other wave's loads behind it.
   const int wave_first = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
@@ -140,6 +143,19 @@ template <typename T>
 __device__ __forceinline__ T* consume_token(T* value, int token) {
   asm volatile("" : "+v"(token)::"memory");
   return value;
+}
+
+// Workgroup-uniform dynamic work fetch for persistent kernels: one thread draws the next ticket
+// from a device-wide counter and the value is returned in a scalar register to every wave.
+// The leading barrier is load-bearing: without a convergent operation between a trailing
+// `if (threadIdx.x == 0) {...}` block of the previous iteration and this one, hipcc threads thread
+// 0's path through both blocks, the loop becomes divergent and thread 0 falls out of step with the
+// workgroup's barriers.  `slot` is 4 bytes of LDS inside the kernel's single dynamic array.
+__device__ __forceinline__ int fetch_ticket_block(int* counter, volatile int* slot) {
+  __syncthreads();
+  if (threadIdx.x == 0) *slot = atomicAdd(counter, 1);
+  __syncthreads();
+  return __builtin_amdgcn_readfirstlane(*slot);
 }
 
 // Single-thread notify.  Call from ONE thread after the workgroup's stores were drained

@@ -1,0 +1,250 @@
+// GEMM + ReduceScatter, tile-pipelined, one persistent kernel per rank:
+//     out[M/w, N] = ReduceScatter_M( A[M, K_local] * B[N, K_local]^T ).
+//
+// Work items are handed out by a device-side ticket counter in this order (cpr = chunks per rank):
+//     GEMM(chunk 0), GEMM(chunk 1), REDUCE(chunk 0), GEMM(chunk 2), REDUCE(chunk 1), ... REDUCE(cpr-1)
+// GEMM(c) covers chunk c of EVERY destination rank, destinations visited as rank+1, rank+2, ...,
+// rank (own rows last), so in each step every xGMI link of the full mesh carries one stream.  The
+// epilogue of a tile stores its 256x256 block straight into the destination's symmetric scatter
+// buffer (segment = source rank).  A per-(destination, chunk) counter counts finished tiles; the
+// workgroup that completes a chunk raises flag[src_rank, chunk] = epoch on the destination
+// (system-scope release).  REDUCE(c) items wait until all w partials of chunk c have landed
+// locally and sum them in fp32.  Because REDUCE(c) is queued behind GEMM(c+1), the reduction of a
+// chunk overlaps the GEMM of the next one and only the last chunk's reduction is exposed.
+//
+// The reference's AMD version is barrier - GEMM(fuse scatter) - barrier - reduce with bf16
+// accumulation (reference: python/triton_dist/kernels/amd/gemm_reduce_scatter.py:125-365); its
+// NVIDIA version pipelines per segment with a separate reduction stream
+// (kernels/nvidia/gemm_reduce_scatter.py:121-250, reduce_scatter.py:600-697).  Here scatter
+// buffers and flags are double-buffered by call parity and flags carry the call's epoch, so no
+// cross-rank barrier is needed at all.
+#include "tdist/common.hpp"
+#include "tdist/gemm_gfx950.hpp"
+#include "tdist/primitives.hpp"
+
+using namespace tdist;
+using namespace tdist::gemm;
+
+struct GemmRsParams {
+  SymmCtx ctx;
+  const uint16_t* A;     // [M, K_local]
+  const uint16_t* B;     // [N, K_local]
+  uint16_t* scatter;     // symmetric, this parity: [w][M_per_rank][N]
+  int* flags;            // symmetric (signal arena), this parity: [w * cpr]
+  int* counters;         // local [w * cpr + 4]; counters[w*cpr] is the ticket. zeroed before launch
+  int* err;
+  uint16_t* out;         // [M_per_rank, N]
+  long long lda, ldb, ldo;
+  int M_per_rank, N, K;
+  int rows_per_chunk;
+  int epoch;
+  int* dbg;               // optional progress trace: [grid][4] ints (last item, stage, items done, spare)
+};
+
+constexpr int RS_TICKET_SLOT = LDS_BYTES;
+constexpr int RED_ROWS = 4;
+constexpr int RED_COLS = THREADS * 8;  // 4096 columns per item
+
+template <bool IS_BF16>
+__device__ __forceinline__ void reduce_item(const GemmRsParams& p, int c, int i, int cpr, int ncb) {
+  const int w = p.ctx.num_ranks;
+  // wait for every source's partial of chunk c
+  {
+    int failed = 0;
+    const bool dead = load_relaxed_agent(p.err) != 0;
+    if ((int)threadIdx.x < w) {
+      if (dead || !spin_until_eq(p.flags + threadIdx.x * cpr + c, p.epoch, SCOPE_SYS)) failed = 1;
+    }
+    if (failed && !dead) atomicOr(p.err, 1);
+    if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  const int rb = i / ncb, cb = i - rb * ncb;
+  const int col = cb * RED_COLS + threadIdx.x * 8;
+  const int row0 = c * p.rows_per_chunk + rb * RED_ROWS;
+  const int row_end = min(min(row0 + RED_ROWS, (c + 1) * p.rows_per_chunk), p.M_per_rank);
+  if (col < p.N) {
+    const long long seg_stride = (long long)p.M_per_rank * p.N;
+    for (int row = row0; row < row_end; ++row) {
+      const uint16_t* src = p.scatter + (long long)row * p.N + col;
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int s0 = 0; s0 < w; s0 += 4) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (s0 + u < w) v[u] = *(const uint4*)(src + (long long)(s0 + u) * seg_stride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (s0 + u < w) {
+            const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (IS_BF16) {
+                acc[2 * e] += __builtin_bit_cast(float, x[e] << 16);
+                acc[2 * e + 1] += __builtin_bit_cast(float, x[e] & 0xffff0000u);
+              } else {
+                typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+                const f16x2 h = __builtin_bit_cast(f16x2, x[e]);
+                acc[2 * e] += (float)h[0];
+                acc[2 * e + 1] += (float)h[1];
+              }
+            }
+          }
+      }
+      uint4 o;
+      o.x = Frag<IS_BF16>::pack2(acc[0], acc[1]);
+      o.y = Frag<IS_BF16>::pack2(acc[2], acc[3]);
+      o.z = Frag<IS_BF16>::pack2(acc[4], acc[5]);
+      o.w = Frag<IS_BF16>::pack2(acc[6], acc[7]);
+      *(uint4*)(p.out + (long long)row * p.ldo + col) = o;
+    }
+  }
+}
+
+template <bool IS_BF16>
+__global__ __launch_bounds__(THREADS, 2) void gemm_rs_kernel(GemmRsParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  volatile int* s_ticket = (volatile int*)(smem + RS_TICKET_SLOT);
+  const int w = p.ctx.num_ranks, rank = p.ctx.rank;
+  const int cpr = p.M_per_rank / p.rows_per_chunk;
+  const int mbpc = (p.rows_per_chunk + BM - 1) / BM;
+  const int num_pid_n = (p.N + BN - 1) / BN;
+  const int tiles_per_dc = mbpc * num_pid_n;          // tiles per (destination, chunk)
+  const int Gc = w * tiles_per_dc;                    // GEMM items per chunk
+  const int ncb = (p.N + RED_COLS - 1) / RED_COLS;
+  const int Rc = ((p.rows_per_chunk + RED_ROWS - 1) / RED_ROWS) * ncb;  // reduce items per chunk
+  const int S = Gc + Rc;
+  const int total = cpr * S;
+  int* ticket = p.counters + w * cpr;
+
+  while (true) {
+    const int item = fetch_ticket_block(ticket, s_ticket);
+    if (item >= total) break;
+    if (p.dbg && threadIdx.x == 0) { p.dbg[blockIdx.x * 4 + 0] = item; p.dbg[blockIdx.x * 4 + 1] = 1; }
+
+    bool is_gemm;
+    int c, i;
+    if (item < Gc) {
+      is_gemm = true;
+      c = 0;
+      i = item;
+    } else {
+      const int i2 = item - Gc;
+      const int blk = i2 / S, rem = i2 - blk * S;
+      if (blk < cpr - 1) {
+        if (rem < Gc) {
+          is_gemm = true;
+          c = blk + 1;
+          i = rem;
+        } else {
+          is_gemm = false;
+          c = blk;
+          i = rem - Gc;
+        }
+      } else {
+        is_gemm = false;
+        c = cpr - 1;
+        i = rem;
+      }
+    }
+
+    if (!is_gemm) {
+      reduce_item<IS_BF16>(p, c, i, cpr, ncb);
+      if (p.dbg && threadIdx.x == 0) { p.dbg[blockIdx.x * 4 + 1] = 5; p.dbg[blockIdx.x * 4 + 2] += 1; }
+      continue;
+    }
+
+    const int dd = i / tiles_per_dc;
+    const int rest = i - dd * tiles_per_dc;
+    const int b = rest / num_pid_n, pid_n = rest - b * num_pid_n;
+    const int d = (rank + 1 + dd) % w;
+    const int r_in = c * p.rows_per_chunk + b * BM;    // row inside the destination's shard
+    const int rows = min(BM, min((c + 1) * p.rows_per_chunk, p.M_per_rank) - r_in);
+    const int g0 = d * p.M_per_rank + r_in;
+
+    TileArgs t;
+    t.A = p.A + (long long)g0 * p.lda;
+    t.B = p.B + (long long)pid_n * BN * p.ldb;
+    t.lda = p.lda;
+    t.ldb = p.ldb;
+    t.a_rows = rows;
+    t.b_rows = p.N - pid_n * BN;
+    t.K = p.K;
+    Acc<IS_BF16> acc;
+    mainloop_256<IS_BF16>(t, smem, acc);
+    if (p.dbg && threadIdx.x == 0) p.dbg[blockIdx.x * 4 + 1] = 2;
+
+    uint16_t* dst_buf = (d == rank) ? p.scatter : symm_at(p.ctx, p.scatter, d);
+    uint16_t* cbase = dst_buf + ((long long)rank * p.M_per_rank + r_in) * p.N + pid_n * BN;
+    const int nrem = p.N - pid_n * BN;
+    const long long ldn = p.N;
+    epilogue_256<IS_BF16>(acc, smem, [&](int r, int cc, const uint4& v) {
+      if (r < rows && cc < nrem) *(uint4*)(cbase + (long long)r * ldn + cc) = v;
+    });
+    if (p.dbg && threadIdx.x == 0) p.dbg[blockIdx.x * 4 + 1] = 3;
+    // publish: every wave drains and writes back its stores, then one thread counts the tile
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int prev = atom_add_acqrel_agent(p.counters + d * cpr + c, 1);
+      if (prev == tiles_per_dc - 1) {
+        int* flag = ((d == rank) ? p.flags : symm_at(p.ctx, p.flags, d)) + rank * cpr + c;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        store_relaxed_system(flag, p.epoch);
+      }
+    }
+  }
+}
+
+TDIST_API int tdist_gemm_rs(const tdist::SymmCtx* ctx, const void* A, const void* B, void* scatter, int* flags,
+                            int* counters, int* err, void* out, long long lda, long long ldb, long long ldo,
+                            int M_per_rank, int N, int K, int rows_per_chunk, int epoch, int num_ctas, int dtype,
+                            void* stream, int* dbg) {
+  TDIST_REQUIRE(K >= 128 && K % 64 == 0, "K must be a multiple of 64 and >= 128");
+  TDIST_REQUIRE(N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldo % 8 == 0, "N/lda/ldb/ldo must be multiples of 8");
+  TDIST_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)out | (uintptr_t)scatter) & 15) == 0,
+                "operands must be 16-byte aligned");
+  TDIST_REQUIRE(M_per_rank > 0 && rows_per_chunk > 0 && M_per_rank % rows_per_chunk == 0,
+                "M_per_rank must be a positive multiple of rows_per_chunk");
+  const int w = ctx->num_ranks;
+  TDIST_REQUIRE(w >= 1 && w <= TDIST_MAX_RANKS, "bad world size");
+  GemmRsParams p;
+  p.ctx = *ctx;
+  p.A = (const uint16_t*)A;
+  p.B = (const uint16_t*)B;
+  p.scatter = (uint16_t*)scatter;
+  p.flags = flags;
+  p.counters = counters;
+  p.err = err;
+  p.out = (uint16_t*)out;
+  p.lda = lda;
+  p.ldb = ldb;
+  p.ldo = ldo;
+  p.M_per_rank = M_per_rank;
+  p.N = N;
+  p.K = K;
+  p.rows_per_chunk = rows_per_chunk;
+  p.epoch = epoch;
+  p.dbg = dbg;
+  const int cpr = M_per_rank / rows_per_chunk;
+  const size_t counter_bytes = (((size_t)(w * cpr + 4) * sizeof(int)) + 15) & ~(size_t)15;
+  static bool attr_set = false;
+  if (!attr_set) {
+    TDIST_HIP_TRY(hipFuncSetAttribute((const void*)gemm_rs_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      LDS_BYTES + 16));
+    TDIST_HIP_TRY(hipFuncSetAttribute((const void*)gemm_rs_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      LDS_BYTES + 16));
+    attr_set = true;
+  }
+  TDIST_HIP_TRY(hipMemsetAsync(counters, 0, counter_bytes, (hipStream_t)stream));
+  int grid = num_ctas > 0 ? num_ctas : 256;
+  if (dtype == 0)
+    hipLaunchKernelGGL(gemm_rs_kernel<true>, dim3(grid), dim3(THREADS), LDS_BYTES + 16, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(gemm_rs_kernel<false>, dim3(grid), dim3(THREADS), LDS_BYTES + 16, (hipStream_t)stream, p);
+  TDIST_HIP_TRY(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,252 @@
+"""AllGather + GEMM (tensor-parallel column-parallel linear with sequence-sharded input).
+
+    C[M, N_local] = AllGather_M(a[M/w, K]) @ b[N_local, K]^T
+
+API-compatible with the reference's AMD op
+(reference: python/triton_dist/kernels/amd/all_gather_gemm.py:316-433 -
+``create_ag_gemm_intra_node_context`` / ``ag_gemm_intra_node``), redesigned for an MI355X node:
+
+* producer = full-mesh push over the w-1 xGMI links, by a push kernel (default: device-side
+  stores + system-scope flag stores, peers rotated per workgroup so all links are busy) or on the
+  SDMA copy engines (one C call issues every copy + flag write);
+* consumer = persistent gfx950 MFMA GEMM (csrc/ops/ag_gemm.hip) pulling tiles in arrival order
+  and waiting on per-(source, chunk) epoch flags;
+* workspaces and flags are double-buffered by call parity, so a call needs no flag reset and no
+  cross-rank barrier (the reference does ``fill_(0)`` + ``barrier_all_ipc`` after every GEMM).
+  Rank A can be at most one call ahead of rank B: A's push n+2 is ordered after A's GEMM n+1,
+  which needs B's push n+1, which B issues after its GEMM n.
+
+On a CPU-only machine the same protocol (workspaces in shared memory, flags as atomics) runs
+through the host runtime so the plumbing is testable without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import dataclasses
+import os
+from typing import Any, List, Optional
+
+import torch
+
+from .. import _lib
+from ..utils.distributed import get_env
+from .gemm import _DT, gemm_nt
+
+EPOCH_MOD = 4093
+_BM = 256
+
+
+@dataclasses.dataclass(repr=False)
+class AllGatherGEMMTensorParallelContext:
+    rank: int
+    num_ranks: int
+    max_M: int
+    N: int
+    K: int
+    dtype: torch.dtype
+    workspaces: List[List[torch.Tensor]]        # [parity][rank] -> [max_M, K]
+    flags: List[List[torch.Tensor]]             # [parity][rank] -> int32 [max chunks]
+    epoch_table: Optional[torch.Tensor]
+    scratch: Optional[torch.Tensor]             # int32: [0:4] ticket, [4:8] error word, [8:] push counters
+    env: Any = None
+    ag_streams: Optional[List["torch.cuda.Stream"]] = None
+    serial: bool = False
+    M_PER_CHUNK: int = 256
+    BLOCK_M: int = 256
+    BLOCK_N: int = 256
+    BLOCK_K: int = 64
+    stages: int = 2
+    autotune: bool = False
+    producer: str = "kernel"                    # "kernel" | "copy_engine"
+    flag_mode: str = "memcpy"                   # copy-engine flags: "memcpy" | "write_value"
+    num_ctas: int = 0                           # 0 = one workgroup per CU
+    call_count: int = 0
+    backend: str = "hip"
+
+    # names the reference exposes on its context
+    @property
+    def workspace_tensors(self):
+        return self.workspaces[self.call_count & 1]
+
+    @property
+    def barrier_tensors(self):
+        return self.flags[self.call_count & 1]
+
+    def check_error(self) -> None:
+        if self.scratch is not None and int(self.scratch[4]) != 0:
+            raise RuntimeError("ag_gemm: a device-side wait timed out (peer data never arrived)")
+
+
+def create_ag_gemm_intra_node_context(max_M, N, K, input_dtype, output_dtype, rank, num_ranks, tp_group=None,
+                                      ag_streams=None, M_PER_CHUNK=256, BLOCK_M=256, BLOCK_N=256, BLOCK_K=64,
+                                      stages=2, serial=False, autotune=False, producer=None, num_ctas=0, env=None):
+    """Collective.  ``N`` is the per-rank N of the weight shard; ``max_M`` the gathered row count."""
+    env = env or get_env()
+    assert max_M % num_ranks == 0, "max_M must be divisible by the number of ranks"
+    heap = env.heap
+    min_chunk = 16
+    max_chunks = num_ranks * max(1, (max_M // num_ranks + min_chunk - 1) // min_chunk)
+    workspaces, flags = [], []
+    for _ in range(2):
+        workspaces.append(heap.create_tensor_list([max_M, K], input_dtype, zero=False))
+        flags.append(heap.create_tensor_list([max_chunks], torch.int32, arena="sig"))
+    # "kernel": push kernel (device-side stores + system-scope flag), no driver-dependent ordering.
+    # "copy_engine": SDMA copies; flags by 4-byte copies (as the reference) or stream write-value.
+    producer = producer or os.environ.get("TDIST_AG_PRODUCER", "kernel")
+    epoch_table = scratch = None
+    if env.backend == "hip":
+        epoch_table = torch.arange(EPOCH_MOD + 2, dtype=torch.int32, device=env.device)
+        scratch = torch.zeros(8 + max_chunks, dtype=torch.int32, device=env.device)
+        if ag_streams is None and num_ranks > 1:
+            # one hardware queue per peer link for the copy engines; the push kernel needs one
+            n_streams = num_ranks - 1 if producer == "copy_engine" else 1
+            ag_streams = [torch.cuda.Stream(priority=-1) for _ in range(n_streams)]
+        torch.cuda.synchronize()
+    if env.cpu_group is not None:
+        torch.distributed.barrier(group=env.cpu_group)
+    return AllGatherGEMMTensorParallelContext(
+        rank=rank, num_ranks=num_ranks, max_M=max_M, N=N, K=K, dtype=input_dtype, workspaces=workspaces, flags=flags,
+        epoch_table=epoch_table, scratch=scratch, env=env, ag_streams=ag_streams, serial=serial,
+        M_PER_CHUNK=M_PER_CHUNK, BLOCK_M=BLOCK_M, BLOCK_N=BLOCK_N, BLOCK_K=BLOCK_K, stages=stages, autotune=autotune,
+        producer=producer,
+        flag_mode=os.environ.get("TDIST_AG_FLAG_MODE", "write_value" if env.shared_gpu else "memcpy"),
+        num_ctas=num_ctas, backend=env.backend)
+
+
+def _rows_per_chunk(M_per_rank: int, want: int) -> int:
+    if want > 0 and M_per_rank % want == 0:
+        return want
+    return M_per_rank
+
+
+def _push_copy_engine(ctx, a, parity, epoch, rpc, include_self):
+    heap, lib = ctx.env.heap, _lib.hip()
+    w, rank = ctx.num_ranks, ctx.rank
+    M_per_rank, K = a.shape
+    ws_ptrs = (ctypes.c_uint64 * w)(*[heap.peer_ptr(ctx.workspaces[parity][rank], r) for r in range(w)])
+    fl_ptrs = (ctypes.c_uint64 * w)(*[heap.peer_ptr(ctx.flags[parity][rank], r) for r in range(w)])
+    streams = (ctypes.c_void_p * len(ctx.ag_streams))(*[s.cuda_stream for s in ctx.ag_streams])
+    flag_src = ctx.epoch_table.data_ptr() + 4 * epoch
+    _lib.check(
+        lib.tdist_ag_push_full_mesh(rank, w, _lib.ptr(a), ws_ptrs, fl_ptrs, ctypes.c_void_p(flag_src),
+                                    ctypes.c_longlong(M_per_rank), ctypes.c_longlong(rpc),
+                                    ctypes.c_longlong(K * a.element_size()), streams, len(ctx.ag_streams), 1,
+                                    0 if ctx.flag_mode == "memcpy" else 1, epoch), "tdist_ag_push_full_mesh")
+    if include_self:
+        s = ctx.ag_streams[0]
+        nbytes = M_per_rank * K * a.element_size()
+        dst = ctx.workspaces[parity][rank].data_ptr() + rank * nbytes
+        _lib.check(lib.tdist_memcpy_async(ctypes.c_void_p(dst), _lib.ptr(a), ctypes.c_size_t(nbytes), 0,
+                                          _lib.stream_handle(s)), "local shard copy")
+        cpr = M_per_rank // rpc
+        for c in range(cpr):
+            fp = ctx.flags[parity][rank].data_ptr() + 4 * (rank * cpr + c)
+            _lib.check(lib.tdist_stream_write_value32(_lib.stream_handle(s), ctypes.c_void_p(fp), epoch), "local flag")
+
+
+def _push_kernel(ctx, a, parity, epoch, rpc, include_self, stream):
+    lib = _lib.hip()
+    M_per_rank, K = a.shape
+    cstruct = ctx.env.heap.ctx_struct()
+    chunk_bytes = rpc * K * a.element_size()
+    slices = max(1, min(16, chunk_bytes // (256 * 1024)))
+    _lib.check(
+        lib.tdist_ag_push_kernel(ctypes.byref(cstruct), _lib.ptr(a), _lib.ptr(ctx.workspaces[parity][ctx.rank]),
+                                 _lib.ptr(ctx.flags[parity][ctx.rank]), _lib.ptr(ctx.scratch[8:]),
+                                 ctypes.c_longlong(K * a.element_size()), M_per_rank, rpc, slices, epoch,
+                                 1 if include_self else 0, _lib.stream_handle(stream)), "tdist_ag_push_kernel")
+
+
+def ag_gemm_intra_node_op(a, b, c, ctx: AllGatherGEMMTensorParallelContext):
+    env = ctx.env
+    w, rank = ctx.num_ranks, ctx.rank
+    M_per_rank, K = a.shape
+    N_local = b.shape[0]
+    assert K == b.shape[1] == ctx.K, "K mismatch with the context"
+    assert M_per_rank * w <= ctx.max_M, "M exceeds the context's max_M"
+    assert a.dtype == b.dtype == ctx.dtype
+    if w == 1 and os.environ.get("TDIST_FORCE_FUSED", "0") != "1":
+        gemm_nt(a, b, out=c)
+        return c
+    a = a.contiguous()
+    parity = ctx.call_count & 1
+    epoch = ctx.call_count % EPOCH_MOD + 1
+    ctx.call_count += 1
+    rpc = _rows_per_chunk(M_per_rank, ctx.M_PER_CHUNK)
+    straddle = M_per_rank % _BM != 0
+
+    if ctx.backend == "host":
+        return _ag_gemm_host(a, b, c, ctx, parity, epoch, rpc)
+
+    lib = _lib.hip()
+    cur = torch.cuda.current_stream()
+    used = []
+    if w > 1:
+        if ctx.producer == "kernel":
+            side = ctx.ag_streams[0]
+            side.wait_stream(cur)
+            _push_kernel(ctx, a, parity, epoch, rpc, straddle, side)
+            used = [side]
+        else:
+            for s in ctx.ag_streams:
+                s.wait_stream(cur)
+            _push_copy_engine(ctx, a, parity, epoch, rpc, straddle)
+            used = ctx.ag_streams
+        if ctx.serial:
+            for s in used:
+                cur.wait_stream(s)
+            torch.cuda.synchronize()
+            if env.cpu_group is not None:
+                torch.distributed.barrier(group=env.cpu_group)
+
+    ws = ctx.workspaces[parity][rank]
+    _lib.check(
+        lib.tdist_ag_gemm_consumer(_lib.ptr(a), _lib.ptr(ws), _lib.ptr(b), _lib.ptr(c), _lib.ptr(ctx.flags[parity][rank]),
+                                   _lib.ptr(ctx.scratch), _lib.ptr(ctx.scratch[4:]), ctypes.c_longlong(a.stride(0)),
+                                   ctypes.c_longlong(ws.stride(0)), ctypes.c_longlong(b.stride(0)),
+                                   ctypes.c_longlong(c.stride(0)), M_per_rank, N_local, K, rank, w, rpc, epoch,
+                                   1 if (straddle and w > 1) else 0, ctx.num_ctas, _DT[a.dtype],
+                                   _lib.stream_handle(cur)), "tdist_ag_gemm_consumer")
+    # `a` is read by the side streams; joining them keeps the caller free to reuse it in stream order
+    for s in used:
+        cur.wait_stream(s)
+    return c
+
+
+def _ag_gemm_host(a, b, c, ctx, parity, epoch, rpc):
+    """CPU emulation of the same protocol over the shared-memory heap."""
+    lib = _lib.host()
+    w, rank = ctx.num_ranks, ctx.rank
+    M_per_rank, K = a.shape
+    cpr = M_per_rank // rpc
+    for i in range(1, w):
+        peer = (rank + i) % w
+        for ch in range(cpr):
+            r0 = rank * M_per_rank + ch * rpc
+            ctx.workspaces[parity][peer][r0:r0 + rpc].copy_(a[ch * rpc:(ch + 1) * rpc])
+            lib.tdh_notify32(ctypes.c_void_p(ctx.flags[parity][peer].data_ptr() + 4 * (rank * cpr + ch)), epoch, 1)
+    ws = ctx.workspaces[parity][rank]
+    for s in range(w):
+        rows = slice(s * M_per_rank, (s + 1) * M_per_rank)
+        if s == rank:
+            src = a
+        else:
+            rc = lib.tdh_wait32(ctypes.c_void_p(ctx.flags[parity][rank].data_ptr() + 4 * s * cpr), cpr, 0, epoch,
+                                ctypes.c_int64(60000))
+            if rc != 0:
+                raise RuntimeError(f"ag_gemm(host): rank {rank} timed out waiting for rank {s}")
+            src = ws[rows]
+        c[rows] = (src.float() @ b.float().t()).to(c.dtype)
+    return c
+
+
+def ag_gemm_intra_node(a, b, transe_b=False, ctx: Optional[AllGatherGEMMTensorParallelContext] = None):
+    """a: [M_per_rank, K], b: [N_per_rank, K] (``transe_b=False``).  Returns [M, N_per_rank]."""
+    if ctx is None:
+        raise RuntimeError("ag_gemm_intra_node requires a context (symmetric workspaces)")
+    if transe_b:
+        b = b.t().contiguous()
+    M_per_rank = a.shape[0]
+    N_local = b.shape[0]
+    c = torch.empty([ctx.num_ranks * M_per_rank, N_local], dtype=a.dtype, device=a.device)
+    return ag_gemm_intra_node_op(a, b, c, ctx)

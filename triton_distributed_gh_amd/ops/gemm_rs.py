@@ -1,0 +1,150 @@
+"""GEMM + ReduceScatter (tensor-parallel row-parallel linear producing sequence-sharded output).
+
+    out[M/w, N] = ReduceScatter_M( a[M, K_local] @ b[N, K_local]^T )
+
+API-compatible with the reference's AMD op
+(reference: python/triton_dist/kernels/amd/gemm_reduce_scatter.py:368-446 -
+``create_gemm_rs_intra_node_context`` / ``gemm_rs_intra_node``).  The MI355X kernel
+(csrc/ops/gemm_rs.hip) is ONE persistent launch that interleaves GEMM tiles, peer stores over xGMI,
+per-chunk epoch flags and the fp32 reduction; see that file for the protocol.  The scatter buffers
+and flags are double-buffered by call parity: rank A can be at most one call ahead of rank B
+(A's call n+1 reduction needs B's call n+1 partials), so call n+2 never overwrites data of call n
+that B is still reducing.
+"""
+from __future__ import annotations
+
+import ctypes
+import dataclasses
+import os
+from typing import Any, List, Optional
+
+import torch
+
+from .. import _lib
+from ..utils.distributed import get_env
+from .gemm import _DT, gemm_nt
+
+EPOCH_MOD = 4093
+
+
+@dataclasses.dataclass(repr=False)
+class GEMMReduceScatterTensorParallelContext:
+    rank: int
+    num_ranks: int
+    max_M: int
+    N: int
+    output_dtype: torch.dtype
+    scatter: List[List[torch.Tensor]]          # [parity][rank] -> [max_M, N] viewed as [w, M_per_rank, N]
+    flags: List[List[torch.Tensor]]            # [parity][rank] -> int32 [w * max chunks]
+    scratch: Optional[torch.Tensor]            # int32 counters + ticket, error word at the end
+    env: Any = None
+    fuse_scatter: bool = True
+    transpose_weight: bool = False
+    M_PER_CHUNK: int = 256
+    num_ctas: int = 0
+    call_count: int = 0
+    backend: str = "hip"
+
+    @property
+    def scatter_bufs(self):
+        return self.scatter[self.call_count & 1]
+
+    @property
+    def sync_bufs(self):
+        return self.flags[self.call_count & 1]
+
+    def check_error(self) -> None:
+        if self.scratch is not None and int(self.scratch[-4]) != 0:
+            raise RuntimeError("gemm_rs: a device-side wait timed out (peer partials never arrived)")
+
+
+def create_gemm_rs_intra_node_context(max_M, N, output_dtype, rank, num_ranks, tp_group=None, fuse_scatter=True,
+                                      transpose_weight=False, M_PER_CHUNK=256, num_ctas=0, env=None):
+    """Collective.  ``max_M`` is the full (pre-scatter) row count, ``N`` the output width."""
+    if not fuse_scatter:
+        raise NotImplementedError("only the fused-scatter epilogue exists")
+    if transpose_weight:
+        raise NotImplementedError("weights are [N, K_local] (K contiguous)")
+    env = env or get_env()
+    assert max_M % num_ranks == 0
+    heap = env.heap
+    max_chunks = num_ranks * max(1, (max_M // num_ranks + 15) // 16)
+    scatter, flags = [], []
+    for _ in range(2):
+        scatter.append(heap.create_tensor_list([max_M, N], output_dtype, zero=False))
+        flags.append(heap.create_tensor_list([max_chunks], torch.int32, arena="sig"))
+    scratch = None
+    if env.backend == "hip":
+        scratch = torch.zeros(max_chunks + 16, dtype=torch.int32, device=env.device)
+        torch.cuda.synchronize()
+    if env.cpu_group is not None:
+        torch.distributed.barrier(group=env.cpu_group)
+    return GEMMReduceScatterTensorParallelContext(rank=rank, num_ranks=num_ranks, max_M=max_M, N=N,
+                                                  output_dtype=output_dtype, scatter=scatter, flags=flags,
+                                                  scratch=scratch, env=env, fuse_scatter=fuse_scatter,
+                                                  transpose_weight=transpose_weight, M_PER_CHUNK=M_PER_CHUNK,
+                                                  num_ctas=num_ctas, backend=env.backend)
+
+
+def _rows_per_chunk(M_per_rank: int, want: int) -> int:
+    # chunks must be whole 256-row tiles (or the whole shard) so tiles never straddle chunks
+    if want > 0 and want % 256 == 0 and M_per_rank % want == 0:
+        return want
+    return M_per_rank
+
+
+def gemm_rs_intra_node_op(a, b, ctx: GEMMReduceScatterTensorParallelContext, out=None):
+    env = ctx.env
+    w, rank = ctx.num_ranks, ctx.rank
+    M, K_local = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K_local and N == ctx.N and M <= ctx.max_M and M % w == 0
+    assert a.dtype == b.dtype == ctx.output_dtype, "partials travel in the output dtype"
+    M_per_rank = M // w
+    if out is None:
+        out = torch.empty((M_per_rank, N), dtype=ctx.output_dtype, device=a.device)
+    if w == 1 and os.environ.get("TDIST_FORCE_FUSED", "0") != "1":
+        gemm_nt(a, b, out=out)
+        return out
+    parity = ctx.call_count & 1
+    epoch = ctx.call_count % EPOCH_MOD + 1
+    ctx.call_count += 1
+    rpc = _rows_per_chunk(M_per_rank, ctx.M_PER_CHUNK)
+    if ctx.backend == "host":
+        return _gemm_rs_host(a, b, out, ctx, parity, epoch)
+    a = a.contiguous()
+    lib = _lib.hip()
+    cstruct = env.heap.ctx_struct()
+    _lib.check(
+        lib.tdist_gemm_rs(ctypes.byref(cstruct), _lib.ptr(a), _lib.ptr(b), _lib.ptr(ctx.scatter[parity][rank]),
+                          _lib.ptr(ctx.flags[parity][rank]), _lib.ptr(ctx.scratch), _lib.ptr(ctx.scratch[-4:]),
+                          _lib.ptr(out), ctypes.c_longlong(a.stride(0)), ctypes.c_longlong(b.stride(0)),
+                          ctypes.c_longlong(out.stride(0)), M_per_rank, N, K_local, rpc, epoch, ctx.num_ctas,
+                          _DT[a.dtype], _lib.stream_handle(), _lib.ptr(getattr(ctx, "debug_trace", None))),
+        "tdist_gemm_rs")
+    return out
+
+
+def _gemm_rs_host(a, b, out, ctx, parity, epoch):
+    lib = _lib.host()
+    w, rank = ctx.num_ranks, ctx.rank
+    M = a.shape[0]
+    N = b.shape[0]
+    M_per_rank = M // w
+    partial = (a.float() @ b.float().t()).to(out.dtype)
+    for i in range(1, w + 1):
+        d = (rank + i) % w
+        seg = ctx.scatter[parity][d].view(-1)[: w * M_per_rank * N].view(w, M_per_rank, N)
+        seg[rank].copy_(partial[d * M_per_rank:(d + 1) * M_per_rank])
+        lib.tdh_notify32(ctypes.c_void_p(ctx.flags[parity][d].data_ptr() + 4 * rank), epoch, 1)
+    rc = lib.tdh_wait32(ctypes.c_void_p(ctx.flags[parity][rank].data_ptr()), w, 0, epoch, ctypes.c_int64(60000))
+    if rc != 0:
+        raise RuntimeError(f"gemm_rs(host): rank {rank} timed out waiting for partials")
+    seg = ctx.scatter[parity][rank].view(-1)[: w * M_per_rank * N].view(w, M_per_rank, N)
+    out.copy_(seg.float().sum(dim=0).to(out.dtype))
+    return out
+
+
+def gemm_rs_intra_node(a, b, ctx: GEMMReduceScatterTensorParallelContext):
+    """a: [M, K_local], b: [N, K_local].  Returns [M // world_size, N]."""
+    return gemm_rs_intra_node_op(a, b, ctx)

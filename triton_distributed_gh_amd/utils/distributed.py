@@ -115,6 +115,20 @@ def initialize_distributed(seed: Optional[int] = None, heap_bytes: Optional[int]
     return _ENV
 
 
+def create_virtual_node(world_size: int, heap_bytes: int = 1 << 28, sig_bytes: int = 1 << 22,
+                        backend: Optional[str] = None):
+    """``world_size`` ranks hosted by THIS process (one DistEnv per virtual rank, no process
+    group).  Every rank's symmetric arena is an ordinary allocation of this process, so fused
+    multi-rank kernels can be exercised on one GPU by launching each rank's op on its own stream.
+    Hardware queues: a rank that spins on a peer must not share a queue with it, so run with
+    GPU_MAX_HW_QUEUES >= 2 * world_size (set before HIP initialises)."""
+    backend = backend or ("hip" if torch.cuda.is_available() else "host")
+    device = torch.device("cuda", torch.cuda.current_device()) if backend == "hip" else torch.device("cpu")
+    heaps = SymmetricHeap.create_virtual(world_size, backend, heap_bytes, sig_bytes)
+    return [DistEnv(r, r, world_size, world_size, device, backend, None, None, heaps[r], True, False)
+            for r in range(world_size)]
+
+
 def finalize_distributed() -> None:
     """Tear down heap and process groups (reference: python/triton_dist/utils.py:145-148)."""
     global _ENV

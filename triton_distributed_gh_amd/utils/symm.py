@@ -141,6 +141,45 @@ class SymmetricHeap:
             self._init_host()
         self._tensor_info = {}
 
+    @classmethod
+    def create_virtual(cls, world_size: int, backend: str, heap_bytes: int, sig_bytes: int = 1 << 22):
+        """``world_size`` heaps living in THIS process (no IPC): rank r's heap sees every other
+        virtual rank's arena at its real address.  Lets one process drive all ranks of a fused op on
+        separate streams of a single GPU - the test harness for multi-rank kernels on a 1-GPU box."""
+        assert world_size <= MAX_RANKS
+        bases = {"data": [], "sig": []}
+        owned = []
+        for arena, nbytes, mode in (("data", heap_bytes, 0), ("sig", sig_bytes, 1)):
+            for _ in range(world_size):
+                p = ctypes.c_void_p()
+                if backend == "hip":
+                    lib = _lib.hip()
+                    rc = lib.tdist_malloc(ctypes.byref(p), ctypes.c_size_t(nbytes), mode)
+                    if rc != 0 and mode != 0:
+                        rc = lib.tdist_malloc(ctypes.byref(p), ctypes.c_size_t(nbytes), 0)
+                    _lib.check(rc, "virtual arena allocation")
+                    _lib.check(lib.tdist_memset(p, 0, ctypes.c_size_t(nbytes)), "arena memset")
+                else:
+                    buf = ctypes.create_string_buffer(nbytes)
+                    owned.append(buf)
+                    p = ctypes.c_void_p(ctypes.addressof(buf))
+                bases[arena].append(p.value)
+        heaps = []
+        for r in range(world_size):
+            h = cls.__new__(cls)
+            h.rank, h.world_size, h.group, h.backend = r, world_size, None, backend
+            h.heap_bytes, h.sig_bytes = heap_bytes, sig_bytes
+            h._alloc = {"data": _FreeList(heap_bytes), "sig": _FreeList(sig_bytes)}
+            h._bases = {a: list(bases[a]) for a in bases}
+            wrap = _wrap_device if backend == "hip" else _wrap_host
+            h._flat = {a: [wrap(bases[a][p], heap_bytes if a == "data" else sig_bytes, owned) for p in range(world_size)]
+                       for a in bases}
+            h._owned = [bases[a][r] for a in bases] if backend == "hip" else []
+            h._opened, h._shm_names, h._closed, h._tensor_info = [], [], False, {}
+            h._virtual = True
+            heaps.append(h)
+        return heaps
+
     # ------------------------------------------------------------------ backends
     def _exchange(self, obj):
         if self.world_size == 1:
@@ -287,6 +326,8 @@ class SymmetricHeap:
             return
         self._closed = True
         self._flat = {"data": [], "sig": []}
+        if getattr(self, "_virtual", False) and self.backend == "host":
+            return
         if self.backend == "hip":
             lib = _lib.hip()
             try:

@@ -1,0 +1,76 @@
+"""Test harness: run every rank of a multi-rank op inside ONE process.
+
+``VirtualCluster(w)`` builds ``w`` virtual ranks (see ``create_virtual_node``).  ``run(fn)`` calls
+``fn(rank, env)`` once per rank:
+
+* hip backend  - sequentially on the host, each rank under its own torch stream; launches are
+  asynchronous, so all ranks' kernels are in flight together and meet through device-side flags;
+* host backend - one Python thread per rank (the CPU protocol blocks in C with the GIL released).
+
+This complements the torchrun-launched multi-process scripts (which exercise hipIpc and gloo/RCCL
+bootstrap): it needs no second process and no IPC, so it runs under plain ``pytest`` on a 1-GPU box.
+The reference has no such harness - all its tests need one real GPU per rank (reference:
+python/triton_dist/test/amd/*.py launched by scripts/launch_amd.sh).
+"""
+from __future__ import annotations
+
+import threading
+from typing import Callable, List
+
+import torch
+
+from .distributed import create_virtual_node
+
+
+class VirtualCluster:
+    def __init__(self, world_size: int, heap_bytes: int = 1 << 28, sig_bytes: int = 1 << 22, backend=None):
+        self.envs = create_virtual_node(world_size, heap_bytes, sig_bytes, backend)
+        self.world_size = world_size
+        self.backend = self.envs[0].backend
+        self.streams = ([torch.cuda.Stream() for _ in range(world_size)] if self.backend == "hip" else None)
+
+    def run(self, fn: Callable, sync: bool = True) -> List:
+        outs = [None] * self.world_size
+        if self.backend == "hip":
+            for r, env in enumerate(self.envs):
+                with torch.cuda.stream(self.streams[r]):
+                    outs[r] = fn(r, env)
+            if sync:
+                torch.cuda.synchronize()
+            return outs
+        errs = [None] * self.world_size
+
+        def work(r):
+            try:
+                outs[r] = fn(r, self.envs[r])
+            except BaseException as e:  # noqa: BLE001 - re-raised below on the main thread
+                errs[r] = e
+
+        threads = [threading.Thread(target=work, args=(r,)) for r in range(self.world_size)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for e in errs:
+            if e is not None:
+                raise e
+        return outs
+
+    def collective(self, fn: Callable) -> List:
+        """Run a collective constructor (symmetric allocation) rank by rank on the host."""
+        return [fn(r, env) for r, env in enumerate(self.envs)]
+
+    def close(self) -> None:
+        import sys
+
+        if sys.exc_info()[0] is not None:
+            # A test is failing: its report may still touch symmetric tensors (reading freed device
+            # memory is a GPU fault), so leak the arenas instead of freeing them.
+            return
+        if self.backend == "hip":
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                return  # the device is in an error state: freeing arenas now could fault again
+        for env in self.envs:
+            env.heap.close()
