@@ -1,0 +1,182 @@
+"""Headline benchmark: intra-node AG-GEMM + GEMM-RS latency, M=4096 N=K=8192 bf16, TP = --gpus.
+
+One step = one tensor-parallel MLP-style pair on every rank:
+    AG-GEMM : C1[M, N/w] = AllGather_M(A1[M/w, K]) @ W1[N/w, K]^T
+    GEMM-RS : C2[M/w, N] = ReduceScatter_M(A2[M, K/w] @ W2[N, K/w]^T)
+with M=4096, N=K=8192 (the shape BASELINE.json names; total work is fixed -> strong scaling).
+`value` is the per-step latency in microseconds (AG-GEMM + GEMM-RS, max over ranks); the two ops
+are also timed separately, and the same pair built from torch.matmul + RCCL collectives is timed in
+the same process as the yardstick the reference uses (reference:
+python/triton_dist/test/amd/test_gemm_rs_intra_node.py:48-64, layers/amd/tp_mlp.py:156-202).
+
+Launch:  python bench.py --gpus 1            (single process)
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+                --master-port P bench.py --gpus N --steps K --warmup W
+Synthetic data, random-init weights.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+M, N, K = 4096, 8192, 8192
+
+
+def _sync_all(env):
+    torch.cuda.synchronize()
+    if env.world_size > 1:
+        dist.barrier(group=env.cpu_group)
+    torch.cuda.synchronize()
+
+
+def _time_steps(env, fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    _sync_all(env)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    _sync_all(env)
+    dt = (time.perf_counter() - t0) / steps
+    if env.world_size > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=env.cpu_group)
+        dt = float(t[0])
+    return dt * 1e6  # us per step
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-baseline", action="store_true", help="skip the torch+RCCL yardstick")
+    args = ap.parse_args()
+
+    from triton_distributed_gh_amd.ops.ag_gemm import ag_gemm_intra_node, create_ag_gemm_intra_node_context
+    from triton_distributed_gh_amd.ops.gemm_rs import create_gemm_rs_intra_node_context, gemm_rs_intra_node
+    from triton_distributed_gh_amd.utils import finalize_distributed, initialize_distributed
+
+    env = initialize_distributed(seed=0)
+    w, r, dev = env.world_size, env.rank, env.device
+    assert w == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={w}"
+    dt = torch.bfloat16
+    ctas = max(8, 224 // w) if env.shared_gpu else 0
+
+    a1 = (torch.rand(M // w, K, device=dev) * 2 - 1).to(dt)
+    w1 = (torch.rand(N // w, K, device=dev) * 2 - 1).to(dt) * 0.05
+    a2 = (torch.rand(M, K // w, device=dev) * 2 - 1).to(dt)
+    w2 = (torch.rand(N, K // w, device=dev) * 2 - 1).to(dt) * 0.05
+
+    ag_ctx = create_ag_gemm_intra_node_context(M, N // w, K, dt, dt, r, w, env.tp_group, M_PER_CHUNK=256, num_ctas=ctas)
+    rs_ctx = create_gemm_rs_intra_node_context(M, N, dt, r, w, env.tp_group, M_PER_CHUNK=256, num_ctas=ctas)
+
+    # ---- torch + RCCL reference implementation of the same pair --------------------------------
+    a1_full = torch.empty(M, K, device=dev, dtype=dt)
+    c2_full = torch.empty(M, N, device=dev, dtype=dt)
+    c2_out = torch.empty(M // w, N, device=dev, dtype=dt)
+
+    def torch_ag_gemm():
+        if w > 1:
+            dist.all_gather_into_tensor(a1_full, a1, group=env.tp_group)
+            return torch.matmul(a1_full, w1.t())
+        return torch.matmul(a1, w1.t())
+
+    def torch_gemm_rs():
+        torch.matmul(a2, w2.t(), out=c2_full)
+        if w > 1:
+            dist.reduce_scatter_tensor(c2_out, c2_full, group=env.tp_group)
+            return c2_out
+        return c2_full
+
+    def fused_ag():
+        return ag_gemm_intra_node(a1, w1, False, ag_ctx)
+
+    def fused_rs():
+        return gemm_rs_intra_node(a2, w2, rs_ctx)
+
+    # ---- one checked step: the timed path must produce the reference's numbers ------------------
+    fused_ok = True
+    note = ""
+    try:
+        c1 = fused_ag()
+        c2 = fused_rs()
+        torch.cuda.synchronize()
+        ag_ctx.check_error()
+        rs_ctx.check_error()
+        if env.has_rccl or w == 1:
+            r1 = torch_ag_gemm().float()
+            r2 = torch_gemm_rs().float()
+            e1 = ((c1.float() - r1).abs().max() / r1.abs().max()).item()
+            e2 = ((c2.float() - r2).abs().max() / r2.abs().max()).item()
+            if not (e1 < 2e-2 and e2 < 2e-2):
+                fused_ok, note = False, f"fused result mismatch (rel err {e1:.3e}, {e2:.3e})"
+    except Exception as exc:  # noqa: BLE001 - reported in the JSON line, the run continues on RCCL
+        fused_ok, note = False, f"fused path failed: {exc}"
+    if w > 1:
+        flag = torch.tensor([1 if fused_ok else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=env.cpu_group)
+        fused_ok = bool(flag[0])
+
+    run_ag, run_rs = (fused_ag, fused_rs) if fused_ok else (torch_ag_gemm, torch_gemm_rs)
+
+    def step():
+        run_ag()
+        run_rs()
+
+    total_us = _time_steps(env, step, args.steps, args.warmup)
+    ag_us = _time_steps(env, run_ag, max(5, args.steps // 2), 3)
+    rs_us = _time_steps(env, run_rs, max(5, args.steps // 2), 3)
+    base_us = None
+    if not args.no_baseline and (env.has_rccl or w == 1):
+        def base_step():
+            torch_ag_gemm()
+            torch_gemm_rs()
+        base_us = _time_steps(env, base_step, max(5, args.steps // 2), 3)
+    if fused_ok:
+        try:
+            ag_ctx.check_error()
+            rs_ctx.check_error()
+        except Exception as exc:  # noqa: BLE001
+            note = f"device-side timeout during the timed loop: {exc}"
+
+    if r == 0:
+        flops = 2.0 * (2.0 * M * N * K) / w  # per GPU per step
+        out = {
+            "metric": "intranode AG-GEMM + GEMM-RS latency (us), M=4096 N=K=8192 bf16",
+            "value": round(total_us, 2),
+            "unit": "us",
+            "n_gpus": w,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(total_us / 1e3, 5),
+            "higher_is_better": False,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic (uniform random activations, random-init weights)",
+            "config": {"model": "TP MLP-style pair (AG-GEMM then GEMM-RS)", "M": M, "N": N, "K": K,
+                       "global_batch": M, "seq_len": 1, "parallelism": f"tp{w}"},
+            "ag_gemm_us": round(ag_us, 2),
+            "gemm_rs_us": round(rs_us, 2),
+            "torch_rccl_pair_us": None if base_us is None else round(base_us, 2),
+            "speedup_vs_torch_rccl": None if base_us is None else round(base_us / total_us, 4),
+            "tflops_per_gpu": round(flops / total_us / 1e6, 1),
+            "timed_path": "fused HIP kernels" if fused_ok else "torch.matmul + RCCL (fused path rejected)",
+            "note": note,
+        }
+        print(json.dumps(out), flush=True)
+    finalize_distributed()
+
+
+if __name__ == "__main__":
+    main()

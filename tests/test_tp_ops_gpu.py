@@ -31,7 +31,7 @@ def test_ag_gemm_virtual_ranks(w, M, N, K, chunk, producer):
     try:
         ctxs = vc.collective(lambda r, env: create_ag_gemm_intra_node_context(
             M, N // w, K, torch.bfloat16, torch.bfloat16, r, w, M_PER_CHUNK=chunk, num_ctas=_ctas(w),
-            producer=producer, env=env))
+            producer=producer, env=env, ag_streams=[vc.side_streams[r]]))
         for it in range(3):
             a = [(torch.rand(M // w, K, device="cuda") * 2 - 1).bfloat16() for _ in range(w)]
             b = [(torch.rand(N // w, K, device="cuda") * 2 - 1).bfloat16() for _ in range(w)]

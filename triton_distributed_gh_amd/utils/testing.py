@@ -3,9 +3,14 @@
 ``VirtualCluster(w)`` builds ``w`` virtual ranks (see ``create_virtual_node``).  ``run(fn)`` calls
 ``fn(rank, env)`` once per rank:
 
-* hip backend  - sequentially on the host, each rank under its own torch stream; launches are
+* hip backend  - sequentially on the host, each rank under its own stream; launches are
   asynchronous, so all ranks' kernels are in flight together and meet through device-side flags;
 * host backend - one Python thread per rank (the CPU protocol blocks in C with the GIL released).
+
+A rank that spins on a peer must not sit in front of that peer's work in the same hardware queue.
+torch's stream pool (64 streams per device) is mapped by HIP onto GPU_MAX_HW_QUEUES queues, so pool
+streams can collide; the harness therefore creates its own 2 streams per rank (compute + side)
+ONCE per process, straight from HIP, and hands them out as ``torch.cuda.ExternalStream``.
 
 This complements the torchrun-launched multi-process scripts (which exercise hipIpc and gloo/RCCL
 bootstrap): it needs no second process and no IPC, so it runs under plain ``pytest`` on a 1-GPU box.
@@ -14,12 +19,26 @@ python/triton_dist/test/amd/*.py launched by scripts/launch_amd.sh).
 """
 from __future__ import annotations
 
+import ctypes
+import sys
 import threading
 from typing import Callable, List
 
 import torch
 
+from .. import _lib
 from .distributed import create_virtual_node
+
+_POOL = {"main": [], "side": []}
+
+
+def _pool_streams(kind: str, n: int):
+    lib = _lib.hip()
+    while len(_POOL[kind]) < n:
+        h = ctypes.c_void_p()
+        _lib.check(lib.tdist_stream_create(ctypes.byref(h), 0), "hipStreamCreate")
+        _POOL[kind].append(torch.cuda.ExternalStream(h.value))
+    return _POOL[kind][:n]
 
 
 class VirtualCluster:
@@ -27,7 +46,15 @@ class VirtualCluster:
         self.envs = create_virtual_node(world_size, heap_bytes, sig_bytes, backend)
         self.world_size = world_size
         self.backend = self.envs[0].backend
-        self.streams = ([torch.cuda.Stream() for _ in range(world_size)] if self.backend == "hip" else None)
+        if self.backend == "hip":
+            # interleave creation so rank r's two streams get neighbouring hardware queues
+            for r in range(world_size):
+                _pool_streams("main", r + 1)
+                _pool_streams("side", r + 1)
+            self.streams = _pool_streams("main", world_size)
+            self.side_streams = _pool_streams("side", world_size)
+        else:
+            self.streams = self.side_streams = None
 
     def run(self, fn: Callable, sync: bool = True) -> List:
         outs = [None] * self.world_size
@@ -61,8 +88,6 @@ class VirtualCluster:
         return [fn(r, env) for r, env in enumerate(self.envs)]
 
     def close(self) -> None:
-        import sys
-
         if sys.exc_info()[0] is not None:
             # A test is failing: its report may still touch symmetric tensors (reading freed device
             # memory is a GPU fault), so leak the arenas instead of freeing them.
