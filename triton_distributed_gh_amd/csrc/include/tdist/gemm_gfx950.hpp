@@ -254,6 +254,134 @@ __device__ __forceinline__ void mainloop_256(const TileArgs& t, char* smem, Acc<
   if (!late_group) __builtin_amdgcn_s_barrier();
 }
 
+// Variant with TWO phases per K-step (32 MFMAs per compute segment instead of 16): half as many
+// barrier hand-overs between the two wave groups of a SIMD, at the price of a shorter prefetch
+// distance.  Phase 0 reads B0, B1, A0 and computes the upper 64 rows of the wave tile, phase 1
+// reads A1 and computes the lower 64 rows.  Staging: phase 0 of step t issues A0, A1 of step t+1,
+// phase 1 issues B0, B1 of step t+2 (their slots were read in phase 0 and retired by the counted
+// lgkmcnt before that phase's barrier; A1's reads are retired before phase 1's barrier).
+template <bool IS_BF16>
+__device__ __forceinline__ void mainloop_256_2ph(const TileArgs& t, char* smem, Acc<IS_BF16>& acc) {
+  using F = Frag<IS_BF16>;
+  using V = typename F::T;
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63;
+  const int wr = w >> 2, wc = w & 3;
+  const bool late_group = w >= 4;
+  const int hr = w * 16 + (l >> 2);
+  const int kchunk = (l & 3) ^ (((l >> 5) & 1) << 1);
+  int arow0 = (hr >> 6) * 128 + (hr & 63);
+  int arow1 = arow0 + 64;
+  int brow0 = (hr >> 5) * 64 + (hr & 31);
+  int brow1 = brow0 + 32;
+  arow0 = arow0 < t.a_rows ? arow0 : t.a_rows - 1;
+  arow1 = arow1 < t.a_rows ? arow1 : t.a_rows - 1;
+  brow0 = brow0 < t.b_rows ? brow0 : t.b_rows - 1;
+  brow1 = brow1 < t.b_rows ? brow1 : t.b_rows - 1;
+  const uint16_t* pa0 = t.A + (long long)arow0 * t.lda + kchunk * 8;
+  const uint16_t* pa1 = t.A + (long long)arow1 * t.lda + kchunk * 8;
+  const uint16_t* pb0 = t.B + (long long)brow0 * t.ldb + kchunk * 8;
+  const uint16_t* pb1 = t.B + (long long)brow1 * t.ldb + kchunk * 8;
+  const int nt = t.K / BK;
+  const int stage_sub = w * 2048;
+  auto stage = [&](int kt, auto kind_c) {
+    constexpr int kind = decltype(kind_c)::value;
+    if (kt < nt) {
+      const uint16_t* src = kind == 0 ? pb0 : (kind == 1 ? pa0 : (kind == 2 ? pb1 : pa1));
+      src += (long long)kt * BK;
+      char* dst = smem + (kt & 1) * BUF_BYTES + kind * HALF_BYTES + stage_sub;
+      __builtin_amdgcn_global_load_lds(TDIST_GLB_PTR(src), TDIST_LDS_PTR(dst), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(TDIST_GLB_PTR(src + 32), TDIST_LDS_PTR(dst + 1024), 16, 0, 0);
+    }
+  };
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+  using K2 = std::integral_constant<int, 2>;
+  using K3 = std::integral_constant<int, 3>;
+  const int lane_off = (((l & 15) * 64) + ((l >> 4) * 16)) ^ ((((l & 15) >> 3) & 1) << 5);
+  const char* a_rd = smem + wr * 8192 + lane_off;
+  const char* b_rd = smem + wc * 4096 + lane_off;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc.v[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  stage(0, K0{}); stage(0, K1{}); stage(0, K2{}); stage(0, K3{});
+  stage(1, K0{}); stage(1, K2{});
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (late_group) __builtin_amdgcn_s_barrier();
+
+  V a[4][2], b0[2][2], b1[2][2];
+  for (int kt = 0; kt < nt; ++kt) {
+    const int boff = (kt & 1) * BUF_BYTES;
+    // ---------------- phase 0: rows 0..63 of the wave tile ----------------
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) b0[n][ks] = *(const V*)(b_rd + boff + OFF_B0 + (n * 2 + ks) * 1024);
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) b1[n][ks] = *(const V*)(b_rd + boff + OFF_B1 + (n * 2 + ks) * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) a[m][ks] = *(const V*)(a_rd + boff + OFF_A0 + (m * 2 + ks) * 1024);
+    stage(kt + 1, K1{});
+    stage(kt + 1, K3{});
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc.v[m][n] = F::mfma(b0[n][ks], a[m][ks], acc.v[m][n]);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc.v[m][2 + n] = F::mfma(b1[n][ks], a[m][ks], acc.v[m][2 + n]);
+      }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---------------- phase 1: rows 64..127 of the wave tile ----------------
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) a[m][ks] = *(const V*)(a_rd + boff + OFF_A1 + (m * 2 + ks) * 1024);
+    stage(kt + 2, K0{});
+    stage(kt + 2, K2{});
+    if (kt + 2 < nt) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else if (kt + 1 < nt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc.v[4 + m][n] = F::mfma(b0[n][ks], a[m][ks], acc.v[4 + m][n]);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc.v[4 + m][2 + n] = F::mfma(b1[n][ks], a[m][ks], acc.v[4 + m][2 + n]);
+      }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  }
+  if (!late_group) __builtin_amdgcn_s_barrier();
+}
+
 // Convert the accumulators to 16-bit, stage the 256x256 tile in LDS and hand 16-byte row pieces to
 // `store(row_in_tile, col_in_tile, uint4)`; every thread calls store 16 times with rows
 // (pass*16 + tid/32) and columns (tid%32)*8.  Ends with a workgroup barrier so LDS may be reused.

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(THREADS, 2) void ag_gemm_consumer_kernel(AgGemmPara
     t.b_rows = p.N_local - pid_n * BN;
     t.K = p.K;
     Acc<IS_BF16> acc;
-    mainloop_256<IS_BF16>(t, smem, acc);
+    mainloop_256_2ph<IS_BF16>(t, smem, acc);
     const int nrem = p.N_local - pid_n * BN;
     uint16_t* cbase = p.C + (long long)g0 * p.ldc + pid_n * BN;
     const long long ldc = p.ldc;

@@ -11,12 +11,12 @@
 
 using namespace tdist::gemm;
 
-template <bool IS_BF16>
+template <bool IS_BF16, int VARIANT>
 __global__ __launch_bounds__(THREADS, 2) void gemm_nt_256_kernel(const uint16_t* __restrict__ A,
                                                                  const uint16_t* __restrict__ B,
                                                                  uint16_t* __restrict__ C, int M, int N, int K,
                                                                  long long lda, long long ldb, long long ldc,
-                                                                 int group_m) {
+                                                                 int group_m, int dbg_flags) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int num_pid_m = (M + BM - 1) / BM;
   const int num_pid_n = (N + BN - 1) / BN;
@@ -35,38 +35,39 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_256_kernel(const uint16_t*
   t.b_rows = N - col0;
   t.K = K;
   Acc<IS_BF16> acc;
-  mainloop_256<IS_BF16>(t, smem, acc);
+  if constexpr (VARIANT == 2)
+    mainloop_256_2ph<IS_BF16>(t, smem, acc);
+  else
+    mainloop_256<IS_BF16>(t, smem, acc);
   const int mrem = M - row0, nrem = N - col0;
   uint16_t* cbase = C + (long long)row0 * ldc + col0;
   epilogue_256<IS_BF16>(acc, smem, [&](int r, int c, const uint4& v) {
-    if (r < mrem && c < nrem) *(uint4*)(cbase + (long long)r * ldc + c) = v;
+    if (r < mrem && c < nrem && !(dbg_flags & 1)) *(uint4*)(cbase + (long long)r * ldc + c) = v;
   });
 }
 
 // dtype: 0 = bf16, 1 = fp16.  Requires K % 64 == 0, K >= 128, N % 8 == 0, 16-byte aligned rows.
 TDIST_API int tdist_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, long long lda,
-                            long long ldb, long long ldc, int dtype, int group_m, void* stream) {
+                            long long ldb, long long ldc, int dtype, int group_m, void* stream, int variant) {
   TDIST_REQUIRE(M > 0 && N > 0, "empty GEMM");
   TDIST_REQUIRE(K >= 128 && K % 64 == 0, "K must be a multiple of 64 and >= 128");
   TDIST_REQUIRE(N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0, "N/lda/ldb/ldc must be multiples of 8");
   TDIST_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0, "operands must be 16-byte aligned");
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   if (group_m <= 0) group_m = 8;
+  typedef void (*kern_t)(const uint16_t*, const uint16_t*, uint16_t*, int, int, int, long long, long long, long long, int, int);
+  kern_t table[2][2] = {{gemm_nt_256_kernel<true, 1>, gemm_nt_256_kernel<true, 2>},
+                        {gemm_nt_256_kernel<false, 1>, gemm_nt_256_kernel<false, 2>}};
   static bool attr_set = false;
   if (!attr_set) {
-    TDIST_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_256_kernel<true>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    TDIST_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_256_kernel<false>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 2; ++j)
+        TDIST_HIP_TRY(hipFuncSetAttribute((const void*)table[i][j], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set = true;
   }
-  if (dtype == 0) {
-    hipLaunchKernelGGL(gemm_nt_256_kernel<true>, dim3(tiles), dim3(THREADS), LDS_BYTES, (hipStream_t)stream,
-                       (const uint16_t*)A, (const uint16_t*)B, (uint16_t*)C, M, N, K, lda, ldb, ldc, group_m);
-  } else {
-    hipLaunchKernelGGL(gemm_nt_256_kernel<false>, dim3(tiles), dim3(THREADS), LDS_BYTES, (hipStream_t)stream,
-                       (const uint16_t*)A, (const uint16_t*)B, (uint16_t*)C, M, N, K, lda, ldb, ldc, group_m);
-  }
+  kern_t k = table[dtype == 0 ? 0 : 1][(variant & 255) == 2 ? 1 : 0];
+  hipLaunchKernelGGL(k, dim3(tiles), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, (const uint16_t*)A,
+                     (const uint16_t*)B, (uint16_t*)C, M, N, K, lda, ldb, ldc, group_m, variant >> 8);
   TDIST_HIP_TRY(hipGetLastError());
   return 0;
 }

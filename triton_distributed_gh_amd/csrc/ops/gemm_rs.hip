@@ -172,7 +172,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_rs_kernel(GemmRsParams p) {
     t.b_rows = p.N - pid_n * BN;
     t.K = p.K;
     Acc<IS_BF16> acc;
-    mainloop_256<IS_BF16>(t, smem, acc);
+    mainloop_256_2ph<IS_BF16>(t, smem, acc);
     if (p.dbg && threadIdx.x == 0) p.dbg[blockIdx.x * 4 + 1] = 2;
 
     uint16_t* dst_buf = (d == rank) ? p.scatter : symm_at(p.ctx, p.scatter, d);

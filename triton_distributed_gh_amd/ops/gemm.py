@@ -10,6 +10,7 @@ GEMM halves of kernels/amd/all_gather_gemm.py / gemm_reduce_scatter.py.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -17,6 +18,8 @@ import torch
 from .. import _lib
 
 _DT = {torch.bfloat16: 0, torch.float16: 1}
+# main-loop schedule: 1 = four phases per K-step, 2 = two phases per K-step
+GEMM_VARIANT = int(os.environ.get("TDIST_GEMM_VARIANT", "2"))
 
 
 def gemm_supported(a: torch.Tensor, b: torch.Tensor) -> bool:
@@ -31,7 +34,7 @@ def gemm_supported(a: torch.Tensor, b: torch.Tensor) -> bool:
 
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, group_m: int = 8,
-            force_native: bool = False) -> torch.Tensor:
+            force_native: bool = False, variant: Optional[int] = None) -> torch.Tensor:
     assert a.shape[1] == b.shape[1], f"K mismatch: {tuple(a.shape)} vs {tuple(b.shape)}"
     M, K = a.shape
     N = b.shape[0]
@@ -46,5 +49,5 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     _lib.check(
         lib.tdist_gemm_nt(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), M, N, K, ctypes.c_longlong(a.stride(0)),
                           ctypes.c_longlong(b.stride(0)), ctypes.c_longlong(out.stride(0)), _DT[a.dtype], group_m,
-                          _lib.stream_handle()), "tdist_gemm_nt")
+                          _lib.stream_handle(), variant if variant is not None else GEMM_VARIANT), "tdist_gemm_nt")
     return out
