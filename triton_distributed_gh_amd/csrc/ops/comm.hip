@@ -1,0 +1,449 @@
+// Small-message communication kernels over xGMI peer mappings:
+//   * low-latency all-gather: push (data + epoch flag), pull (ready flag, then peer reads) and the
+//     LL protocol (every 4 payload bytes travel with a 4-byte flag in one 8-byte store)
+//   * DeepSeek-style low-latency all-to-all (EP dispatch / combine for decode)
+//   * EP normal-mode dispatch / combine (token-granular puts with slot allocation)
+//   * p2p copies for pipeline parallelism
+//
+// Role in the reference: kernels/nvidia/low_latency_allgather.py:47-777 (`_forward_pull_kernel`,
+// `_forward_push_2d_kernel`, `_pack_ll_block` :548-566 / `_recv_ll_block` :530-545),
+// kernels/nvidia/low_latency_all_to_all.py:35-118 (`all_to_all_kernel`),
+// kernels/nvidia/ep_a2a.py:36-320 (dispatch / combine / splits / bincount),
+// kernels/nvidia/p2p.py:30-85.  NUMA / multi-node / multimem variants have nothing to map to inside
+// one full-mesh xGMI node and are served by the same kernels.
+#include "tdist/common.hpp"
+#include "tdist/primitives.hpp"
+#include "tdist/shmem_device.hpp"
+
+using namespace tdist;
+
+// ------------------------------------------------------------------------------------------------
+// all-gather.  `buf` is symmetric [w][bytes_per_rank]; slot `rank` holds the local shard on entry.
+// grid = (w - 1) * slices.  flags: symmetric int32 [w] (push) / [w] (pull ready flags).
+// ------------------------------------------------------------------------------------------------
+struct AgParams {
+  SymmCtx ctx;
+  char* buf;
+  int* flags;       // [2][w]: [0] data-arrived (push) / shard-ready (pull); [1] reader-done (pull)
+  int* local_cnt;   // local int32 [w], zeroed before launch (push with slices > 1)
+  int* err;
+  long long bytes_per_rank;
+  int slices;
+  int epoch;
+};
+
+__global__ __launch_bounds__(512) void allgather_push_kernel(AgParams p) {
+  const int w = p.ctx.num_ranks, rank = p.ctx.rank;
+  const int pi = blockIdx.x / p.slices, slice = blockIdx.x % p.slices;
+  const int peer = (rank + 1 + pi) % w;
+  const long long per = ((p.bytes_per_rank + p.slices - 1) / p.slices + 15) & ~15ll;
+  const long long b0 = min((long long)slice * per, p.bytes_per_rank), b1 = min(b0 + per, p.bytes_per_rank);
+  char* src = p.buf + rank * p.bytes_per_rank;
+  char* dst = symm_at(p.ctx, p.buf, peer) + rank * p.bytes_per_rank;
+  shmem::copy_bytes(dst + b0, src + b0, (size_t)(b1 - b0), threadIdx.x, blockDim.x);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int prev = atom_add_acqrel_agent(p.local_cnt + peer, 1);
+    if (prev == p.slices - 1) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      store_relaxed_system(symm_at(p.ctx, p.flags, peer) + rank, p.epoch);
+    }
+  }
+  __syncthreads();
+  // every workgroup waits for the shard of "its" peer, so kernel completion = all shards present
+  if (slice == 0) wait(p.flags + peer, 1, SCOPE_SYS, SEM_ACQUIRE, p.epoch, p.err);
+}
+
+__global__ __launch_bounds__(512) void allgather_pull_kernel(AgParams p) {
+  const int w = p.ctx.num_ranks, rank = p.ctx.rank;
+  const int pi = blockIdx.x / p.slices, slice = blockIdx.x % p.slices;
+  const int peer = (rank + 1 + pi) % w;
+  // announce "my shard is ready" to the peer this workgroup serves, then wait for the peer's
+  if (slice == 0 && threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    store_relaxed_system(symm_at(p.ctx, p.flags, peer) + rank, p.epoch);
+  }
+  wait(p.flags + peer, 1, SCOPE_SYS, SEM_ACQUIRE, p.epoch, p.err);
+  const long long per = ((p.bytes_per_rank + p.slices - 1) / p.slices + 15) & ~15ll;
+  const long long b0 = min((long long)slice * per, p.bytes_per_rank), b1 = min(b0 + per, p.bytes_per_rank);
+  const char* src = symm_at(p.ctx, p.buf, peer) + peer * p.bytes_per_rank;
+  shmem::copy_bytes(p.buf + peer * p.bytes_per_rank + b0, src + b0, (size_t)(b1 - b0), threadIdx.x, blockDim.x);
+  // tell the peer we are done reading its shard (it may overwrite it once everyone has), and do
+  // not leave before every peer has finished reading ours
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int prev = atom_add_acqrel_agent(p.local_cnt + peer, 1);
+    if (prev == p.slices - 1) store_relaxed_system(symm_at(p.ctx, p.flags, peer) + w + rank, p.epoch);
+  }
+  __syncthreads();
+  if (slice == 0) wait(p.flags + w + peer, 1, SCOPE_SYS, SEM_RELAXED, p.epoch, p.err);
+}
+
+// LL protocol: staging is symmetric uint64 [w][words_per_rank]; word = (flag << 32) | payload32.
+// Sender workgroup pi packs and stores the local shard into peer's staging slot [rank]; receiver
+// workgroup (same kernel, blockIdx >= w-1) spins per word and unpacks into buf slot [src].
+struct AgLLParams {
+  SymmCtx ctx;
+  char* buf;                  // [w][bytes_per_rank], local shard at slot rank (bytes multiple of 4)
+  unsigned long long* stage;  // symmetric [w][words]
+  int* err;
+  long long words;
+  unsigned flag;              // != 0, changes every call
+};
+
+__global__ __launch_bounds__(512) void allgather_ll_kernel(AgLLParams p) {
+  const int w = p.ctx.num_ranks, rank = p.ctx.rank;
+  const int b = blockIdx.x;
+  if (b < w - 1) {
+    const int peer = (rank + 1 + b) % w;
+    const unsigned* src = (const unsigned*)(p.buf + (long long)rank * p.words * 4);
+    unsigned long long* dst = symm_at(p.ctx, p.stage, peer) + (long long)rank * p.words;
+    for (long long i = threadIdx.x; i < p.words; i += blockDim.x)
+      store_relaxed_system(dst + i, ((unsigned long long)p.flag << 32) | src[i]);
+  } else {
+    const int src_rank = (rank + 1 + (b - (w - 1))) % w;
+    const unsigned long long* st = p.stage + (long long)src_rank * p.words;
+    unsigned* dst = (unsigned*)(p.buf + (long long)src_rank * p.words * 4);
+    const uint64_t t0 = wall_ticks();
+    for (long long i = threadIdx.x; i < p.words; i += blockDim.x) {
+      unsigned long long v;
+      int spins = 0;
+      while (true) {
+        v = load_relaxed_system(st + i);
+        if ((unsigned)(v >> 32) == p.flag) break;
+        if (((++spins) & 1023) == 0 && wall_ticks() - t0 > TDIST_SPIN_TIMEOUT_TICKS) {
+          atomicOr(p.err, 1);
+          break;
+        }
+      }
+      dst[i] = (unsigned)v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Low-latency all-to-all.  Workgroup `pid` serves destination rank pid.
+//   rows [cum[pid*EPR], cum[(pid+1)*EPR]) of send_buf -> peer recv[half][rank*max_m ...]
+//   per-expert splits (EPR ints)              -> peer split[half][rank*EPR ...]
+//   optional per-row scales (scale_elems f32) -> peer scale[half][rank*max_m ...]
+//   signal[half][rank] := call_count on the peer, then wait for signal[half][pid] == call_count.
+// ------------------------------------------------------------------------------------------------
+struct A2AParams {
+  SymmCtx ctx;
+  const char* send_buf;     // [max_m, row_bytes]
+  char* recv_buf;           // symmetric [2][w*max_m, row_bytes]
+  const float* send_scale;  // [max_m, scale_elems] or null
+  float* recv_scale;        // symmetric [2][w*max_m, scale_elems]
+  const int* cumsum;        // [num_tot_experts + 1] exclusive cumsum of tokens per expert
+  int* split_buf;           // symmetric [2][w*EPR]
+  unsigned long long* signal;  // symmetric [2][w]
+  int* err;
+  long long row_bytes;
+  int max_m, epr, scale_elems;
+  unsigned long long call_count;
+};
+
+__global__ __launch_bounds__(1024) void all_to_all_kernel(A2AParams p) {
+  const int w = p.ctx.num_ranks, rank = p.ctx.rank, pid = blockIdx.x;
+  const int half = (int)(p.call_count & 1);
+  const int m_st = p.cumsum[pid * p.epr], m_ed = p.cumsum[(pid + 1) * p.epr];
+  const long long slot_row = (long long)half * w * p.max_m + (long long)rank * p.max_m;
+  char* dst = symm_at(p.ctx, p.recv_buf, pid) + slot_row * p.row_bytes;
+  shmem::copy_bytes(dst, p.send_buf + (long long)m_st * p.row_bytes, (size_t)(m_ed - m_st) * p.row_bytes, threadIdx.x,
+                    blockDim.x);
+  if (p.send_scale) {
+    float* sd = symm_at(p.ctx, p.recv_scale, pid) + slot_row * p.scale_elems;
+    shmem::copy_bytes(sd, p.send_scale + (long long)m_st * p.scale_elems,
+                      (size_t)(m_ed - m_st) * p.scale_elems * sizeof(float), threadIdx.x, blockDim.x);
+  }
+  int* sp = symm_at(p.ctx, p.split_buf, pid) + half * w * p.epr + rank * p.epr;
+  for (int e = threadIdx.x; e < p.epr; e += blockDim.x)
+    sp[e] = p.cumsum[pid * p.epr + e + 1] - p.cumsum[pid * p.epr + e];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    store_relaxed_system(symm_at(p.ctx, p.signal, pid) + half * w + rank, p.call_count);
+    if (!spin_until_eq(p.signal + half * w + pid, p.call_count, SCOPE_SYS)) atomicOr(p.err, 1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// EP normal mode.
+// counts exchange: every rank pushes its per-expert token counts [E] to all peers' table row [rank].
+// ------------------------------------------------------------------------------------------------
+struct EpCountParams {
+  SymmCtx ctx;
+  const int* counts;   // local [E]
+  int* table;          // symmetric [w][E]
+  int* flags;          // symmetric [w]
+  int* err;
+  int E, epoch;
+};
+
+__global__ __launch_bounds__(256) void ep_exchange_counts_kernel(EpCountParams p) {
+  const int w = p.ctx.num_ranks, rank = p.ctx.rank, peer = blockIdx.x;
+  int* dst = symm_at(p.ctx, p.table, peer) + rank * p.E;
+  for (int e = threadIdx.x; e < p.E; e += blockDim.x) dst[e] = p.counts[e];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) store_relaxed_system(symm_at(p.ctx, p.flags, peer) + rank, p.epoch);
+  wait(p.flags + peer, 1, SCOPE_SYS, SEM_ACQUIRE, p.epoch, p.err);
+}
+
+// dispatch: one wave per (token, k).  dst_base[e] = first row, inside the destination rank's
+// receive buffer, of the (expert e, this source rank) segment; cursor[e] is a local atomic slot
+// allocator.  Writes the row and records scatter_idx[token, k] = destination row.
+struct EpDispatchParams {
+  SymmCtx ctx;
+  const char* tokens;      // [T, row_bytes]
+  const int* topk_idx;     // [T, topk]
+  const int* dst_base;     // [E]
+  int* cursor;             // [E], zeroed before launch
+  char* recv_buf;          // symmetric [cap_rows, row_bytes]
+  int* scatter_idx;        // [T, topk]
+  int* flags;              // symmetric [w]: source rank's tokens have landed
+  int* done;               // local counter, zeroed before launch
+  int* err;
+  long long row_bytes;
+  int T, topk, epr, epoch;
+};
+
+__global__ __launch_bounds__(512) void ep_dispatch_kernel(EpDispatchParams p) {
+  const int w = p.ctx.num_ranks;
+  const int waves_per_block = blockDim.x / 64;
+  const int lane = threadIdx.x & 63;
+  const long long total = (long long)p.T * p.topk;
+  for (long long item = (long long)blockIdx.x * waves_per_block + (threadIdx.x >> 6); item < total;
+       item += (long long)gridDim.x * waves_per_block) {
+    const int t = (int)(item / p.topk);
+    const int e = p.topk_idx[item];
+    const int d = e / p.epr;
+    int slot = 0;
+    if (lane == 0) slot = p.dst_base[e] + atomicAdd(p.cursor + e, 1);
+    slot = __shfl(slot, 0);
+    char* dst = symm_at(p.ctx, p.recv_buf, d) + (long long)slot * p.row_bytes;
+    shmem::copy_bytes(dst, p.tokens + (long long)t * p.row_bytes, (size_t)p.row_bytes, lane, 64);
+    if (lane == 0) p.scatter_idx[item] = slot;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int prev = atom_add_acqrel_agent(p.done, 1);
+    if (prev == (int)gridDim.x - 1) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int r = 0; r < w; ++r) store_relaxed_system(symm_at(p.ctx, p.flags, r) + p.ctx.rank, p.epoch);
+    }
+  }
+  __syncthreads();
+  // kernel completion = every source's tokens are present locally
+  wait(p.flags, w, SCOPE_SYS, SEM_ACQUIRE, p.epoch, p.err);
+}
+
+// combine: one workgroup per token; out[t] = sum_k weight[t,k] * expert_out(owner rank)[scatter_idx[t,k]]
+struct EpCombineParams {
+  SymmCtx ctx;
+  const uint16_t* expert_out;   // symmetric [cap_rows, hidden] (bf16)
+  const int* topk_idx;
+  const int* scatter_idx;
+  const float* weights;         // [T, topk] or null (=1)
+  uint16_t* out;                // [T, hidden]
+  int* flags;                   // symmetric [w]: rank's expert outputs are final
+  int* err;
+  int T, topk, epr, hidden, epoch;
+};
+
+__global__ __launch_bounds__(256) void ep_combine_kernel(EpCombineParams p) {
+  const int w = p.ctx.num_ranks;
+  // phase 0: tell everyone that this rank's expert_out is complete (it was produced by earlier
+  // kernels on this stream), then wait for all ranks.
+  if (blockIdx.x == 0 && threadIdx.x < w) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    store_relaxed_system(symm_at(p.ctx, p.flags, (int)threadIdx.x) + p.ctx.rank, p.epoch);
+  }
+  wait(p.flags, w, SCOPE_SYS, SEM_ACQUIRE, p.epoch, p.err);
+  for (int t = blockIdx.x; t < p.T; t += gridDim.x) {
+    for (int c = threadIdx.x * 8; c < p.hidden; c += blockDim.x * 8) {
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < p.topk; ++k) {
+        const int e = p.topk_idx[t * p.topk + k];
+        const int d = e / p.epr;
+        const int slot = p.scatter_idx[t * p.topk + k];
+        const float wt = p.weights ? p.weights[t * p.topk + k] : 1.f;
+        const uint4 v = *(const uint4*)(symm_at(p.ctx, const_cast<uint16_t*>(p.expert_out), d) + (long long)slot * p.hidden + c);
+        const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[2 * i] += wt * __builtin_bit_cast(float, x[i] << 16);
+          acc[2 * i + 1] += wt * __builtin_bit_cast(float, x[i] & 0xffff0000u);
+        }
+      }
+      typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+      uint32_t o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        b2 v = {(__bf16)acc[2 * i], (__bf16)acc[2 * i + 1]};
+        o[i] = __builtin_bit_cast(uint32_t, v);
+      }
+      *(uint4*)(p.out + (long long)t * p.hidden + c) = uint4{o[0], o[1], o[2], o[3]};
+    }
+  }
+}
+
+// p2p copy (pull): local_dst <- peer's symmetric src
+__global__ __launch_bounds__(512) void p2p_pull_kernel(SymmCtx ctx, char* local_dst, char* symm_src, long long bytes,
+                                                       int peer) {
+  const long long per = ((bytes + gridDim.x - 1) / gridDim.x + 15) & ~15ll;
+  const long long b0 = min((long long)blockIdx.x * per, bytes), b1 = min(b0 + per, bytes);
+  shmem::copy_bytes(local_dst + b0, symm_at(ctx, symm_src, peer) + b0, (size_t)(b1 - b0), threadIdx.x, blockDim.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+TDIST_API int tdist_allgather(const SymmCtx* ctx, void* buf, int* flags, int* local_cnt, int* err,
+                              long long bytes_per_rank, int slices, int epoch, int mode, void* stream) {
+  const int w = ctx->num_ranks;
+  if (w <= 1) return 0;
+  AgParams p;
+  p.ctx = *ctx;
+  p.buf = (char*)buf;
+  p.flags = flags;
+  p.local_cnt = local_cnt;
+  p.err = err;
+  p.bytes_per_rank = bytes_per_rank;
+  p.slices = slices > 0 ? slices : 1;
+  p.epoch = epoch;
+  hipStream_t s = (hipStream_t)stream;
+  TDIST_HIP_TRY(hipMemsetAsync(local_cnt, 0, TDIST_MAX_RANKS * sizeof(int), s));
+  if (mode == 0) {
+    hipLaunchKernelGGL(allgather_push_kernel, dim3((w - 1) * p.slices), dim3(512), 0, s, p);
+  } else {
+    hipLaunchKernelGGL(allgather_pull_kernel, dim3((w - 1) * p.slices), dim3(512), 0, s, p);
+  }
+  TDIST_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+TDIST_API int tdist_allgather_ll(const SymmCtx* ctx, void* buf, void* stage, int* err, long long bytes_per_rank,
+                                 unsigned flag, void* stream) {
+  const int w = ctx->num_ranks;
+  if (w <= 1) return 0;
+  TDIST_REQUIRE(bytes_per_rank % 4 == 0 && flag != 0, "LL all-gather needs 4-byte multiples and a non-zero flag");
+  AgLLParams p;
+  p.ctx = *ctx;
+  p.buf = (char*)buf;
+  p.stage = (unsigned long long*)stage;
+  p.err = err;
+  p.words = bytes_per_rank / 4;
+  p.flag = flag;
+  hipLaunchKernelGGL(allgather_ll_kernel, dim3(2 * (w - 1)), dim3(512), 0, (hipStream_t)stream, p);
+  TDIST_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+TDIST_API int tdist_all_to_all(const SymmCtx* ctx, const void* send_buf, void* recv_buf, const float* send_scale,
+                               float* recv_scale, const int* cumsum, int* split_buf, void* signal, int* err,
+                               long long row_bytes, int max_m, int epr, int scale_elems,
+                               unsigned long long call_count, void* stream) {
+  A2AParams p;
+  p.ctx = *ctx;
+  p.send_buf = (const char*)send_buf;
+  p.recv_buf = (char*)recv_buf;
+  p.send_scale = send_scale;
+  p.recv_scale = recv_scale;
+  p.cumsum = cumsum;
+  p.split_buf = split_buf;
+  p.signal = (unsigned long long*)signal;
+  p.err = err;
+  p.row_bytes = row_bytes;
+  p.max_m = max_m;
+  p.epr = epr;
+  p.scale_elems = scale_elems;
+  p.call_count = call_count;
+  hipLaunchKernelGGL(all_to_all_kernel, dim3(ctx->num_ranks), dim3(1024), 0, (hipStream_t)stream, p);
+  TDIST_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+TDIST_API int tdist_ep_exchange_counts(const SymmCtx* ctx, const int* counts, int* table, int* flags, int* err, int E,
+                                       int epoch, void* stream) {
+  EpCountParams p;
+  p.ctx = *ctx;
+  p.counts = counts;
+  p.table = table;
+  p.flags = flags;
+  p.err = err;
+  p.E = E;
+  p.epoch = epoch;
+  hipLaunchKernelGGL(ep_exchange_counts_kernel, dim3(ctx->num_ranks), dim3(256), 0, (hipStream_t)stream, p);
+  TDIST_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+TDIST_API int tdist_ep_dispatch(const SymmCtx* ctx, const void* tokens, const int* topk_idx, const int* dst_base,
+                                int* cursor, void* recv_buf, int* scatter_idx, int* flags, int* done, int* err,
+                                long long row_bytes, int T, int topk, int E, int epr, int epoch, int num_ctas,
+                                void* stream) {
+  EpDispatchParams p;
+  p.ctx = *ctx;
+  p.tokens = (const char*)tokens;
+  p.topk_idx = topk_idx;
+  p.dst_base = dst_base;
+  p.cursor = cursor;
+  p.recv_buf = (char*)recv_buf;
+  p.scatter_idx = scatter_idx;
+  p.flags = flags;
+  p.done = done;
+  p.err = err;
+  p.row_bytes = row_bytes;
+  p.T = T;
+  p.topk = topk;
+  p.epr = epr;
+  p.epoch = epoch;
+  hipStream_t s = (hipStream_t)stream;
+  TDIST_HIP_TRY(hipMemsetAsync(cursor, 0, (size_t)E * sizeof(int), s));
+  TDIST_HIP_TRY(hipMemsetAsync(done, 0, 16, s));
+  hipLaunchKernelGGL(ep_dispatch_kernel, dim3(num_ctas > 0 ? num_ctas : 40), dim3(512), 0, s, p);
+  TDIST_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+TDIST_API int tdist_ep_combine(const SymmCtx* ctx, const void* expert_out, const int* topk_idx, const int* scatter_idx,
+                               const float* weights, void* out, int* flags, int* err, int T, int topk, int epr,
+                               int hidden, int epoch, int num_ctas, void* stream) {
+  TDIST_REQUIRE(hidden % 8 == 0, "hidden must be a multiple of 8");
+  EpCombineParams p;
+  p.ctx = *ctx;
+  p.expert_out = (const uint16_t*)expert_out;
+  p.topk_idx = topk_idx;
+  p.scatter_idx = scatter_idx;
+  p.weights = weights;
+  p.out = (uint16_t*)out;
+  p.flags = flags;
+  p.err = err;
+  p.T = T;
+  p.topk = topk;
+  p.epr = epr;
+  p.hidden = hidden;
+  p.epoch = epoch;
+  hipLaunchKernelGGL(ep_combine_kernel, dim3(num_ctas > 0 ? num_ctas : 64), dim3(256), 0, (hipStream_t)stream, p);
+  TDIST_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+TDIST_API int tdist_p2p_pull(const SymmCtx* ctx, void* local_dst, void* symm_src, long long bytes, int peer, int num_ctas,
+                             void* stream) {
+  hipLaunchKernelGGL(p2p_pull_kernel, dim3(num_ctas > 0 ? num_ctas : 4), dim3(512), 0, (hipStream_t)stream, *ctx,
+                     (char*)local_dst, (char*)symm_src, bytes, peer);
+  TDIST_HIP_TRY(hipGetLastError());
+  return 0;
+}

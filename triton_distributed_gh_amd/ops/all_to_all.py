@@ -1,0 +1,159 @@
+"""DeepSeek-style low-latency all-to-all (expert-parallel dispatch / combine for decode) and the
+fp8 group quantisation that goes with it.
+
+API of the reference (reference: python/triton_dist/kernels/nvidia/low_latency_all_to_all.py -
+``create_all_to_all_context`` :176-195, ``fast_all_to_all`` :198-257, ``all_to_all_post_process``
+:260-279; fp8 helpers tutorials/04-deepseek-infer-all2all.py:334-427).  One workgroup per
+destination rank moves that rank's contiguous token rows (tokens are pre-sorted by expert), the
+per-expert splits and the optional fp32 scales straight into the peer's receive buffer over xGMI,
+then raises a 64-bit signal with the call count; receive buffers are double-buffered by call parity
+so the sender never waits for the receiver to have consumed the previous message.
+"""
+from __future__ import annotations
+
+import ctypes
+import dataclasses
+from typing import Any, List, Optional, Tuple
+
+import torch
+
+from .. import _lib
+from ..utils.distributed import get_env
+
+FP8_MAX = 448.0  # OCP e4m3fn
+
+
+@dataclasses.dataclass(repr=False)
+class AllToAllContext:
+    max_m: int
+    hidden: int
+    rank: int
+    num_tot_experts: int
+    world_size: int
+    experts_per_rank: int
+    dtype: torch.dtype
+    scale_dtype: torch.dtype
+    scale_elems: int
+    send_buf: torch.Tensor
+    recv_buf: List[torch.Tensor]
+    scale_send_buf: torch.Tensor
+    scale_recv_buf: List[torch.Tensor]
+    split_send_buf: torch.Tensor
+    split_recv_buf: List[torch.Tensor]
+    signal_buf: List[torch.Tensor]
+    err: Optional[torch.Tensor]
+    env: Any = None
+    call_count: int = 1
+    MOD_VALUE: int = 1000000
+
+    def check_error(self) -> None:
+        if self.err is not None and int(self.err[0]) != 0:
+            raise RuntimeError("fast_all_to_all: a device-side wait timed out")
+
+
+def create_all_to_all_context(max_m, hidden, rank, num_tot_experts, WORLD_SIZE, experts_per_rank,
+                              dtype=torch.bfloat16, scale_dtype=torch.float32, scale_group: int = 128,
+                              env=None) -> AllToAllContext:
+    env = env or get_env()
+    heap = env.heap
+    w = WORLD_SIZE
+    scale_elems = max(1, hidden // scale_group)
+    dev = env.device
+    send_buf = torch.empty((max_m, hidden), dtype=dtype, device=dev)
+    recv = heap.create_tensor_list([2, w * max_m, hidden], dtype, zero=False)
+    scale_send = torch.empty((max_m, scale_elems), dtype=scale_dtype, device=dev)
+    scale_recv = heap.create_tensor_list([2, w * max_m, scale_elems], scale_dtype, zero=False)
+    split_send = torch.zeros((num_tot_experts + 1,), dtype=torch.int32, device=dev)
+    split_recv = heap.create_tensor_list([2, w * experts_per_rank], torch.int32)
+    signal = heap.create_tensor_list([2 * w], torch.int64, arena="sig")
+    err = torch.zeros(4, dtype=torch.int32, device=dev) if env.backend == "hip" else None
+    if env.backend == "hip":
+        torch.cuda.synchronize()
+    if env.cpu_group is not None:
+        torch.distributed.barrier(group=env.cpu_group)
+    return AllToAllContext(max_m, hidden, rank, num_tot_experts, w, experts_per_rank, dtype, scale_dtype, scale_elems,
+                           send_buf, recv, scale_send, scale_recv, split_send, split_recv, signal, err, env)
+
+
+def fast_all_to_all(ctx: AllToAllContext, send_tensor: torch.Tensor, send_split_cumsum: torch.Tensor,
+                    send_scale: Optional[torch.Tensor] = None):
+    """send_tensor [num_tokens, hidden] sorted by destination expert; send_split_cumsum
+    [num_tot_experts + 1] int32 exclusive cumsum.  Returns (recv_splits [w, EPR], recv [w, max_m,
+    hidden], recv_scale or None) - views into this call's half of the receive buffers."""
+    env = ctx.env
+    w, rank = ctx.world_size, ctx.rank
+    n = send_tensor.shape[0]
+    assert n <= ctx.max_m and send_tensor.shape[1] == ctx.hidden
+    half = ctx.call_count & 1
+    ctx.send_buf[:n].copy_(send_tensor)
+    ctx.split_send_buf.copy_(send_split_cumsum.to(torch.int32))
+    with_scale = send_scale is not None
+    if with_scale:
+        ctx.scale_send_buf[:n].copy_(send_scale)
+    if env.backend == "host":
+        _a2a_host(ctx, n, half, with_scale)
+    else:
+        cs = env.heap.ctx_struct()
+        row_bytes = ctx.hidden * ctx.send_buf.element_size()
+        _lib.check(
+            _lib.hip().tdist_all_to_all(ctypes.byref(cs), _lib.ptr(ctx.send_buf), _lib.ptr(ctx.recv_buf[rank]),
+                                        _lib.ptr(ctx.scale_send_buf) if with_scale else ctypes.c_void_p(0),
+                                        _lib.ptr(ctx.scale_recv_buf[rank]), _lib.ptr(ctx.split_send_buf),
+                                        _lib.ptr(ctx.split_recv_buf[rank]), _lib.ptr(ctx.signal_buf[rank]),
+                                        _lib.ptr(ctx.err), ctypes.c_longlong(row_bytes), ctx.max_m,
+                                        ctx.experts_per_rank, ctx.scale_elems, ctypes.c_ulonglong(ctx.call_count),
+                                        _lib.stream_handle()), "tdist_all_to_all")
+    ctx.call_count = (ctx.call_count + 1) % ctx.MOD_VALUE or 1
+    recv = ctx.recv_buf[rank][half].view(w, ctx.max_m, ctx.hidden)
+    splits = ctx.split_recv_buf[rank][half].view(w, ctx.experts_per_rank)
+    scale = ctx.scale_recv_buf[rank][half].view(w, ctx.max_m, ctx.scale_elems) if with_scale else None
+    return splits, recv, scale
+
+
+def _a2a_host(ctx, n, half, with_scale):
+    lib = _lib.host()
+    w, rank, epr = ctx.world_size, ctx.rank, ctx.experts_per_rank
+    cum = ctx.split_send_buf
+    for i in range(w):
+        d = (rank + i) % w
+        st, ed = int(cum[d * epr]), int(cum[(d + 1) * epr])
+        ctx.recv_buf[d][half, rank * ctx.max_m: rank * ctx.max_m + (ed - st)].copy_(ctx.send_buf[st:ed])
+        if with_scale:
+            ctx.scale_recv_buf[d][half, rank * ctx.max_m: rank * ctx.max_m + (ed - st)].copy_(ctx.scale_send_buf[st:ed])
+        ctx.split_recv_buf[d][half, rank * epr:(rank + 1) * epr].copy_(cum[d * epr + 1:(d + 1) * epr + 1] - cum[d * epr:(d + 1) * epr])
+        lib.tdh_notify64(ctypes.c_void_p(ctx.signal_buf[d].data_ptr() + 8 * (half * w + rank)), ctx.call_count, 1)
+    if lib.tdh_wait64(ctypes.c_void_p(ctx.signal_buf[rank].data_ptr() + 8 * half * w), w, 0, ctx.call_count,
+                      ctypes.c_int64(60000)) != 0:
+        raise RuntimeError("fast_all_to_all(host) timed out")
+
+
+def all_to_all_post_process(ctx: AllToAllContext, splits: torch.Tensor, recv: torch.Tensor,
+                            scale: Optional[torch.Tensor] = None):
+    """Compact the per-source segments: returns (tokens [sum, hidden], scales or None,
+    tokens_per_local_expert [EPR])."""
+    w = ctx.world_size
+    per_src = splits.sum(dim=1).tolist()
+    rows = [recv[s, : per_src[s]] for s in range(w)]
+    out = torch.cat(rows, dim=0)
+    out_scale = torch.cat([scale[s, : per_src[s]] for s in range(w)], dim=0) if scale is not None else None
+    return out, out_scale, splits.sum(dim=0)
+
+
+# ---- fp8 group quantisation (per 128-element group, scale = max|x| / 448) --------------------
+def quantize_fp8_groupwise(x: torch.Tensor, group: int = 128) -> Tuple[torch.Tensor, torch.Tensor]:
+    M, H = x.shape
+    assert H % group == 0
+    if x.is_cuda:
+        from .elementwise import fp8_group_quant
+
+        return fp8_group_quant(x, group)
+    xg = x.float().view(M, H // group, group)
+    scale = xg.abs().amax(dim=-1).clamp_min(1e-12) / FP8_MAX
+    q = (xg / scale.unsqueeze(-1)).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).view(M, H)
+    return q, scale
+
+
+def dequantize_fp8_groupwise(q: torch.Tensor, scale: torch.Tensor, group: int = 128,
+                             dtype=torch.bfloat16) -> torch.Tensor:
+    M, H = q.shape
+    return (q.float().view(M, H // group, group) * scale.float().unsqueeze(-1)).view(M, H).to(dtype)
