@@ -88,6 +88,10 @@ struct TileArgs {
   int a_rows;          // valid rows in A starting at A (rows >= a_rows are clamped, results masked)
   int b_rows;          // valid rows in B starting at B
   int K;               // multiple of 64, >= 128
+  // Optional row gather for A (grouped / MoE GEMMs): tile row r reads A row a_gather[r]
+  // (negative = padding: reads row 0, the caller discards that output row).  Because the
+  // direct-to-LDS load takes a per-lane SOURCE address, the gather costs nothing extra.
+  const int* a_gather = nullptr;
 };
 
 // Accumulators of one wave: 8 (m) x 4 (n) tiles of 16x16, stored transposed (lane: m = lane&15,
@@ -279,6 +283,11 @@ __device__ __forceinline__ void mainloop_256_2ph(const TileArgs& t, char* smem, 
   arow1 = arow1 < t.a_rows ? arow1 : t.a_rows - 1;
   brow0 = brow0 < t.b_rows ? brow0 : t.b_rows - 1;
   brow1 = brow1 < t.b_rows ? brow1 : t.b_rows - 1;
+  if (t.a_gather) {
+    const int g0 = t.a_gather[arow0], g1 = t.a_gather[arow1];
+    arow0 = g0 < 0 ? 0 : g0;
+    arow1 = g1 < 0 ? 0 : g1;
+  }
   const uint16_t* pa0 = t.A + (long long)arow0 * t.lda + kchunk * 8;
   const uint16_t* pa1 = t.A + (long long)arow1 * t.lda + kchunk * 8;
   const uint16_t* pb0 = t.B + (long long)brow0 * t.ldb + kchunk * 8;

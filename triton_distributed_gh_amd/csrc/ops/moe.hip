@@ -1,0 +1,372 @@
+// Mixture-of-experts kernels for tensor-parallel MoE:
+//   moe_align        - sort (token, k) pairs by (expert, source rank), pad each expert to the 256-row
+//                      tile, emit per-tile expert id and the range of source ranks the tile touches
+//   moe_group_gemm   - persistent grouped GEMM on the 256x256 MFMA engine with gathered A rows
+//                      (AllGather + MoE: waits per tile on the arrival flags of the ranks it needs;
+//                      MoE + ReduceScatter: scales rows by the routing weight in the epilogue)
+//   moe_topk_reduce_rs - sum the topk expert outputs of every token, push the result to the rank
+//                      that owns the token, wait for all ranks, reduce the w partials in fp32
+//
+// Role in the reference: csrc/lib/moe_utils.cu:60-353 (align, single-CTA and per-rank variants),
+// kernels/nvidia/allgather_group_gemm.py:84-165 (sorted gather index) and :534-608 (grouped GEMM
+// consumer), kernels/nvidia/moe_reduce_rs.py:166-244 (grouped GEMM with weights) and :292-376
+// (topk reduce + reduce-scatter), kernels/nvidia/threadblock_swizzle_ag_moe.cu (tile order by
+// arrival stage: here tiles are simply SORTED by the last source rank they need, in arrival
+// order, on the device side of `moe_align`).
+#include "tdist/common.hpp"
+#include "tdist/gemm_gfx950.hpp"
+#include "tdist/primitives.hpp"
+
+using namespace tdist;
+using namespace tdist::gemm;
+
+// ------------------------------------------------------------------------------------------------
+// align: ONE workgroup of 1024 threads.  LDS: hist[E*w], base[E*w], pad_off[E+1]
+// ------------------------------------------------------------------------------------------------
+struct AlignParams {
+  const int* topk_ids;    // [n] expert of flat pair i = token*topk + k
+  int* sorted_ids;        // [cap] flat pair index or -1 (cap = n + E*256 rounded)
+  int* expert_of_block;   // [cap/256]
+  int* seg_range;         // [cap/256][2] first / last source rank present in the block
+  int* order;             // [cap/256] block ids sorted by arrival (rotated last source rank)
+  int* meta;              // [0] num_blocks, [1] padded rows, [2..2+E) tokens per expert
+  int n, E, w, topk, tokens_per_rank, rank, cap;
+};
+
+__global__ __launch_bounds__(1024) void moe_align_kernel(AlignParams p) {
+  extern __shared__ int lds[];
+  int* hist = lds;                       // [E*w] counts, later cursors
+  int* base = lds + p.E * p.w;           // [E*w] start row of (e, s)
+  int* pad_off = base + p.E * p.w;       // [E+1]
+  const int EW = p.E * p.w;
+  for (int i = threadIdx.x; i < EW; i += blockDim.x) hist[i] = 0;
+  for (int i = threadIdx.x; i < p.cap; i += blockDim.x) p.sorted_ids[i] = -1;
+  __syncthreads();
+  for (int i = threadIdx.x; i < p.n; i += blockDim.x) {
+    const int e = p.topk_ids[i];
+    const int s = min((i / p.topk) / p.tokens_per_rank, p.w - 1);
+    atomicAdd(&hist[e * p.w + s], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int off = 0;
+    for (int e = 0; e < p.E; ++e) {
+      pad_off[e] = off;
+      int tot = 0;
+      for (int s = 0; s < p.w; ++s) {
+        base[e * p.w + s] = off + tot;
+        tot += hist[e * p.w + s];
+      }
+      p.meta[2 + e] = tot;
+      off += (tot + BM - 1) / BM * BM;
+    }
+    pad_off[p.E] = off;
+    p.meta[0] = off / BM;
+    p.meta[1] = off;
+  }
+  __syncthreads();
+  const int nblocks = pad_off[p.E] / BM;
+  // per-block expert id + source-rank range (computed before the cursors are consumed)
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+    const int r0 = b * BM, r1 = r0 + BM;
+    int e = 0;
+    while (pad_off[e + 1] <= r0) ++e;
+    int smin = p.w, smax = -1;
+    for (int s = 0; s < p.w; ++s) {
+      const int a = base[e * p.w + s], c = a + hist[e * p.w + s];
+      if (c > a && a < r1 && c > r0) {
+        smin = min(smin, s);
+        smax = max(smax, s);
+      }
+    }
+    p.expert_of_block[b] = e;
+    p.seg_range[2 * b] = smin > smax ? 0 : smin;
+    p.seg_range[2 * b + 1] = smin > smax ? 0 : smax;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < EW; i += blockDim.x) hist[i] = 0;   // now cursors
+  __syncthreads();
+  for (int i = threadIdx.x; i < p.n; i += blockDim.x) {
+    const int e = p.topk_ids[i];
+    const int s = min((i / p.topk) / p.tokens_per_rank, p.w - 1);
+    const int slot = base[e * p.w + s] + atomicAdd(&hist[e * p.w + s], 1);
+    p.sorted_ids[slot] = i;
+  }
+  __syncthreads();
+  // arrival order: a block is ready once its LAST needed source (in push-arrival order: own rank
+  // first, then rank+1, rank+2, ... as pushed by the producers) has landed.  Counting sort on
+  // stage = max over [smin, smax] of ((s - rank + w) % w).
+  if (threadIdx.x == 0) {
+    int pos = 0;
+    for (int st = 0; st < p.w; ++st)
+      for (int b = 0; b < nblocks; ++b) {
+        int stage = 0;
+        for (int s = p.seg_range[2 * b]; s <= p.seg_range[2 * b + 1]; ++s) stage = max(stage, (s - p.rank + p.w) % p.w);
+        if (stage == st) p.order[pos++] = b;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// grouped GEMM
+// ------------------------------------------------------------------------------------------------
+struct GroupGemmParams {
+  const uint16_t* A;          // rows gathered through a_rows
+  const uint16_t* B;          // [E][N][K]
+  uint16_t* out;              // rows scattered through out_rows
+  const int* sorted_ids;      // [cap] flat pair index or -1
+  const int* expert_of_block;
+  const int* seg_range;       // may be null (no waiting)
+  const int* order;           // may be null (natural order)
+  const int* meta;            // meta[0] = number of 256-row blocks
+  const float* row_scale;     // [n] routing weight of flat pair i, or null
+  const int* flags;           // arrival flags [w * cpr] (epoch valued) or null
+  int* ticket;
+  int* err;
+  long long lda, ldb, ldo, b_expert_stride;
+  int N, K;
+  int topk;                   // A row of flat pair i: a_mode 0 -> i / topk (token row), 1 -> i
+  int a_mode;
+  int cpr, epoch;
+};
+
+constexpr int GG_TICKET = LDS_BYTES;        // int ticket
+constexpr int GG_ROWS = LDS_BYTES + 16;     // int[256] gather rows, then int[256] out rows, float[256] scales
+
+template <bool IS_BF16>
+__global__ __launch_bounds__(THREADS, 2) void moe_group_gemm_kernel(GroupGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  volatile int* s_ticket = (volatile int*)(smem + GG_TICKET);
+  int* s_arow = (int*)(smem + GG_ROWS);
+  int* s_orow = s_arow + BM;
+  float* s_scale = (float*)(s_orow + BM);
+  const int num_pid_n = (p.N + BN - 1) / BN;
+  const int nblocks = p.meta[0];
+  const int total = nblocks * num_pid_n;
+  while (true) {
+    const int item = fetch_ticket_block(p.ticket, s_ticket);
+    if (item >= total) break;
+    const int bi = item / num_pid_n, pid_n = item - bi * num_pid_n;
+    const int b = p.order ? p.order[bi] : bi;
+    const int e = p.expert_of_block[b];
+    if (threadIdx.x < BM) {
+      const int flat = p.sorted_ids[b * BM + threadIdx.x];
+      s_arow[threadIdx.x] = flat < 0 ? -1 : (p.a_mode == 0 ? flat / p.topk : flat);
+      s_orow[threadIdx.x] = flat;
+      s_scale[threadIdx.x] = (flat >= 0 && p.row_scale) ? p.row_scale[flat] : 1.f;
+    }
+    if (p.flags && p.seg_range) {
+      const int f0 = p.seg_range[2 * b] * p.cpr, f1 = (p.seg_range[2 * b + 1] + 1) * p.cpr;
+      wait(p.flags + f0, f1 - f0, SCOPE_SYS, SEM_ACQUIRE, p.epoch, p.err);
+    } else {
+      __syncthreads();
+    }
+    TileArgs t;
+    t.A = p.A;
+    t.B = p.B + (long long)e * p.b_expert_stride + (long long)pid_n * BN * p.ldb;
+    t.lda = p.lda;
+    t.ldb = p.ldb;
+    t.a_rows = BM;
+    t.b_rows = p.N - pid_n * BN;
+    t.K = p.K;
+    t.a_gather = s_arow;
+    Acc<IS_BF16> acc;
+    mainloop_256_2ph<IS_BF16>(t, smem, acc);
+    if (p.row_scale) {
+      // accumulator layout: lane holds tile-row (l & 15) of each 16-row block
+      const int w_ = threadIdx.x >> 6, l = threadIdx.x & 63;
+      const int wr = w_ >> 2;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const float sc = s_scale[wr * 128 + m * 16 + (l & 15)];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc.v[m][n] *= sc;
+      }
+    }
+    const int nrem = p.N - pid_n * BN;
+    uint16_t* obase = p.out + pid_n * BN;
+    const long long ldo = p.ldo;
+    epilogue_256<IS_BF16>(acc, smem, [&](int r, int c, const uint4& v) {
+      const int orow = s_orow[r];
+      if (orow >= 0 && c < nrem) *(uint4*)(obase + (long long)orow * ldo + c) = v;
+    });
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// topk reduce + reduce-scatter.  gemm_out [ntokens*topk, N] (already weight-scaled).
+// items 0 .. ntokens-1          : sum topk rows of token t, push to owner d = t / tpr slot [rank]
+// items ntokens .. ntokens+tpr-1: wait all sources, out[t_local] = sum over w slots
+// ------------------------------------------------------------------------------------------------
+struct TopkRsParams {
+  SymmCtx ctx;
+  const uint16_t* gemm_out;
+  uint16_t* scatter;     // symmetric [w][tpr][N]
+  int* flags;            // symmetric [w]
+  int* counters;         // local [w] + ticket at [w]; zeroed before launch
+  int* err;
+  uint16_t* out;         // [tpr, N]
+  int ntokens, topk, N, tpr, epoch;
+};
+
+__global__ __launch_bounds__(256) void moe_topk_reduce_rs_kernel(TopkRsParams p) {
+  __shared__ int s_item;
+  const int w = p.ctx.num_ranks, rank = p.ctx.rank;
+  const int total = p.ntokens + p.tpr;
+  while (true) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_item = atomicAdd(p.counters + w, 1);
+    __syncthreads();
+    const int item = __builtin_amdgcn_readfirstlane(s_item);
+    if (item >= total) break;
+    if (item < p.ntokens) {
+      // visit tokens so that consecutive items go to different owners
+      const int d = (rank + 1 + item % w) % w;
+      const int tl = item / w;
+      // items are laid out as tpr rounds of w owners: (tl, d)
+      if (tl < p.tpr) {
+        const int t = d * p.tpr + tl;
+        uint16_t* dst = ((d == rank) ? p.scatter : symm_at(p.ctx, p.scatter, d)) + ((long long)rank * p.tpr + tl) * p.N;
+        for (int c = threadIdx.x * 8; c < p.N; c += blockDim.x * 8) {
+          float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          for (int k = 0; k < p.topk; ++k) {
+            const uint4 v = *(const uint4*)(p.gemm_out + ((long long)t * p.topk + k) * p.N + c);
+            const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              acc[2 * i] += __builtin_bit_cast(float, x[i] << 16);
+              acc[2 * i + 1] += __builtin_bit_cast(float, x[i] & 0xffff0000u);
+            }
+          }
+          uint4 o;
+          o.x = Frag<true>::pack2(acc[0], acc[1]);
+          o.y = Frag<true>::pack2(acc[2], acc[3]);
+          o.z = Frag<true>::pack2(acc[4], acc[5]);
+          o.w = Frag<true>::pack2(acc[6], acc[7]);
+          *(uint4*)(dst + c) = o;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          const int prev = atom_add_acqrel_agent(p.counters + d, 1);
+          if (prev == p.tpr - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            store_relaxed_system(((d == rank) ? p.flags : symm_at(p.ctx, p.flags, d)) + rank, p.epoch);
+          }
+        }
+      }
+    } else {
+      const int tl = item - p.ntokens;
+      wait(p.flags, w, SCOPE_SYS, SEM_ACQUIRE, p.epoch, p.err);
+      for (int c = threadIdx.x * 8; c < p.N; c += blockDim.x * 8) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < w; ++s) {
+          const uint4 v = *(const uint4*)(p.scatter + ((long long)s * p.tpr + tl) * p.N + c);
+          const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            acc[2 * i] += __builtin_bit_cast(float, x[i] << 16);
+            acc[2 * i + 1] += __builtin_bit_cast(float, x[i] & 0xffff0000u);
+          }
+        }
+        uint4 o;
+        o.x = Frag<true>::pack2(acc[0], acc[1]);
+        o.y = Frag<true>::pack2(acc[2], acc[3]);
+        o.z = Frag<true>::pack2(acc[4], acc[5]);
+        o.w = Frag<true>::pack2(acc[6], acc[7]);
+        *(uint4*)(p.out + (long long)tl * p.N + c) = o;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+TDIST_API int tdist_moe_align(const int* topk_ids, int* sorted_ids, int* expert_of_block, int* seg_range, int* order,
+                              int* meta, int n, int E, int w, int topk, int tokens_per_rank, int rank, int cap,
+                              void* stream) {
+  TDIST_REQUIRE(E > 0 && w > 0 && cap % BM == 0 && cap >= n, "bad align arguments");
+  const size_t lds = (size_t)(2 * E * w + E + 1) * sizeof(int);
+  TDIST_REQUIRE(lds <= 160 * 1024, "too many experts x ranks for one workgroup");
+  AlignParams p{topk_ids, sorted_ids, expert_of_block, seg_range, order, meta, n, E, w, topk, tokens_per_rank, rank, cap};
+  static bool attr_set = false;
+  if (!attr_set) {
+    TDIST_HIP_TRY(hipFuncSetAttribute((const void*)moe_align_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(moe_align_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, p);
+  TDIST_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+TDIST_API int tdist_moe_group_gemm(const void* A, const void* B, void* out, const int* sorted_ids,
+                                   const int* expert_of_block, const int* seg_range, const int* order, const int* meta,
+                                   const float* row_scale, const int* flags, int* ticket, int* err, long long lda,
+                                   long long ldb, long long ldo, long long b_expert_stride, int N, int K, int topk,
+                                   int a_mode, int cpr, int epoch, int num_ctas, int dtype, void* stream) {
+  TDIST_REQUIRE(K >= 128 && K % 64 == 0, "K must be a multiple of 64 and >= 128");
+  TDIST_REQUIRE(N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldo % 8 == 0, "N/lda/ldb/ldo must be multiples of 8");
+  GroupGemmParams p;
+  p.A = (const uint16_t*)A;
+  p.B = (const uint16_t*)B;
+  p.out = (uint16_t*)out;
+  p.sorted_ids = sorted_ids;
+  p.expert_of_block = expert_of_block;
+  p.seg_range = seg_range;
+  p.order = order;
+  p.meta = meta;
+  p.row_scale = row_scale;
+  p.flags = flags;
+  p.ticket = ticket;
+  p.err = err;
+  p.lda = lda;
+  p.ldb = ldb;
+  p.ldo = ldo;
+  p.b_expert_stride = b_expert_stride;
+  p.N = N;
+  p.K = K;
+  p.topk = topk;
+  p.a_mode = a_mode;
+  p.cpr = cpr;
+  p.epoch = epoch;
+  const int lds = LDS_BYTES + 16 + 3 * BM * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    TDIST_HIP_TRY(hipFuncSetAttribute((const void*)moe_group_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    TDIST_HIP_TRY(hipFuncSetAttribute((const void*)moe_group_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  TDIST_HIP_TRY(hipMemsetAsync(ticket, 0, 16, (hipStream_t)stream));
+  const int grid = num_ctas > 0 ? num_ctas : 256;
+  if (dtype == 0)
+    hipLaunchKernelGGL(moe_group_gemm_kernel<true>, dim3(grid), dim3(THREADS), lds, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(moe_group_gemm_kernel<false>, dim3(grid), dim3(THREADS), lds, (hipStream_t)stream, p);
+  TDIST_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+TDIST_API int tdist_moe_topk_reduce_rs(const SymmCtx* ctx, const void* gemm_out, void* scatter, int* flags,
+                                       int* counters, int* err, void* out, int ntokens, int topk, int N, int epoch,
+                                       int num_ctas, void* stream) {
+  const int w = ctx->num_ranks;
+  TDIST_REQUIRE(ntokens % w == 0 && N % 8 == 0, "ntokens must divide by world size and N by 8");
+  TopkRsParams p;
+  p.ctx = *ctx;
+  p.gemm_out = (const uint16_t*)gemm_out;
+  p.scatter = (uint16_t*)scatter;
+  p.flags = flags;
+  p.counters = counters;
+  p.err = err;
+  p.out = (uint16_t*)out;
+  p.ntokens = ntokens;
+  p.topk = topk;
+  p.N = N;
+  p.tpr = ntokens / w;
+  p.epoch = epoch;
+  TDIST_HIP_TRY(hipMemsetAsync(counters, 0, (size_t)(TDIST_MAX_RANKS + 4) * sizeof(int), (hipStream_t)stream));
+  hipLaunchKernelGGL(moe_topk_reduce_rs_kernel, dim3(num_ctas > 0 ? num_ctas : 128), dim3(256), 0, (hipStream_t)stream, p);
+  TDIST_HIP_TRY(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,285 @@
+"""Tensor-parallel MoE ops: AllGather + grouped GEMM and grouped GEMM + topk-reduce + ReduceScatter,
+plus the index utilities around them.
+
+API of the reference:
+* ``create_ag_group_gemm_context`` / ``ag_group_gemm(a, b, ctx, full_topk_ids)`` (reference:
+  python/triton_dist/kernels/nvidia/allgather_group_gemm.py:337-411)
+* ``create_moe_rs_context`` / ``run_moe_reduce_rs(x, weights, chosen_experts, expert_weight, ctx,
+  n_chunks)`` (reference: kernels/nvidia/moe_reduce_rs.py:87-119, :569-656)
+* ``moe_utils``: ``calc_gather_scatter_index``, ``reduce_topk``, histogram (reference:
+  kernels/nvidia/moe_utils.py:95-405) and ``moe_ag_scatter_align_block_size`` (csrc/lib/moe_utils.cu)
+
+Expert weights are consumed K-contiguous: ``[E, N, K]``.  The reference's ``[E, K, N]`` layout is
+accepted and converted once per weight tensor (cached).
+"""
+from __future__ import annotations
+
+import ctypes
+import dataclasses
+from typing import Any, Optional
+
+import torch
+
+from .. import _lib
+from ..utils.distributed import get_env
+from .ag_gemm import (AllGatherGEMMTensorParallelContext, EPOCH_MOD, _push_kernel, _rows_per_chunk,
+                      create_ag_gemm_intra_node_context)
+from .gemm import _DT
+
+BLOCK_M = 256
+
+
+# ---- index utilities ----------------------------------------------------------------------------
+@dataclasses.dataclass(repr=False)
+class AlignedIndex:
+    sorted_ids: torch.Tensor        # [cap] flat (token*topk+k) or -1
+    expert_of_block: torch.Tensor   # [cap/256]
+    seg_range: torch.Tensor         # [cap/256, 2]
+    order: torch.Tensor             # [cap/256]
+    meta: torch.Tensor              # [2+E]: num_blocks, padded rows, tokens per expert
+
+
+def moe_align_block_size(topk_ids: torch.Tensor, num_experts: int, world_size: int = 1, rank: int = 0,
+                         tokens_per_rank: Optional[int] = None) -> AlignedIndex:
+    """Sort (token, k) pairs by (expert, source rank) and pad every expert to 256 rows."""
+    ids = topk_ids.to(torch.int32).contiguous()
+    ntokens, topk = ids.shape
+    n = ntokens * topk
+    tokens_per_rank = tokens_per_rank or max(1, ntokens // world_size)
+    cap = (n + num_experts * (BLOCK_M - 1) + BLOCK_M - 1) // BLOCK_M * BLOCK_M
+    dev = ids.device
+    if not ids.is_cuda:
+        return _align_cpu(ids, num_experts, world_size, rank, tokens_per_rank, cap)
+    nb = cap // BLOCK_M
+    out = AlignedIndex(torch.empty(cap, dtype=torch.int32, device=dev), torch.zeros(nb, dtype=torch.int32, device=dev),
+                       torch.zeros((nb, 2), dtype=torch.int32, device=dev), torch.zeros(nb, dtype=torch.int32, device=dev),
+                       torch.zeros(2 + num_experts, dtype=torch.int32, device=dev))
+    _lib.check(
+        _lib.hip().tdist_moe_align(_lib.ptr(ids), _lib.ptr(out.sorted_ids), _lib.ptr(out.expert_of_block),
+                                   _lib.ptr(out.seg_range), _lib.ptr(out.order), _lib.ptr(out.meta), n, num_experts,
+                                   world_size, topk, tokens_per_rank, rank, cap, _lib.stream_handle()),
+        "tdist_moe_align")
+    return out
+
+
+def _align_cpu(ids, E, w, rank, tpr, cap):
+    """Reference implementation (also the oracle of the GPU kernel's tests)."""
+    ntokens, topk = ids.shape
+    flat_e = ids.reshape(-1).long()
+    src = (torch.arange(ntokens * topk) // topk // tpr).clamp(max=w - 1)
+    key = flat_e * w + src
+    order = torch.sort(key, stable=True).indices
+    counts = torch.bincount(flat_e, minlength=E)
+    padded = (counts + BLOCK_M - 1) // BLOCK_M * BLOCK_M
+    pad_off = torch.cumsum(padded, 0) - padded
+    sorted_ids = torch.full((cap,), -1, dtype=torch.int32)
+    start = torch.cumsum(counts, 0) - counts
+    for e in range(E):
+        c = int(counts[e])
+        sorted_ids[int(pad_off[e]): int(pad_off[e]) + c] = order[int(start[e]): int(start[e]) + c].int()
+    nb = cap // BLOCK_M
+    nblocks = int(padded.sum()) // BLOCK_M
+    eob = torch.zeros(nb, dtype=torch.int32)
+    seg = torch.zeros((nb, 2), dtype=torch.int32)
+    for b in range(nblocks):
+        rows = sorted_ids[b * BLOCK_M:(b + 1) * BLOCK_M]
+        valid = rows[rows >= 0].long()
+        eob[b] = int(flat_e[valid[0]])
+        s = src[valid]
+        seg[b, 0], seg[b, 1] = int(s.min()), int(s.max())
+    stage = [max((s - rank + w) % w for s in range(int(seg[b, 0]), int(seg[b, 1]) + 1)) for b in range(nblocks)]
+    ordv = torch.zeros(nb, dtype=torch.int32)
+    ordv[:nblocks] = torch.tensor(sorted(range(nblocks), key=lambda b: (stage[b], b)), dtype=torch.int32)
+    meta = torch.zeros(2 + E, dtype=torch.int32)
+    meta[0], meta[1] = nblocks, int(padded.sum())
+    meta[2:] = counts.int()
+    return AlignedIndex(sorted_ids, eob, seg, ordv, meta)
+
+
+def calc_gather_scatter_index(choosed_experts: torch.Tensor, num_experts: int):
+    """(gather_index, scatter_index, splits): rows sorted by expert (stable)."""
+    flat = choosed_experts.reshape(-1).long()
+    gather_index = torch.sort(flat, stable=True).indices.int()
+    scatter_index = torch.empty_like(gather_index)
+    scatter_index[gather_index.long()] = torch.arange(flat.numel(), device=flat.device, dtype=torch.int32)
+    return gather_index, scatter_index, torch.bincount(flat, minlength=num_experts).int()
+
+
+def histogram(x: torch.Tensor, bins: int) -> torch.Tensor:
+    return torch.bincount(x.reshape(-1).long(), minlength=bins).int()
+
+
+def reduce_topk(x: torch.Tensor, topk: int, weights: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[ntokens*topk, N] -> [ntokens, N] (optionally weighted), fp32 accumulation."""
+    n = x.shape[0] // topk
+    xf = x.float().view(n, topk, -1)
+    if weights is not None:
+        xf = xf * weights.float().view(n, topk, 1)
+    return xf.sum(1).to(x.dtype)
+
+
+_WEIGHT_CACHE = {}
+
+
+def _as_enk(b: torch.Tensor, N: int, K: int) -> torch.Tensor:
+    """Expert weights as [E, N, K] contiguous."""
+    if b.shape[1] == N and b.shape[2] == K and b.is_contiguous():
+        return b   # (square weights are taken as [E, N, K])
+    key = (b.data_ptr(), b._version, tuple(b.shape))
+    if key not in _WEIGHT_CACHE:
+        _WEIGHT_CACHE.clear()
+        _WEIGHT_CACHE[key] = b.transpose(1, 2).contiguous()
+    return _WEIGHT_CACHE[key]
+
+
+# ---- AllGather + grouped GEMM -----------------------------------------------------------------
+@dataclasses.dataclass(repr=False)
+class MoEAllGatherGroupGEMMTensorParallelContext:
+    ag: AllGatherGEMMTensorParallelContext
+    num_experts: int
+    topk: int
+    N_per_rank: int
+    K: int
+    rank: int
+    num_ranks: int
+    env: Any = None
+    num_ctas: int = 0
+
+    def check_error(self):
+        self.ag.check_error()
+
+
+def create_ag_group_gemm_context(max_ntokens, N_per_rank, K, num_experts, topk, dtype, rank, num_ranks,
+                                 num_local_ranks=8, BLOCK_SIZE_M=256, BLOCK_SIZE_N=256, BLOCK_SIZE_K=64,
+                                 GROUP_SIZE_M=8, stages=2, num_warps=8, num_ctas=0, ag_streams=None, env=None):
+    env = env or get_env()
+    ag = create_ag_gemm_intra_node_context(max_ntokens, N_per_rank, K, dtype, dtype, rank, num_ranks,
+                                           producer="kernel", num_ctas=num_ctas, ag_streams=ag_streams, env=env)
+    return MoEAllGatherGroupGEMMTensorParallelContext(ag, num_experts, topk, N_per_rank, K, rank, num_ranks, env, num_ctas)
+
+
+def ag_group_gemm(a: torch.Tensor, b: torch.Tensor, ctx: MoEAllGatherGroupGEMMTensorParallelContext,
+                  full_topk_ids: torch.Tensor) -> torch.Tensor:
+    """a [ntokens/w, K] local tokens, b expert weights ([E, N/w, K] or [E, K, N/w]), full_topk_ids
+    [ntokens, topk] (already all-gathered).  Returns [ntokens*topk, N/w]: row token*topk+k is
+    token's activation through expert full_topk_ids[token, k]."""
+    ag, env = ctx.ag, ctx.env
+    w, rank = ctx.num_ranks, ctx.rank
+    M_per_rank, K = a.shape
+    ntokens, topk = full_topk_ids.shape
+    assert ntokens == M_per_rank * w and K == ctx.K
+    N = ctx.N_per_rank
+    if env.backend == "host" or not a.is_cuda:
+        raise NotImplementedError("ag_group_gemm runs on the GPU backend")
+    b = _as_enk(b, N, K)
+    a = a.contiguous()
+    idx = moe_align_block_size(full_topk_ids, ctx.num_experts, w, rank, M_per_rank)
+    out = torch.empty((ntokens * topk, N), dtype=a.dtype, device=a.device)
+    parity = ag.call_count & 1
+    epoch = ag.call_count % EPOCH_MOD + 1
+    ag.call_count += 1
+    rpc = _rows_per_chunk(M_per_rank, ag.M_PER_CHUNK)
+    cur = torch.cuda.current_stream()
+    used = []
+    if w > 1:
+        side = ag.ag_streams[0]
+        side.wait_stream(cur)
+        _push_kernel(ag, a, parity, epoch, rpc, True, side)      # own shard goes into the workspace too
+        used = [side]
+        A, flags = ag.workspaces[parity][rank], ag.flags[parity][rank]
+    else:
+        A, flags = a, None
+    _lib.check(
+        _lib.hip().tdist_moe_group_gemm(_lib.ptr(A), _lib.ptr(b), _lib.ptr(out), _lib.ptr(idx.sorted_ids),
+                                        _lib.ptr(idx.expert_of_block), _lib.ptr(idx.seg_range) if w > 1 else None,
+                                        _lib.ptr(idx.order) if w > 1 else None, _lib.ptr(idx.meta), None,
+                                        _lib.ptr(flags), _lib.ptr(ag.scratch), _lib.ptr(ag.scratch[4:]),
+                                        ctypes.c_longlong(A.stride(0)), ctypes.c_longlong(b.stride(1)),
+                                        ctypes.c_longlong(out.stride(0)), ctypes.c_longlong(b.stride(0)), N, K, topk, 0,
+                                        M_per_rank // rpc, epoch, ctx.num_ctas, _DT[a.dtype], _lib.stream_handle(cur)),
+        "tdist_moe_group_gemm")
+    for s in used:
+        cur.wait_stream(s)
+    return out
+
+
+# ---- grouped GEMM + topk reduce + ReduceScatter -----------------------------------------------
+@dataclasses.dataclass(repr=False)
+class MoEReduceRSContext:
+    rank: int
+    world_size: int
+    max_token_num: int
+    hidden_dim: int
+    num_experts: int
+    topk: int
+    dtype: torch.dtype
+    scatter: list
+    flags: list
+    scratch: Optional[torch.Tensor]
+    env: Any = None
+    num_ctas: int = 0
+    call_count: int = 0
+
+    def check_error(self):
+        if self.scratch is not None and int(self.scratch[40]) != 0:
+            raise RuntimeError("moe_reduce_rs: a device-side wait timed out")
+
+
+def create_moe_rs_context(rank, world_size, local_world_size, max_token_num, hidden_dim, num_experts, topk,
+                          input_dtype, n_chunks_max=8, num_ctas=0, env=None) -> MoEReduceRSContext:
+    env = env or get_env()
+    heap = env.heap
+    scatter, flags = [], []
+    for _ in range(2):
+        scatter.append(heap.create_tensor_list([max_token_num, hidden_dim], input_dtype, zero=False))
+        flags.append(heap.create_tensor_list([world_size], torch.int32, arena="sig"))
+    scratch = torch.zeros(64, dtype=torch.int32, device=env.device) if env.backend == "hip" else None
+    if env.backend == "hip":
+        torch.cuda.synchronize()
+    if env.cpu_group is not None:
+        torch.distributed.barrier(group=env.cpu_group)
+    return MoEReduceRSContext(rank, world_size, max_token_num, hidden_dim, num_experts, topk, input_dtype, scatter,
+                              flags, scratch, env, num_ctas)
+
+
+def run_moe_reduce_rs(x: torch.Tensor, weights: torch.Tensor, chosen_experts: torch.Tensor,
+                      expert_weight: torch.Tensor, ctx: MoEReduceRSContext, n_chunks: int = 2, config=None):
+    """x [ntokens*topk, K/w] (row token*topk+k), weights = expert weights ([E, hidden, K/w] or
+    [E, K/w, hidden]), chosen_experts [ntokens, topk], expert_weight [ntokens, topk] routing
+    weights.  Returns [ntokens/w, hidden] = ReduceScatter_tokens(sum_k w_k * x_k @ W[e_k])."""
+    env = ctx.env
+    w, rank = ctx.world_size, ctx.rank
+    ntokens, topk = chosen_experts.shape
+    K = x.shape[1]
+    N = ctx.hidden_dim
+    assert x.shape[0] == ntokens * topk and ntokens % w == 0 and ntokens <= ctx.max_token_num
+    if env.backend == "host" or not x.is_cuda:
+        raise NotImplementedError("run_moe_reduce_rs runs on the GPU backend")
+    b = _as_enk(weights, N, K)
+    x = x.contiguous()
+    idx = moe_align_block_size(chosen_experts, ctx.num_experts, 1, 0, ntokens)
+    gemm_out = torch.empty((ntokens * topk, N), dtype=x.dtype, device=x.device)
+    scale = expert_weight.reshape(-1).to(torch.float32).contiguous()
+    lib = _lib.hip()
+    _lib.check(
+        lib.tdist_moe_group_gemm(_lib.ptr(x), _lib.ptr(b), _lib.ptr(gemm_out), _lib.ptr(idx.sorted_ids),
+                                 _lib.ptr(idx.expert_of_block), None, None, _lib.ptr(idx.meta), _lib.ptr(scale), None,
+                                 _lib.ptr(ctx.scratch[48:]), _lib.ptr(ctx.scratch[40:]), ctypes.c_longlong(x.stride(0)),
+                                 ctypes.c_longlong(b.stride(1)), ctypes.c_longlong(gemm_out.stride(0)),
+                                 ctypes.c_longlong(b.stride(0)), N, K, topk, 1, 1, 0, ctx.num_ctas, _DT[x.dtype],
+                                 _lib.stream_handle()), "tdist_moe_group_gemm")
+    if w == 1:
+        from .moe import reduce_topk as _rt
+
+        return _rt(gemm_out, topk)
+    parity = ctx.call_count & 1
+    epoch = ctx.call_count % EPOCH_MOD + 1
+    ctx.call_count += 1
+    out = torch.empty((ntokens // w, N), dtype=x.dtype, device=x.device)
+    cs = env.heap.ctx_struct()
+    _lib.check(
+        lib.tdist_moe_topk_reduce_rs(ctypes.byref(cs), _lib.ptr(gemm_out), _lib.ptr(ctx.scatter[parity][rank]),
+                                     _lib.ptr(ctx.flags[parity][rank]), _lib.ptr(ctx.scratch), _lib.ptr(ctx.scratch[40:]),
+                                     _lib.ptr(out), ntokens, topk, N, epoch, ctx.num_ctas, _lib.stream_handle()),
+        "tdist_moe_topk_reduce_rs")
+    return out
