@@ -1,0 +1,166 @@
+"""Flash-decode (split-KV / fused / intra-rank + inter-rank merge), varlen flash attention and
+sequence-parallel all-gather attention vs fp32 PyTorch references (scenarios of the reference's
+test_decode_attn.py, test_sp_decode_attn.py and test_sp_ag_attention_intra_node.py)."""
+import math
+
+import pytest
+import torch
+
+from triton_distributed_gh_amd.ops import flash_decode as fd
+from triton_distributed_gh_amd.ops.flash_attn import (attention_reference, flash_attn_varlen_fwd,
+                                                      flash_attn_with_kvcache)
+from triton_distributed_gh_amd.ops.sp_ag_attention import (create_sp_ag_attention_context_intra_node,
+                                                           fused_sp_ag_attn_intra_node, shard_positions)
+from triton_distributed_gh_amd.utils.testing import VirtualCluster
+
+pytestmark = pytest.mark.gpu
+
+
+def _paged_cache(batch, kv_lens, page, kv_heads, D, dtype, extra_pages=3):
+    max_pages = max((int(l) + page - 1) // page for l in kv_lens) + 1
+    total_pages = batch * max_pages + extra_pages
+    k = (torch.randn(total_pages, page, kv_heads, D, device="cuda") * 0.5).to(dtype)
+    v = (torch.randn(total_pages, page, kv_heads, D, device="cuda") * 0.5).to(dtype)
+    perm = torch.randperm(total_pages, device="cuda")[: batch * max_pages].int().view(batch, max_pages)
+    return k, v, perm.contiguous()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("batch,q_heads,kv_heads,D,page,kv_split,soft_cap", [
+    (2, 32, 4, 128, 16, 4, 0.0),
+    (3, 24, 3, 128, 1, -1, 0.0),
+    (1, 8, 8, 64, 64, 3, 0.0),
+    (2, 40, 2, 128, 32, 8, 30.0),
+    (1, 16, 2, 256, 16, 2, 0.0),
+])
+def test_flash_decode_variants(dtype, batch, q_heads, kv_heads, D, page, kv_split, soft_cap):
+    kv_lens = torch.tensor([1000, 37, 513][:batch], dtype=torch.int32, device="cuda")
+    k, v, table = _paged_cache(batch, kv_lens.tolist(), page, kv_heads, D, dtype)
+    q = torch.randn(batch, q_heads, D, device="cuda").to(dtype)
+    scale = 1.0 / math.sqrt(D)
+    ref, ref_lse = fd.decode_reference(q, k, v, kv_lens, table, scale, soft_cap, return_lse=True)
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    o1 = fd.gqa_fwd_batch_decode(q, k, v, None, None, kv_lens, table, scale, soft_cap, kv_split=kv_split)
+    o2 = fd.gqa_fwd_batch_decode_persistent(q, k, v, None, None, kv_lens, table, scale, soft_cap, kv_split=kv_split)
+    o3 = fd.gqa_fwd_batch_decode_intra_rank(q, k, v, None, None, kv_lens, table, scale, soft_cap, kv_split=kv_split)
+    torch.cuda.synchronize()
+    assert (o1.float() - ref).abs().max().item() < tol
+    assert (o2.float() - ref).abs().max().item() < tol
+    assert (o3[..., :D] - ref).abs().max().item() < tol
+    assert (o3[..., D] - ref_lse).abs().max().item() < 2e-2
+    # a second fused launch must find its tickets reset
+    o4 = fd.gqa_fwd_batch_decode_persistent(q, k, v, None, None, kv_lens, table, scale, soft_cap, kv_split=kv_split)
+    assert torch.equal(o2, o4)
+
+
+def test_flash_decode_zero_length_and_inter_rank_merge():
+    R, batch, q_heads, kv_heads, D, page = 4, 2, 16, 2, 128, 16
+    dtype = torch.bfloat16
+    lens = torch.tensor([[300, 0], [17, 90], [0, 0], [129, 64]], dtype=torch.int32, device="cuda")
+    q = torch.randn(batch, q_heads, D, device="cuda").to(dtype)
+    scale = 1.0 / math.sqrt(D)
+    parts, ks, vs = [], [], []
+    for r in range(R):
+        k, v, table = _paged_cache(batch, [max(int(x), 1) for x in lens[r]], page, kv_heads, D, dtype)
+        parts.append(fd.gqa_fwd_batch_decode_intra_rank(q, k, v, None, None, lens[r].contiguous(), table, scale))
+        for b in range(batch):
+            L = int(lens[r, b])
+            npg = (L + page - 1) // page
+            ks.append((b, k[table[b, :npg].long()].reshape(-1, kv_heads, D)[:L]))
+            vs.append((b, v[table[b, :npg].long()].reshape(-1, kv_heads, D)[:L]))
+    out = fd.gqa_fwd_batch_decode_inter_rank_combine(torch.stack(parts), lens, dtype=dtype)
+    for b in range(batch):
+        kk = torch.cat([t for bb, t in ks if bb == b]).float()
+        vv = torch.cat([t for bb, t in vs if bb == b]).float()
+        s = torch.einsum("hgd,lhd->hgl", q[b].float().view(kv_heads, -1, D), kk) * scale
+        ref = torch.einsum("hgl,lhd->hgd", torch.softmax(s, -1), vv).reshape(q_heads, D)
+        assert (out[b].float() - ref).abs().max().item() < 2e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("seqs_q,seqs_k,Hq,Hkv,D,causal", [
+    ([128], [128], 4, 4, 128, True),
+    ([200, 77, 333], [200, 77, 333], 8, 2, 128, True),
+    ([64, 130], [300, 130], 6, 3, 64, True),
+    ([100, 260], [150, 260], 4, 1, 128, False),
+])
+def test_flash_attn_varlen(dtype, seqs_q, seqs_k, Hq, Hkv, D, causal):
+    cu_q = torch.tensor([0] + list(torch.tensor(seqs_q).cumsum(0)), dtype=torch.int32, device="cuda")
+    cu_k = torch.tensor([0] + list(torch.tensor(seqs_k).cumsum(0)), dtype=torch.int32, device="cuda")
+    q = torch.randn(sum(seqs_q), Hq, D, device="cuda").to(dtype)
+    k = torch.randn(sum(seqs_k), Hkv, D, device="cuda").to(dtype)
+    v = torch.randn(sum(seqs_k), Hkv, D, device="cuda").to(dtype)
+    out, lse = flash_attn_varlen_fwd(q, k, v, cu_q, cu_k, max(seqs_q), causal=causal, return_lse=True)
+    ref = attention_reference(q, k, v, cu_q.tolist(), cu_k.tolist(), causal)
+    torch.cuda.synchronize()
+    tol = 3e-2 if dtype == torch.bfloat16 else 5e-3
+    assert (out.float() - ref).abs().max().item() < tol
+    assert torch.isfinite(lse).all()
+
+
+def test_flash_attn_with_kvcache_prefill_then_decode():
+    B, Hq, Hkv, D, max_len = 2, 8, 2, 128, 512
+    dtype = torch.bfloat16
+    kc = torch.zeros(B, max_len, Hkv, D, device="cuda", dtype=dtype)
+    vc = torch.zeros_like(kc)
+    S = 96
+    q = torch.randn(B, S, Hq, D, device="cuda").to(dtype)
+    k = torch.randn(B, S, Hkv, D, device="cuda").to(dtype)
+    v = torch.randn(B, S, Hkv, D, device="cuda").to(dtype)
+    lens = torch.zeros(B, dtype=torch.int32, device="cuda")
+    o = flash_attn_with_kvcache(q, kc, vc, k, v, cache_seqlens=lens)
+    for b in range(B):
+        ref = attention_reference(q[b], k[b], v[b], [0, S], [0, S], True)
+        assert (o[b].float() - ref).abs().max().item() < 3e-2
+    assert torch.equal(kc[:, :S], k) and torch.equal(vc[:, :S], v)
+    q1 = torch.randn(B, 1, Hq, D, device="cuda").to(dtype)
+    k1 = torch.randn(B, 1, Hkv, D, device="cuda").to(dtype)
+    v1 = torch.randn(B, 1, Hkv, D, device="cuda").to(dtype)
+    lens = torch.full((B,), S, dtype=torch.int32, device="cuda")
+    o1 = flash_attn_with_kvcache(q1, kc, vc, k1, v1, cache_seqlens=lens)
+    for b in range(B):
+        kk = torch.cat([k[b], k1[b]])
+        vv = torch.cat([v[b], v1[b]])
+        ref = attention_reference(q1[b], kk, vv, [0, 1], [0, S + 1], True)
+        assert (o1[b].float() - ref).abs().max().item() < 3e-2
+
+
+@pytest.mark.parametrize("w,zigzag,causal", [(2, True, True), (4, True, True), (4, False, True), (8, True, True),
+                                               (2, False, False)])
+def test_sp_ag_attention(w, zigzag, causal):
+    Hq, Hkv, D = 4, 2, 128
+    dtype = torch.bfloat16
+    full = [64 * 2 * w, 128 * 2 * w]                 # per-sequence full lengths (multiples of 64 per half-block)
+    shard = [L // w for L in full]
+    cu_k = torch.tensor([0, full[0], full[0] + full[1]], dtype=torch.int32, device="cuda")
+    cu_q = torch.tensor([0, shard[0], shard[0] + shard[1]], dtype=torch.int32, device="cuda")
+    vc = VirtualCluster(w, heap_bytes=1 << 27)
+    try:
+        ctxs = vc.collective(lambda r, env: create_sp_ag_attention_context_intra_node(
+            2, Hq, Hkv, max(full), max(shard), D, dtype, dtype, r, w, ag_stream=vc.side_streams[r], env=env))
+        for it in range(3):
+            qf = torch.randn(sum(full), Hq, D, device="cuda").to(dtype)
+            kf = torch.randn(sum(full), Hkv, D, device="cuda").to(dtype)
+            vf = torch.randn(sum(full), Hkv, D, device="cuda").to(dtype)
+            ref = attention_reference(qf, kf, vf, cu_k.tolist(), cu_k.tolist(), causal)
+
+            def rows(r):
+                idx = []
+                for b in range(2):
+                    pos = shard_positions([0, shard[b]], r, w, zigzag)
+                    idx.append(pos + int(cu_k[b]))
+                return torch.cat(idx).cuda()
+
+            qs = [qf[rows(r)].contiguous() for r in range(w)]
+            ks = [kf[rows(r)].contiguous() for r in range(w)]
+            vs = [vf[rows(r)].contiguous() for r in range(w)]
+            outs = [torch.empty_like(qs[r]) for r in range(w)]
+            torch.cuda.synchronize()
+            vc.run(lambda r, env: fused_sp_ag_attn_intra_node(ctxs[r], qs[r], ks[r], vs[r], outs[r], cu_q, cu_k,
+                                                              max(shard), max(full), r, w, causal, zigzag))
+            for r in range(w):
+                ctxs[r].check_error()
+                err = (outs[r].float() - ref[rows(r)]).abs().max().item()
+                assert err < 3e-2, f"rank {r} iter {it}: {err}"
+    finally:
+        vc.close()

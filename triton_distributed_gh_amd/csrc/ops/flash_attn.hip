@@ -1,0 +1,409 @@
+// Variable-length causal GQA flash-attention forward for gfx950 and the sequence-parallel
+// KV all-gather that feeds it.
+//
+// Role in the reference: kernels/nvidia/sp_ag_attention_intra_node.py - KV all-gather producer
+// (:105-183) and kernel_consumer_flash_attn_forward (:255-425); the same kernel serves the
+// prefill attention of the TP attention layer (layers/amd/tp_attn.py:275-308 uses flash_attn).
+//
+// Attention kernel: one workgroup (4 waves) per 128 query rows of one (sequence, head); each wave
+// owns 32 rows = two 16-row MFMA column blocks.  K/V blocks of 32 tokens are staged once per
+// workgroup in double-buffered LDS (one barrier per block).  As in the decode kernel the scores
+// are produced transposed (S^T = K.Q^T) so the P operand of O^T = V^T.P^T falls out of the
+// accumulators without cross-lane traffic and the V operand is an in-register transpose of
+// eight 16-byte LDS row reads.
+//
+// Sequence parallelism: the query rows of a rank map to global positions either contiguously
+// or zig-zag (rank r owns half-blocks r and 2w-1-r), and the kernel can wait on per-source-rank
+// arrival flags right before it first touches a rank's slab of the gathered KV, so attention
+// over early slabs overlaps the rest of the gather (the reference joins the streams instead).
+#include "tdist/common.hpp"
+#include "tdist/atomics.hpp"
+#include "tdist/gemm_gfx950.hpp"
+#include "tdist/primitives.hpp"
+#include "tdist/shmem_device.hpp"
+
+namespace {
+
+using namespace tdist;
+using tdist::gemm::f32x4;
+using tdist::gemm::Frag;
+
+struct AttnArgs {
+  const uint16_t *q, *k, *v;
+  uint16_t* o;
+  float* lse;              // optional [q_heads, total_q]
+  const int *cu_q, *cu_k;  // [batch + 1]
+  long long q_stride_t, q_stride_h, k_stride_t, k_stride_h, v_stride_t, v_stride_h, o_stride_t, o_stride_h;
+  long long lse_stride_h;
+  int q_heads, kv_heads;
+  int causal;
+  int pos_mode;            // 0: q rows are the LAST Lq positions of the sequence; 1: contiguous shard of
+                           // rank `rank`; 2: zig-zag shard of rank `rank`
+  int rank, world;
+  float sm_scale;
+  const int* flags;        // optional [world] KV arrival flags (value == epoch when slab landed)
+  int epoch;
+  int* err;
+};
+
+__device__ __forceinline__ int q_position(const AttnArgs& a, int i, int Lq, int Lk) {
+  if (a.pos_mode == 0) return i + (Lk - Lq);
+  if (a.pos_mode == 1) return a.rank * Lq + i;
+  const int half = Lq >> 1;
+  return i < half ? a.rank * half + i : (2 * a.world - 1 - a.rank) * half + (i - half);
+}
+
+__device__ __forceinline__ int kv_source_rank(const AttnArgs& a, int n, int Lk) {
+  if (a.pos_mode == 2) {
+    const int half = max(Lk / (2 * a.world), 1);
+    const int blk = min(n / half, 2 * a.world - 1);
+    return blk < a.world ? blk : 2 * a.world - 1 - blk;
+  }
+  const int per = max(Lk / a.world, 1);
+  return min(n / per, a.world - 1);
+}
+
+template <bool IS_BF16, int D>
+__global__ __launch_bounds__(256) void flash_attn_fwd_kernel(AttnArgs a) {
+  using F = Frag<IS_BF16>;
+  using VT = typename F::T;
+  constexpr int KS = D / 32;
+  constexpr int NDV = D / 16;
+  constexpr int VW = NDV / 2;
+  constexpr int ROW_B = D * 2 + 16;          // padded LDS row (bytes): 16 rows hit 16 distinct bank quads
+  constexpr int TILE_B = 32 * ROW_B;
+  constexpr int CPR = D / 8;                 // 16-byte chunks per row
+  constexpr int LD_PER_T = (32 * CPR) / 256; // 16-byte loads per thread per tile
+  constexpr float LOG2E = 1.4426950408889634f;
+
+  extern __shared__ char smem[];             // [2 stages][K tile, V tile]
+
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = a.cu_q[b], Lq = a.cu_q[b + 1] - q0;
+  const int k0 = a.cu_k[b], Lk = a.cu_k[b + 1] - k0;
+  const int m0 = blockIdx.x * 128;
+  if (m0 >= Lq) return;
+  const int kvh = h / (a.q_heads / a.kv_heads);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int row_base = m0 + wave * 32;
+
+  // ---- Q operand (column block rb, head-dim step s): lane (row li, k-group lg)
+  VT qreg[2][KS];
+  int qpos[2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    const int r = row_base + 16 * rb + li;
+    qpos[rb] = r < Lq ? q_position(a, r, Lq, Lk) : -1;
+    const uint16_t* qp = a.q + (long long)(q0 + min(r, Lq - 1)) * a.q_stride_t + (long long)h * a.q_stride_h + lg * 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      uint4 v = uint4{0, 0, 0, 0};
+      if (r < Lq) v = *(const uint4*)(qp + 32 * s);
+      qreg[rb][s] = __builtin_bit_cast(VT, v);
+    }
+  }
+  const int last_row = min(m0 + 127, Lq - 1);
+  const int kv_hi = a.causal ? min(Lk, q_position(a, last_row, Lq, Lk) + 1) : Lk;
+  const int wave_last = min(row_base + 31, Lq - 1);
+  const int wave_hi = row_base >= Lq ? 0 : (a.causal ? min(Lk, q_position(a, wave_last, Lq, Lk) + 1) : Lk);
+  const int nblk = (kv_hi + 31) / 32;
+
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  f32x4 acc[2][NDV];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int j = 0; j < NDV; ++j) acc[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const float scale2 = a.sm_scale * LOG2E;
+  const uint16_t* kg = a.k + (long long)k0 * a.k_stride_t + (long long)kvh * a.k_stride_h;
+  const uint16_t* vg = a.v + (long long)k0 * a.v_stride_t + (long long)kvh * a.v_stride_h;
+  unsigned seen = 0;   // bit r: rank r's KV slab is known to have landed
+
+  uint4 kst[LD_PER_T], vst[LD_PER_T];
+  auto issue = [&](int blk) {
+    const int n0 = blk * 32;
+    if (a.flags) {
+      const int r_lo = kv_source_rank(a, n0, Lk), r_hi = kv_source_rank(a, min(n0 + 31, Lk - 1), Lk);
+      for (int r = r_lo;; r = r_hi) {
+        if (!((seen >> r) & 1u)) {
+          (void)wait(a.flags + r, 1, SCOPE_SYS, SEM_ACQUIRE, a.epoch, a.err);
+          seen |= 1u << r;
+        }
+        if (r == r_hi) break;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < LD_PER_T; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      const int row = idx / CPR, ch = idx - row * CPR;
+      const int tok = min(n0 + row, Lk - 1);
+      kst[i] = *(const uint4*)(kg + (long long)tok * a.k_stride_t + ch * 8);
+      vst[i] = *(const uint4*)(vg + (long long)tok * a.v_stride_t + ch * 8);
+    }
+  };
+  auto commit = [&](int stage) {
+    char* kt = smem + stage * 2 * TILE_B;
+    char* vt = kt + TILE_B;
+#pragma unroll
+    for (int i = 0; i < LD_PER_T; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      const int row = idx / CPR, ch = idx - row * CPR;
+      *(uint4*)(kt + row * ROW_B + ch * 16) = kst[i];
+      *(uint4*)(vt + row * ROW_B + ch * 16) = vst[i];
+    }
+  };
+
+  if (nblk > 0) {
+    issue(0);
+    commit(0);
+    __syncthreads();
+    if (nblk > 1) issue(1);
+  }
+
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int n0 = blk * 32;
+    const char* kt = smem + (blk & 1) * 2 * TILE_B;
+    const char* vt = kt + TILE_B;
+    if (n0 < wave_hi) {
+      VT kfr[2][KS];
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+          kfr[tb][s] = __builtin_bit_cast(VT, *(const uint4*)(kt + (16 * tb + li) * ROW_B + (32 * s + 8 * lg) * 2));
+      uint32_t vreg[8][VW];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const char* vp = vt + (16 * (t >> 2) + 4 * lg + (t & 3)) * ROW_B + li * NDV * 2;
+        if constexpr (VW >= 4) {
+#pragma unroll
+          for (int c = 0; c < VW / 4; ++c) {
+            const uint4 v = *(const uint4*)(vp + 16 * c);
+            vreg[t][4 * c] = v.x, vreg[t][4 * c + 1] = v.y, vreg[t][4 * c + 2] = v.z, vreg[t][4 * c + 3] = v.w;
+          }
+        } else {
+          const uint2 v = *(const uint2*)vp;
+          vreg[t][0] = v.x, vreg[t][1] = v.y;
+        }
+      }
+      VT pfrag[2];
+      float alpha[2];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        f32x4 st[2];
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+          st[tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < KS; ++s) st[tb] = F::mfma(kfr[tb][s], qreg[rb][s], st[tb]);
+        }
+        float sc[8];
+        float mx = -INFINITY;
+        const int lim = a.causal ? min(qpos[rb], Lk - 1) : (qpos[rb] < 0 ? -1 : Lk - 1);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const int tok = n0 + 16 * (t >> 2) + 4 * lg + (t & 3);
+          const float s = tok <= lim ? st[t >> 2][t & 3] * scale2 : -INFINITY;
+          sc[t] = s;
+          mx = fmaxf(mx, s);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run[rb], mx);
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;
+        alpha[rb] = __builtin_amdgcn_exp2f(m_run[rb] - m_use);
+        m_run[rb] = m_new;
+        float psum = 0.f;
+        uint32_t pw[4];
+#pragma unroll
+        for (int t = 0; t < 8; t += 2) {
+          const float p0 = __builtin_amdgcn_exp2f(sc[t] - m_use), p1 = __builtin_amdgcn_exp2f(sc[t + 1] - m_use);
+          psum += p0 + p1;
+          pw[t >> 1] = F::pack2(p0, p1);
+        }
+        l_run[rb] = l_run[rb] * alpha[rb] + psum;
+        pfrag[rb] = __builtin_bit_cast(VT, uint4{pw[0], pw[1], pw[2], pw[3]});
+      }
+#pragma unroll
+      for (int j = 0; j < NDV; ++j) {
+        const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
+        uint32_t vw[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) vw[p] = __builtin_amdgcn_perm(vreg[2 * p + 1][j >> 1], vreg[2 * p][j >> 1], sel);
+        const VT vfrag = __builtin_bit_cast(VT, uint4{vw[0], vw[1], vw[2], vw[3]});
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          f32x4 c = acc[rb][j];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) c[i] *= alpha[rb];
+          acc[rb][j] = F::mfma(vfrag, pfrag[rb], c);
+        }
+      }
+    }
+    if (blk + 1 < nblk) {
+      commit((blk + 1) & 1);
+      __syncthreads();
+      if (blk + 2 < nblk) issue(blk + 2);
+    }
+  }
+
+  // ---- epilogue: normalise, stage this wave's 32 x D tile in LDS, store full rows
+  __syncthreads();
+  char* stg = smem + wave * TILE_B;
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    float l = l_run[rb];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    const int r = row_base + 16 * rb + li;
+    if (a.lse && lg == 0 && r < Lq)
+      a.lse[(long long)h * a.lse_stride_h + q0 + r] = l > 0.f ? (m_run[rb] + __log2f(l)) * 0.6931471805599453f : -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NDV; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = acc[rb][j][i] * inv;
+        uint16_t bits;
+        if constexpr (IS_BF16) bits = __builtin_bit_cast(uint16_t, (__bf16)v);
+        else bits = __builtin_bit_cast(uint16_t, (_Float16)v);
+        *(uint16_t*)(stg + (16 * rb + li) * ROW_B + (NDV * (4 * lg + i) + j) * 2) = bits;
+      }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  for (int idx = lane; idx < 32 * CPR; idx += 64) {
+    const int row = idx / CPR, ch = idx - row * CPR;
+    const int r = row_base + row;
+    if (r < Lq)
+      *(uint4*)(a.o + (long long)(q0 + r) * a.o_stride_t + (long long)h * a.o_stride_h + ch * 8) =
+          *(const uint4*)(stg + row * ROW_B + ch * 16);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// KV all-gather for sequence-parallel attention: every rank pushes the K and V rows of its shard
+// to the global-order position in every rank's gathered buffer (own copy included), then raises
+// flag[rank] = epoch on each peer once all of its workgroups are done.
+struct KvPushArgs {
+  SymmCtx ctx;
+  const uint16_t *k_shard, *v_shard;   // [total_shard, row_elems]
+  uint16_t *k_full, *v_full;           // symmetric [total_full, row_elems]
+  int* flags;                          // symmetric [world]
+  int* done;                           // local counter, zero at launch
+  const int *cu_shard, *cu_full;       // [batch + 1]
+  int batch, zigzag, epoch;
+  long long row_bytes;
+  int rows_per_wg;
+};
+
+__global__ __launch_bounds__(256) void sp_kv_push_kernel(KvPushArgs p) {
+  const int w = p.ctx.num_ranks, rank = p.ctx.rank;
+  const int total = p.cu_shard[p.batch];
+  const int r0 = blockIdx.x * p.rows_per_wg, r1 = min(r0 + p.rows_per_wg, total);
+  const int chunks = (int)(p.row_bytes / 16);
+  for (int i = 0; i < w; ++i) {
+    const int peer = (rank + (i + blockIdx.x) % w) % w;   // rotate so the links are loaded evenly
+    char* kd = (char*)symm_at(p.ctx, p.k_full, peer);
+    char* vd = (char*)symm_at(p.ctx, p.v_full, peer);
+    for (int idx = threadIdx.x; idx < (r1 - r0) * chunks; idx += 256) {
+      const int row = r0 + idx / chunks, ch = idx % chunks;
+      int b = 0;
+      while (b + 1 < p.batch && row >= p.cu_shard[b + 1]) ++b;
+      const int i_loc = row - p.cu_shard[b], Ls = p.cu_shard[b + 1] - p.cu_shard[b];
+      int g;
+      if (p.zigzag) {
+        const int half = Ls >> 1;
+        g = i_loc < half ? rank * half + i_loc : (2 * w - 1 - rank) * half + (i_loc - half);
+      } else {
+        g = rank * Ls + i_loc;
+      }
+      const long long dst = ((long long)p.cu_full[b] + g) * p.row_bytes + ch * 16;
+      const long long src = (long long)row * p.row_bytes + ch * 16;
+      *(uint4*)(kd + dst) = *(const uint4*)((const char*)p.k_shard + src);
+      *(uint4*)(vd + dst) = *(const uint4*)((const char*)p.v_shard + src);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int prev = atom_add_acqrel_agent(p.done, 1);
+    if (prev == (int)gridDim.x - 1) {
+      *p.done = 0;
+      for (int i = 0; i < w; ++i) store_release_system(symm_at(p.ctx, p.flags, (rank + i) % w) + rank, p.epoch);
+    }
+  }
+}
+
+template <bool IS_BF16, int D>
+hipError_t launch_attn(const AttnArgs& a, int max_seqlen_q, int batch, hipStream_t st) {
+  constexpr int lds = 2 * 2 * 32 * (D * 2 + 16);
+  static bool attr_done = false;
+  if (!attr_done) {
+    const hipError_t e = hipFuncSetAttribute((const void*)flash_attn_fwd_kernel<IS_BF16, D>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((flash_attn_fwd_kernel<IS_BF16, D>), dim3((max_seqlen_q + 127) / 128, a.q_heads, batch), dim3(256),
+                     lds, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+// q [total_q, q_heads, D], k/v [total_k, kv_heads, D] (strides in elements, last dim contiguous),
+// o like q.  dtype 0 = bf16, 1 = fp16.  flags/err may be null.
+TDIST_API int tdist_flash_attn_varlen_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                                          const int* cu_q, const int* cu_k, int batch, int max_seqlen_q, int q_heads,
+                                          int kv_heads, int head_dim, long long q_stride_t, long long q_stride_h,
+                                          long long k_stride_t, long long k_stride_h, long long v_stride_t,
+                                          long long v_stride_h, long long o_stride_t, long long o_stride_h,
+                                          long long lse_stride_h, float sm_scale, int causal, int pos_mode, int rank,
+                                          int world, const int* flags, int epoch, int* err, int dtype, void* stream) {
+  TDIST_REQUIRE(batch > 0 && max_seqlen_q > 0 && q_heads > 0 && kv_heads > 0 && q_heads % kv_heads == 0, "bad shape");
+  TDIST_REQUIRE(head_dim == 64 || head_dim == 128, "head_dim must be 64 or 128");
+  TDIST_REQUIRE((q_stride_t | q_stride_h | k_stride_t | k_stride_h | v_stride_t | v_stride_h | o_stride_t | o_stride_h) % 8 == 0,
+                "strides must keep 16-byte alignment");
+  TDIST_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0, "q/k/v/o must be 16-byte aligned");
+  TDIST_REQUIRE(pos_mode >= 0 && pos_mode <= 2 && world >= 1 && world <= 32 && rank >= 0 && rank < world, "bad position map");
+  AttnArgs a;
+  a.q = (const uint16_t*)q, a.k = (const uint16_t*)k, a.v = (const uint16_t*)v, a.o = (uint16_t*)o, a.lse = lse;
+  a.cu_q = cu_q, a.cu_k = cu_k;
+  a.q_stride_t = q_stride_t, a.q_stride_h = q_stride_h, a.k_stride_t = k_stride_t, a.k_stride_h = k_stride_h;
+  a.v_stride_t = v_stride_t, a.v_stride_h = v_stride_h, a.o_stride_t = o_stride_t, a.o_stride_h = o_stride_h;
+  a.lse_stride_h = lse_stride_h;
+  a.q_heads = q_heads, a.kv_heads = kv_heads, a.causal = causal, a.pos_mode = pos_mode, a.rank = rank, a.world = world;
+  a.sm_scale = sm_scale, a.flags = flags, a.epoch = epoch, a.err = err;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e;
+  if (head_dim == 64)
+    e = dtype == 0 ? launch_attn<true, 64>(a, max_seqlen_q, batch, st) : launch_attn<false, 64>(a, max_seqlen_q, batch, st);
+  else
+    e = dtype == 0 ? launch_attn<true, 128>(a, max_seqlen_q, batch, st) : launch_attn<false, 128>(a, max_seqlen_q, batch, st);
+  TDIST_HIP_TRY(e);
+  return 0;
+}
+
+TDIST_API int tdist_sp_kv_push(const tdist::SymmCtx* ctx, const void* k_shard, const void* v_shard, void* k_full,
+                               void* v_full, int* flags, int* done, const int* cu_shard, const int* cu_full, int batch,
+                               int total_shard_rows, long long row_bytes, int zigzag, int epoch, void* stream) {
+  TDIST_REQUIRE(batch > 0 && total_shard_rows > 0 && row_bytes > 0 && row_bytes % 16 == 0, "bad KV push shape");
+  KvPushArgs p;
+  p.ctx = *ctx;
+  p.k_shard = (const uint16_t*)k_shard, p.v_shard = (const uint16_t*)v_shard;
+  p.k_full = (uint16_t*)k_full, p.v_full = (uint16_t*)v_full;
+  p.flags = flags, p.done = done, p.cu_shard = cu_shard, p.cu_full = cu_full;
+  p.batch = batch, p.zigzag = zigzag, p.epoch = epoch, p.row_bytes = row_bytes;
+  const int target_wgs = 128;
+  p.rows_per_wg = (total_shard_rows + target_wgs - 1) / target_wgs;
+  if (p.rows_per_wg < 4) p.rows_per_wg = 4;
+  const int grid = (total_shard_rows + p.rows_per_wg - 1) / p.rows_per_wg;
+  hipLaunchKernelGGL(sp_kv_push_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  TDIST_HIP_TRY(hipGetLastError());
+  return 0;
+}

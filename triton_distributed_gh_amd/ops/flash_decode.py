@@ -1,0 +1,200 @@
+"""GQA decode attention over a paged KV cache (split-KV + LSE merge) and its distributed merges.
+
+Host API of the reference's kernels/nvidia/flash_decode.py: ``gqa_fwd_batch_decode`` (:763-844),
+``gqa_fwd_batch_decode_intra_rank`` (:847-928, also returns the LSE column so ranks can be merged),
+``gqa_fwd_batch_decode_persistent`` (:931-976, one launch) and the inter-rank combine (:452-532).
+All of them run csrc/ops/flash_decode.hip on the GPU; CPU tensors take the PyTorch reference path.
+
+Differences by design: partial results are always fp32 (the reference keeps them in q's dtype),
+the "persistent" variant merges in the last workgroup to finish instead of a grid barrier, and the
+default split count is sized for 256 CUs rather than fixed at 32.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Optional
+
+import torch
+
+from .. import _lib
+
+_TICKETS = {}
+
+
+def _tickets(device, n: int) -> torch.Tensor:
+    t = _TICKETS.get(device)
+    if t is None or t.numel() < n:
+        t = torch.zeros(max(n, 4096), dtype=torch.int32, device=device)
+        _TICKETS[device] = t
+    return t
+
+
+def auto_kv_splits(batch: int, q_heads: int, kv_heads: int, max_kv_len: int, num_cus: int = 256) -> int:
+    """Enough workgroups for ~2 waves of the chip, but at least 256 tokens of KV per split."""
+    group = q_heads // kv_heads
+    base = batch * kv_heads * ((group + 15) // 16)
+    want = max(1, (2 * num_cus + base - 1) // base)
+    cap = max(1, max_kv_len // 256)
+    return int(max(1, min(want, cap, 64)))
+
+
+def _dt(q: torch.Tensor) -> int:
+    if q.dtype == torch.bfloat16:
+        return 0
+    if q.dtype == torch.float16:
+        return 1
+    raise TypeError(f"flash decode supports bf16 / fp16, got {q.dtype}")
+
+
+def decode_reference(q, k_cache, v_cache, kv_lens, block_table, scale, soft_cap=0.0, return_lse=False):
+    """Plain PyTorch fp32 decode attention over the paged cache (test oracle and CPU path)."""
+    batch, q_heads, D = q.shape
+    _, page, kv_heads, _ = k_cache.shape
+    g = q_heads // kv_heads
+    out = torch.zeros(batch, q_heads, v_cache.shape[-1], dtype=torch.float32, device=q.device)
+    lse = torch.full((batch, q_heads), float("-inf"), dtype=torch.float32, device=q.device)
+    for b in range(batch):
+        L = int(kv_lens[b])
+        if L == 0:
+            continue
+        npg = (L + page - 1) // page
+        pages = block_table[b, :npg].long()
+        k = k_cache[pages].reshape(-1, kv_heads, D)[:L].float()
+        v = v_cache[pages].reshape(-1, kv_heads, v_cache.shape[-1])[:L].float()
+        qh = q[b].float().view(kv_heads, g, D)
+        s = torch.einsum("hgd,lhd->hgl", qh, k) * scale
+        if soft_cap > 0:
+            s = soft_cap * torch.tanh(s / soft_cap)
+        lse[b] = torch.logsumexp(s, -1).reshape(-1)
+        out[b] = torch.einsum("hgl,lhd->hgd", torch.softmax(s, -1), v).reshape(q_heads, -1)
+    return (out, lse) if return_lse else out
+
+
+def _launch(q, k_cache, v_cache, kv_lens, block_table, scale, soft_cap, splits, fused, partial, out):
+    batch, q_heads, D = q.shape
+    _, page, kv_heads, _ = k_cache.shape
+    assert v_cache.shape[-1] == D, "the native kernel needs equal K and V head dims"
+    assert q.stride(2) == 1 and k_cache.stride(3) == 1 and v_cache.stride(3) == 1
+    assert k_cache.stride(0) == page * k_cache.stride(1) and v_cache.stride(0) == page * v_cache.stride(1), \
+        "pages must be contiguous runs of slots"
+    assert kv_lens.dtype == torch.int32 and block_table.dtype == torch.int32 and block_table.stride(1) == 1
+    assert kv_lens.numel() >= batch and block_table.shape[0] >= batch
+    assert partial.dtype == torch.float32 and partial.is_contiguous() and partial.numel() >= batch * q_heads * splits * (D + 1)
+    group = q_heads // kv_heads
+    tick = _tickets(q.device, batch * kv_heads * ((group + 15) // 16)) if fused else None
+    _lib.check(
+        _lib.hip().tdist_flash_decode_split(
+            _lib.ptr(q), _lib.ptr(k_cache), _lib.ptr(v_cache), _lib.ptr(block_table), _lib.ptr(kv_lens),
+            _lib.ptr(partial), _lib.ptr(out), _lib.ptr(tick), batch, q_heads, kv_heads, D, splits, page,
+            block_table.stride(0), ctypes.c_longlong(q.stride(0)), ctypes.c_longlong(q.stride(1)),
+            ctypes.c_longlong(k_cache.stride(1)), ctypes.c_longlong(k_cache.stride(2)),
+            ctypes.c_longlong(v_cache.stride(1)), ctypes.c_longlong(v_cache.stride(2)),
+            ctypes.c_longlong(out.stride(0) if out is not None else 0),
+            ctypes.c_longlong(out.stride(1) if out is not None else 0), ctypes.c_float(scale),
+            ctypes.c_float(soft_cap), fused, _dt(q), _lib.stream_handle()), "tdist_flash_decode_split")
+
+
+def _combine(partial, strides, n, batch, heads, D, lens, out, out_mode, dtype_code):
+    _lib.check(
+        _lib.hip().tdist_flash_decode_combine(
+            _lib.ptr(partial), ctypes.c_longlong(strides[0]), ctypes.c_longlong(strides[1]),
+            ctypes.c_longlong(strides[2]), n, batch, heads, D, _lib.ptr(lens), lens.stride(0) if lens is not None else 0,
+            _lib.ptr(out), ctypes.c_longlong(out.stride(0)), ctypes.c_longlong(out.stride(1)), out_mode, dtype_code,
+            _lib.stream_handle()), "tdist_flash_decode_combine")
+
+
+def _splits(q, k_cache, block_table, kv_split):
+    if kv_split is not None and kv_split > 0:
+        return int(kv_split)
+    batch, q_heads, _ = q.shape
+    return auto_kv_splits(batch, q_heads, k_cache.shape[2], block_table.shape[1] * k_cache.shape[1])
+
+
+def _partial(q, splits, output_split):
+    batch, q_heads, D = q.shape
+    if output_split is not None and output_split.dtype == torch.float32 and output_split.is_contiguous() \
+            and output_split.numel() >= batch * q_heads * splits * (D + 1):
+        return output_split
+    return torch.empty((batch, q_heads, splits, D + 1), dtype=torch.float32, device=q.device)
+
+
+def gqa_fwd_batch_decode(q, k_cache, v_cache, workspace, q_lens, kv_lens, block_table, scale, soft_cap=0.0,
+                         output_split=None, output_combine=None, kv_split=-1):
+    """q [batch, q_heads, D]; k/v_cache [pages, page_size, kv_heads, D]; returns [batch, q_heads, D]
+    in q's dtype.  Two launches: split-KV then merge (reference :763-844)."""
+    batch, q_heads, D = q.shape
+    if not q.is_cuda:
+        return decode_reference(q, k_cache, v_cache, kv_lens, block_table, scale, soft_cap).to(q.dtype)
+    splits = _splits(q, k_cache, block_table, kv_split)
+    part = _partial(q, splits, output_split)
+    out = output_combine if (output_combine is not None and output_combine.dtype == q.dtype) else \
+        torch.empty((batch, q_heads, D), dtype=q.dtype, device=q.device)
+    _launch(q, k_cache, v_cache, kv_lens, block_table, scale, soft_cap, splits, 0, part, None)
+    _combine(part, (D + 1, q_heads * splits * (D + 1), splits * (D + 1)), splits, batch, q_heads, D, None, out, 1, _dt(q))
+    return out
+
+
+def gqa_fwd_batch_decode_intra_rank(q, k_cache, v_cache, workspace, q_lens, kv_lens, block_table, scale, soft_cap=0.0,
+                                    output_split=None, output_combine=None, kv_split=-1):
+    """Like ``gqa_fwd_batch_decode`` but returns fp32 [batch, q_heads, D + 1] with the natural-log
+    LSE in the last column, the form the inter-rank merge consumes (reference :847-928)."""
+    batch, q_heads, D = q.shape
+    if not q.is_cuda:
+        o, lse = decode_reference(q, k_cache, v_cache, kv_lens, block_table, scale, soft_cap, return_lse=True)
+        return torch.cat([o, lse.unsqueeze(-1)], -1)
+    splits = _splits(q, k_cache, block_table, kv_split)
+    part = _partial(q, splits, output_split)
+    out = output_combine if (output_combine is not None and output_combine.dtype == torch.float32) else \
+        torch.empty((batch, q_heads, D + 1), dtype=torch.float32, device=q.device)
+    _launch(q, k_cache, v_cache, kv_lens, block_table, scale, soft_cap, splits, 2, part, out)
+    return out
+
+
+def gqa_fwd_batch_decode_persistent(q, k_cache, v_cache, workspace, q_lens, kv_lens, block_table, scale, soft_cap=0.0,
+                                    output_split=None, output_combine=None, kv_split=-1):
+    """Single-launch decode: the last workgroup of every (batch, head block) merges the splits
+    (reference :931-976 uses a persistent grid with a grid barrier)."""
+    batch, q_heads, D = q.shape
+    if not q.is_cuda:
+        return decode_reference(q, k_cache, v_cache, kv_lens, block_table, scale, soft_cap).to(q.dtype)
+    splits = _splits(q, k_cache, block_table, kv_split)
+    part = _partial(q, splits, output_split)
+    out = output_combine if (output_combine is not None and output_combine.dtype == q.dtype) else \
+        torch.empty((batch, q_heads, D), dtype=q.dtype, device=q.device)
+    _launch(q, k_cache, v_cache, kv_lens, block_table, scale, soft_cap, splits, 1, part, out)
+    return out
+
+
+# the reference exposes AOT-compiled twins of the two entry points; here every kernel is AOT
+gqa_fwd_batch_decode_aot = gqa_fwd_batch_decode
+gqa_fwd_batch_decode_intra_rank_aot = gqa_fwd_batch_decode_intra_rank
+
+
+def gqa_fwd_batch_decode_inter_rank_combine(partials: torch.Tensor, kv_lens_per_rank: Optional[torch.Tensor],
+                                            out: Optional[torch.Tensor] = None, dtype=torch.bfloat16):
+    """partials fp32 [num_ranks, batch, q_heads, D + 1] (LSE last) -> [batch, q_heads, D] in
+    ``dtype``; ranks whose ``kv_lens_per_rank [num_ranks, batch]`` entry is 0 are skipped
+    (reference :452-532)."""
+    R, batch, heads, D1 = partials.shape
+    D = D1 - 1
+    if out is None:
+        out = torch.empty((batch, heads, D), dtype=dtype, device=partials.device)
+    if not partials.is_cuda:
+        lse = partials[..., D].clone()
+        if kv_lens_per_rank is not None:
+            lse = lse.masked_fill((kv_lens_per_rank <= 0).unsqueeze(-1), float("-inf"))
+        w = torch.softmax(lse, 0).nan_to_num(0.0)
+        out.copy_((w.unsqueeze(-1) * partials[..., :D]).sum(0).to(out.dtype))
+        return out
+    assert partials.dtype == torch.float32 and partials.is_contiguous()
+    lens = kv_lens_per_rank
+    if lens is not None:
+        assert lens.dtype == torch.int32 and lens.shape == (R, batch) and lens.is_contiguous()
+    _combine(partials, (batch * heads * D1, heads * D1, D1), R, batch, heads, D, lens, out, 1,
+             0 if out.dtype == torch.bfloat16 else 1)
+    return out
+
+
+def default_scale(head_dim: int) -> float:
+    return 1.0 / math.sqrt(head_dim)
