@@ -1,0 +1,312 @@
+"""TP layers, PP primitive and whole models on virtual ranks of one GPU vs PyTorch fp32 goldens.
+
+Scenarios follow the reference's layer / e2e tests: test/amd/test_tp_mlp.py, test_tp_attn.py,
+test_tp_e2e.py (--check against the torch forward), test/nvidia/test_tp_moe.py, test_pp.py
+(double-buffered send / recv), test_sp_decode_attn.py and test_e2e_inference.py (graph decode)."""
+import os
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+os.environ["RANDOM_PARAMS"] = "1"
+os.environ["TDIST_NO_HF_CONFIG"] = "1"
+
+from triton_distributed_gh_amd.layers import CommOp, SpGQAFlashDecodeAttention, TP_Attn, TP_MLP, TP_MoE  # noqa: E402
+from triton_distributed_gh_amd.layers.tp_attn import _set_cos_sin_cache  # noqa: E402
+from triton_distributed_gh_amd.models import AutoLLM, Engine, KV_Cache, ModelConfig  # noqa: E402
+from triton_distributed_gh_amd.ops.flash_decode import decode_reference  # noqa: E402
+from triton_distributed_gh_amd.utils.testing import VirtualCluster  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _lin(o, i, scale=0.05):
+    return SimpleNamespace(weight=((torch.rand(o, i, device="cuda") * 2 - 1) * scale).to(BF), bias=None)
+
+
+def _rel(a, b):
+    return (a.float() - b.float()).abs().max().item() / max(b.float().abs().max().item(), 1e-6)
+
+
+def _mlp_tree(H, I):
+    return SimpleNamespace(gate_proj=_lin(I, H), up_proj=_lin(I, H), down_proj=_lin(H, I),
+                           act_fn=torch.nn.functional.silu)
+
+
+def _mlp_ref(x, t):
+    xf = x.float()
+    h = torch.nn.functional.silu(xf @ t.gate_proj.weight.float().t()) * (xf @ t.up_proj.weight.float().t())
+    return h @ t.down_proj.weight.float().t()
+
+
+@pytest.mark.parametrize("w,M,H,I", [(2, 512, 1024, 2048), (4, 1024, 512, 4096), (8, 2048, 1024, 2048)])
+def test_tp_mlp_modes(w, M, H, I):
+    torch.manual_seed(1)
+    tree = _mlp_tree(H, I)
+    vc = VirtualCluster(w, heap_bytes=1 << 28)
+    try:
+        mlps = [TP_MLP(rank=r, world_size=w, env=vc.envs[r]) for r in range(w)]
+        for m in mlps:
+            m._init_parameters(tree)
+
+        def init(r, env):
+            mlps[r]._init_ctx(max_M=M, ag_intranode_stream=[vc.side_streams[r]])
+            mlps[r]._init_AR_ctx(max_M=M)
+            mlps[r]._init_gemm_ar_ctx(max_M=M)
+
+        vc.collective(init)
+        x = ((torch.rand(M, H, device="cuda") * 2 - 1)).to(BF)
+        ref = _mlp_ref(x, tree)
+        Mr = M // w
+        torch.cuda.synchronize()
+        for it in range(2):
+            outs = vc.run(lambda r, env: mlps[r].dist_triton_fwd(x[r * Mr:(r + 1) * Mr]))
+            assert _rel(torch.cat(outs), ref) < 3e-2
+            outs = vc.run(lambda r, env: mlps[r].dist_triton_AR_fwd(x))
+            for o in outs:
+                assert _rel(o, ref) < 3e-2
+            outs = vc.run(lambda r, env: mlps[r].dist_triton_gemm_ar_fwd(x))
+            for o in outs:
+                assert _rel(o, ref) < 3e-2
+        for m in mlps:
+            m.ag_ctx.check_error()
+            m.rs_ctx.check_error()
+    finally:
+        vc.close()
+
+
+def _attn_tree(H, Hq, Hkv, D):
+    norm = lambda: SimpleNamespace(weight=(1 + 0.1 * torch.randn(D, device="cuda")).to(BF), variance_epsilon=1e-6)  # noqa: E731
+    return SimpleNamespace(head_dim=D, q_proj=_lin(Hq * D, H), k_proj=_lin(Hkv * D, H), v_proj=_lin(Hkv * D, H),
+                           o_proj=_lin(H, Hq * D), q_norm=norm(), k_norm=norm())
+
+
+def _attn_ref(x, t, pos, cos_sin, past_k=None, past_v=None):
+    """fp32 reference of norm -> rope -> causal GQA attention -> o_proj.  x [B, S, H]."""
+    B, S, H = x.shape
+    D = t.head_dim
+    xf = x.float()
+    q = (xf @ t.q_proj.weight.float().t()).view(B, S, -1, D)
+    k = (xf @ t.k_proj.weight.float().t()).view(B, S, -1, D)
+    v = (xf @ t.v_proj.weight.float().t()).view(B, S, -1, D)
+
+    def rms(z, n):
+        return z * torch.rsqrt(z.pow(2).mean(-1, keepdim=True) + 1e-6) * n.weight.float()
+
+    def rope(z):
+        c = cos_sin[0][pos].unsqueeze(2)
+        s = cos_sin[1][pos].unsqueeze(2)
+        z1, z2 = z[..., : D // 2], z[..., D // 2:]
+        return torch.cat([z1 * c - z2 * s, z2 * c + z1 * s], -1)
+
+    q, k = rope(rms(q, t.q_norm)), rope(rms(k, t.k_norm))
+    if past_k is not None:
+        k, v = torch.cat([past_k, k], 1), torch.cat([past_v, v], 1)
+    Hq, Hkv = q.shape[2], k.shape[2]
+    kk = k.repeat_interleave(Hq // Hkv, dim=2)
+    vv = v.repeat_interleave(Hq // Hkv, dim=2)
+    s = torch.einsum("bqhd,bkhd->bhqk", q, kk) / D ** 0.5
+    Lk = k.shape[1]
+    mask = torch.arange(Lk, device=x.device)[None, :] <= (torch.arange(S, device=x.device)[:, None] + (Lk - S))
+    p = torch.softmax(s.masked_fill(~mask, float("-inf")), -1)
+    o = torch.einsum("bhqk,bkhd->bqhd", p, vv).reshape(B, S, -1)
+    return o @ t.o_proj.weight.float().t(), k, v
+
+
+@pytest.mark.parametrize("w,B,S,H,Hq,Hkv,D", [(2, 4, 64, 1024, 8, 4, 128), (4, 4, 32, 512, 16, 8, 64)])
+def test_tp_attn_prefill_and_decode(w, B, S, H, Hq, Hkv, D):
+    torch.manual_seed(2)
+    tree = _attn_tree(H, Hq, Hkv, D)
+    inv = 1.0 / (1e6 ** (torch.arange(0, D, 2, device="cuda").float() / D))
+    cos_sin = _set_cos_sin_cache(inv, 256)
+    vc = VirtualCluster(w, heap_bytes=1 << 28)
+    try:
+        attns = [TP_Attn(rank=r, world_size=w, env=vc.envs[r]) for r in range(w)]
+        for a in attns:
+            a._init_parameters(tree)
+
+        def init(r, env):
+            attns[r]._init_ctx(max_M=B * S, ag_intranode_stream=[vc.side_streams[r]])
+            attns[r]._init_AR_ctx(max_M=B * S)
+            attns[r]._init_gemm_ar_ctx(max_M=B * S)
+
+        vc.collective(init)
+        for mode in ("dist_triton_fwd", "dist_triton_AR_fwd", "dist_triton_gemm_ar_fwd"):
+            kvs = [KV_Cache(1, B, 256, Hkv, D, BF, w) for _ in range(w)]
+            x = (torch.rand(B, S, H, device="cuda") * 2 - 1).to(BF)
+            pos = torch.arange(S, device="cuda")[None].repeat(B, 1)
+            ref, pk, pv = _attn_ref(x, tree, pos, cos_sin)
+            sharded = mode == "dist_triton_fwd"
+            per = B // w
+            torch.cuda.synchronize()
+            outs = vc.run(lambda r, env: getattr(attns[r], mode)(x[r * per:(r + 1) * per] if sharded else x, pos, cos_sin,
+                                                                 kvs[r], 0))
+            got = torch.cat(outs) if sharded else outs[0]
+            assert _rel(got, ref) < 3e-2, mode
+            for kv in kvs:
+                kv.kv_offset.fill_(S)
+            # one decode step on top of the prefilled cache
+            x1 = (torch.rand(B, 1, H, device="cuda") * 2 - 1).to(BF)
+            pos1 = torch.full((B, 1), S, device="cuda", dtype=torch.long)
+            ref1, _, _ = _attn_ref(x1, tree, pos1, cos_sin, pk, pv)
+            torch.cuda.synchronize()
+            outs = vc.run(lambda r, env: getattr(attns[r], mode)(x1[r * per:(r + 1) * per] if sharded else x1, pos1,
+                                                                 cos_sin, kvs[r], 0))
+            got = torch.cat(outs) if sharded else outs[0]
+            assert _rel(got, ref1) < 3e-2, mode + " decode"
+    finally:
+        vc.close()
+
+
+@pytest.mark.parametrize("w,T,H,I,E,topk", [(2, 256, 512, 512, 8, 2), (4, 512, 1024, 1024, 16, 4)])
+def test_tp_moe_matches_expert_loop(w, T, H, I, E, topk):
+    torch.manual_seed(3)
+    tree = SimpleNamespace(num_experts=E, top_k=topk, norm_topk_prob=True, gate=_lin(E, H, 1.0),
+                           experts=[_mlp_tree(H, I) for _ in range(E)])
+    x = (torch.rand(T, H, device="cuda") * 2 - 1).to(BF)
+    logits = x @ tree.gate.weight.t()
+    wts, ids = torch.topk(torch.softmax(logits, 1, dtype=torch.float), topk, dim=-1)
+    wts = wts / wts.sum(-1, keepdim=True)
+    ref = torch.zeros(T, H, device="cuda")
+    for e in range(E):
+        tok, k = torch.where(ids == e)
+        if tok.numel():
+            ref.index_add_(0, tok, _mlp_ref(x[tok], tree.experts[e]) * wts[tok, k, None])
+    vc = VirtualCluster(w, heap_bytes=1 << 28)
+    try:
+        moes = [TP_MoE(rank=r, world_size=w, env=vc.envs[r]) for r in range(w)]
+        for m in moes:
+            m._init_parameters(tree)
+        vc.collective(lambda r, env: moes[r]._init_ctx(T, ag_streams=[vc.side_streams[r]]))
+        per = T // w
+        torch.cuda.synchronize()
+        for it in range(2):
+            outs = vc.run(lambda r, env: moes[r].dist_triton_fwd(x[r * per:(r + 1) * per]))
+            assert _rel(torch.cat(outs), ref) < 4e-2
+    finally:
+        vc.close()
+
+
+def test_pp_commop_double_buffered_send_recv():
+    """Rank 0 sends 6 activations to rank 1 through 2 alternating buffers (pull + signal handshake)."""
+    w, T, Hd = 2, 128, 512
+    vc = VirtualCluster(w, heap_bytes=1 << 26)
+    try:
+        ops = vc.collective(lambda r, env: CommOp(T, Hd, r, w, None, BF, num_buffers=2, env=env))
+        msgs = [torch.randn(T, Hd, device="cuda").to(BF) for _ in range(6)]
+        recv = [torch.empty(T, Hd, device="cuda", dtype=BF) for _ in range(6)]
+        torch.cuda.synchronize()
+
+        def fn(r, env):
+            for i, m in enumerate(msgs):
+                buf = i % 2
+                if r == 0:
+                    ops[0].wait_signal(0, buf, 0)             # slot free
+                    ops[0].get_buffer(buf).copy_(m)
+                    ops[0].set_signal(0, buf, 1)              # data ready
+                else:
+                    ops[1].wait_signal(0, buf, 1)
+                    ops[1].read(0, buf, recv[i], sm=4)
+                    ops[1].set_signal(0, buf, 0)              # hand the slot back
+
+        vc.run(fn)
+        for m, g in zip(msgs, recv):
+            assert torch.equal(m, g)
+    finally:
+        vc.close()
+
+
+@pytest.mark.parametrize("w,batch,Hq,Hkv,D,kv_len", [(2, 2, 16, 2, 128, 700), (4, 1, 32, 4, 128, 1500)])
+def test_sp_flash_decode_layer(w, batch, Hq, Hkv, D, kv_len):
+    torch.manual_seed(4)
+    page = 16
+    per_rank = (kv_len + w - 1) // w
+    pages = (per_rank + page - 1) // page
+    q = torch.randn(batch, Hq, D, device="cuda").to(BF)
+    k_all = torch.randn(batch, kv_len, Hkv, D, device="cuda").to(BF)
+    v_all = torch.randn(batch, kv_len, Hkv, D, device="cuda").to(BF)
+    scale = D ** -0.5
+    # reference over the whole sequence
+    kc = k_all.reshape(batch * kv_len, 1, Hkv, D)
+    vcache = v_all.reshape(batch * kv_len, 1, Hkv, D)
+    table = torch.arange(batch * kv_len, device="cuda", dtype=torch.int32).view(batch, kv_len)
+    ref = decode_reference(q, kc, vcache, torch.full((batch,), kv_len, device="cuda", dtype=torch.int32), table, scale)
+    vc = VirtualCluster(w, heap_bytes=1 << 26)
+    try:
+        layers = vc.collective(lambda r, env: SpGQAFlashDecodeAttention(r, 0, w, 1, Hq, Hkv, D, D, page_size=page,
+                                                                        scale=scale, max_allowed_batch=batch, env=env))
+        lens = torch.zeros(w, batch, dtype=torch.int32, device="cuda")
+        shards = []
+        for r in range(w):
+            lo, hi = r * per_rank, min(kv_len, (r + 1) * per_rank)
+            n = max(hi - lo, 0)
+            lens[r] = n
+            kr = torch.zeros(batch * pages, page, Hkv, D, device="cuda", dtype=BF)
+            vr = torch.zeros_like(kr)
+            for b in range(batch):
+                kr[b * pages:(b + 1) * pages].view(-1, Hkv, D)[:n] = k_all[b, lo:hi]
+                vr[b * pages:(b + 1) * pages].view(-1, Hkv, D)[:n] = v_all[b, lo:hi]
+            bt = torch.arange(batch * pages, device="cuda", dtype=torch.int32).view(batch, pages)
+            shards.append((kr, vr, bt))
+        torch.cuda.synchronize()
+        for it in range(3):
+            outs = vc.run(lambda r, env: layers[r](q, shards[r][0], shards[r][1], lens, shards[r][2]))
+            for o in outs:
+                assert _rel(o, ref) < 2e-2
+    finally:
+        vc.close()
+
+
+@pytest.mark.parametrize("name,mode,w", [("tdist/tiny-dense", "triton_dist", 2), ("tdist/tiny-dense", "triton_dist", 4),
+                                         ("tdist/tiny-dense", "triton_dist_AR", 2),
+                                         ("tdist/tiny-dense", "triton_dist_gemm_ar", 4),
+                                         ("tdist/tiny-moe", "triton_dist", 2)])
+def test_model_modes_match_single_rank(name, mode, w):
+    bsz, prompt, L = 8, 32, 256
+    torch.manual_seed(5)
+    ids = torch.randint(0, 1000, (bsz, prompt), device="cuda")
+    pos = torch.arange(prompt, device="cuda")[None].repeat(bsz, 1)
+    g = AutoLLM.from_pretrained(ModelConfig(model_name=name, max_length=L, dtype=BF, rank=0, world_size=1))
+    gkv = KV_Cache(g.num_layers, bsz, L, g.num_key_value_heads, g.head_dim, BF, 1)
+    gold = [g.inference(ids, pos, gkv)]
+    gkv.kv_offset.fill_(prompt)
+    tok = gold[0][:, -1].argmax(-1, keepdim=True)
+    gold.append(g.inference(tok, gkv.get_kv_len()[:, None].long(), gkv))
+    vc = VirtualCluster(w, heap_bytes=1 << 28)
+    try:
+        models = [AutoLLM.from_pretrained(ModelConfig(model_name=name, max_length=L, dtype=BF, rank=r, world_size=w),
+                                          env=vc.envs[r]) for r in range(w)]
+        kvs = [KV_Cache(g.num_layers, bsz, L, g.num_key_value_heads, g.head_dim, BF, w) for _ in range(w)]
+        for m in models:
+            m.set_fwd(mode)
+        init = {"triton_dist": lambda m: m.init_triton_dist_ctx(max_M=bsz * prompt),
+                "triton_dist_AR": lambda m: m.init_triton_dist_AR_ctx(max_M=bsz * prompt),
+                "triton_dist_gemm_ar": lambda m: m.init_triton_dist_gemm_ar_ctx(max_M=bsz * prompt)}[mode]
+        vc.collective(lambda r, env: init(models[r]))
+        sharded = mode == "triton_dist"
+        per = bsz // w
+        sh = (lambda x, r: x[r * per:(r + 1) * per]) if sharded else (lambda x, r: x)
+        torch.cuda.synchronize()
+        outs = vc.run(lambda r, env: models[r].inference(sh(ids, r), pos, kvs[r]))
+        got = torch.cat(outs) if sharded else outs[0]
+        assert _rel(got, gold[0]) < 5e-2
+        for kv in kvs:
+            kv.kv_offset.fill_(prompt)
+        outs = vc.run(lambda r, env: models[r].inference(sh(tok, r), kvs[r].get_kv_len()[:, None].long(), kvs[r]))
+        got = torch.cat(outs) if sharded else outs[0]
+        assert _rel(got, gold[1]) < 5e-2
+    finally:
+        vc.close()
+
+
+def test_engine_graph_decode_matches_eager():
+    cfg = ModelConfig(model_name="tdist/tiny-dense", max_length=128, dtype=BF, rank=0, world_size=1)
+    eng = Engine(cfg)
+    prompt = torch.randint(0, 1000, (4, 16))
+    eng.no_graph = True
+    eager = eng.serve(prompt, gen_len=8)
+    eng.no_graph = False
+    graphed = eng.serve(prompt, gen_len=8)
+    assert torch.equal(eager, graphed)

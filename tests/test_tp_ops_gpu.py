@@ -25,6 +25,7 @@ def _ctas(w):
     (4, 256, 2048, 256, 256, "kernel"),       # 64 rows per rank: tiles straddle ranks
     (8, 4096, 2048, 256, 256, "kernel"),
     (8, 2048, 1024, 128, 128, "kernel"),
+    (4, 256, 1536, 512, 256, "kernel"),       # 384 columns per rank: partial N tile
 ])
 def test_ag_gemm_virtual_ranks(w, M, N, K, chunk, producer):
     vc = VirtualCluster(w, heap_bytes=1 << 27)
@@ -59,6 +60,7 @@ def test_ag_gemm_virtual_ranks(w, M, N, K, chunk, producer):
     (4, 4096, 2048, 512, 512),
     (8, 4096, 1024, 1024, 256),
     (8, 512, 768, 2048, 256),       # 64 rows per rank
+    (4, 256, 512, 512, 256),        # K_local = 128: two K-steps only
 ])
 def test_gemm_rs_virtual_ranks(w, M, N, K, chunk):
     vc = VirtualCluster(w, heap_bytes=1 << 27)

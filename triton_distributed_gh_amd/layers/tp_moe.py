@@ -1,0 +1,167 @@
+"""Tensor-parallel Mixture-of-Experts block (every expert's FFN is sharded over the TP ranks).
+
+Reference: layers/nvidia/tp_moe.py:42-279 (the reference has no AMD implementation and its Qwen3
+MoE model raises NotImplemented on AMD, models/qwen_moe.py:164-165).
+
+Pipeline of ``dist_triton_fwd``: router softmax / top-k on the local tokens -> all-gather of the
+(ids, weights) pairs with the low-latency symmetric-memory all-gather (the reference uses two NCCL
+all_gathers here) -> AG + grouped GEMM (gate_up) -> fused SiLU*up -> grouped GEMM with routing
+weights + top-k reduce + reduce-scatter.
+
+Weights are kept K-contiguous ([E, N, K], the layout the MFMA grouped GEMM reads); the reference
+stores the transposes.  The per-rank intermediate size is zero-padded to a multiple of 64 (>= 128)
+so the down projection's K meets the GEMM tile constraints (e.g. 768 / 8 = 96 -> 128).
+"""
+from __future__ import annotations
+
+import torch
+
+from ..ops import elementwise
+from ..ops.allgather import create_fast_allgather_context, fast_allgather
+from ..ops.moe import ag_group_gemm, create_ag_group_gemm_context, create_moe_rs_context, run_moe_reduce_rs
+from ..utils.distributed import get_env
+from .tp_mlp import shard_local
+
+
+def _pad_to(n: int) -> int:
+    return max(128, (n + 63) // 64 * 64)
+
+
+class TP_MoE:
+
+    def __init__(self, rank=0, world_size=8, group=None, autotune=False, env=None):
+        self.rank = rank
+        self.world_size = world_size
+        self.group = group
+        self.env = env
+        self.act_fn = None
+        self.gate_up_proj = None     # [E, 2 * Ip, H]   (Ip = padded I / w)
+        self.down_proj = None        # [E, H, Ip]
+        self.ag_ctx = self.rs_ctx = None
+        self.top_k = self.num_experts = self.gate = None
+        self.norm_topk_prob = True
+        self.ag_group_gemm = ag_group_gemm
+        self.run_moe_reduce_rs = run_moe_reduce_rs
+
+    def _env(self):
+        return self.env or get_env()
+
+    def _device(self):
+        try:
+            return self._env().device
+        except RuntimeError:
+            return torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+    def _init_parameters(self, mlp, verbose=False):
+        """``mlp`` has ``gate.weight [E, H]``, ``experts[e].{gate,up,down}_proj.weight``, ``num_experts``
+        and ``top_k``."""
+        dev = self._device()
+        w = self.world_size
+        self.num_experts = int(mlp.num_experts)
+        self.top_k = int(mlp.top_k)
+        self.norm_topk_prob = bool(getattr(mlp, "norm_topk_prob", True))
+        self.gate = mlp.gate.weight.detach().to(dev)
+        H = self.gate.shape[1]
+        self.hidden_size = H
+        I = mlp.experts[0].gate_proj.weight.shape[0]
+        dtype = mlp.experts[0].gate_proj.weight.dtype
+        Il = I // w
+        Ip = _pad_to(Il)
+        self.inter_local, self.inter_padded = Il, Ip
+        self.gate_up_proj = torch.zeros(self.num_experts, 2 * Ip, H, dtype=dtype, device=dev)
+        self.down_proj = torch.zeros(self.num_experts, H, Ip, dtype=dtype, device=dev)
+        for e in range(self.num_experts):
+            ex = mlp.experts[e]
+            self.gate_up_proj[e, :Il] = shard_local(ex.gate_proj.weight.detach(), w, 0, self.rank).to(dev)
+            self.gate_up_proj[e, Ip:Ip + Il] = shard_local(ex.up_proj.weight.detach(), w, 0, self.rank).to(dev)
+            self.down_proj[e, :, :Il] = shard_local(ex.down_proj.weight.detach(), w, 1, self.rank).to(dev)
+        self.act_fn = getattr(mlp.experts[0], "act_fn", torch.nn.functional.silu)
+        self.dtype = dtype
+        if verbose:
+            print(f"[RANK {self.rank}] MoE gate_up {tuple(self.gate_up_proj.shape)} down {tuple(self.down_proj.shape)}")
+
+    def _init_ctx(self, M, ag_streams=None):
+        """``M`` = max tokens over ALL ranks per forward."""
+        env = self._env()
+        w = self.world_size
+        self.max_M = M
+        self.ag_ctx = create_ag_group_gemm_context(M, self.gate_up_proj.shape[1], self.hidden_size, self.num_experts,
+                                                   self.top_k, self.dtype, self.rank, w, w, ag_streams=ag_streams,
+                                                   env=self.env)
+        self.rs_ctx = create_moe_rs_context(rank=self.rank, world_size=w, local_world_size=w, max_token_num=M,
+                                            hidden_dim=self.hidden_size, num_experts=self.num_experts, topk=self.top_k,
+                                            input_dtype=self.dtype, env=self.env)
+        # router metadata all-gather: per token topk int32 ids + topk fp32 weights
+        self.meta_bytes = (M // w) * self.top_k * 8
+        self.meta_ctx = create_fast_allgather_context(self.rank, max_buffer_size=self.meta_bytes, env=self.env)
+        self.meta_buf = env.heap.create_tensor([2, w, self.meta_bytes // 4], torch.int32)
+        self.meta_state = {"calls": 0}     # shared by every layer that shares this context
+
+    def finalize(self):
+        self.ag_ctx = self.rs_ctx = None
+
+    def _route(self, x2: torch.Tensor):
+        logits = torch.nn.functional.linear(x2, self.gate)
+        probs = torch.nn.functional.softmax(logits, dim=1, dtype=torch.float)
+        wts, ids = torch.topk(probs, self.top_k, dim=-1)
+        if self.norm_topk_prob:
+            wts = wts / wts.sum(dim=-1, keepdim=True)
+        return wts, ids
+
+    def _act(self, gate_up):
+        return elementwise.silu_mul(gate_up)
+
+    @torch.inference_mode()
+    def torch_fwd(self, x):
+        """Golden: loop over experts, x replicated [bsz, seq, H]; output all-reduced."""
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1])
+        wts, ids = self._route(x2)
+        wts = wts.to(x.dtype)
+        Ip = self.inter_padded
+        out = torch.zeros_like(x2)
+        for e in range(self.num_experts):
+            tok, k = torch.where(ids == e)
+            if tok.numel() == 0:
+                continue
+            h = x2[tok] @ self.gate_up_proj[e].t()
+            h = torch.nn.functional.silu(h[:, :Ip]) * h[:, Ip:]
+            h = (h @ self.down_proj[e].t()) * wts[tok, k, None]
+            out.index_add_(0, tok, h)
+        if self.world_size > 1 and torch.distributed.is_initialized():
+            torch.distributed.all_reduce(out, torch.distributed.ReduceOp.SUM, group=self.group)
+        return out.view(shape)
+
+    torch_fwd_no_loop = torch_fwd
+
+    def _gather_meta(self, wts: torch.Tensor, ids: torch.Tensor):
+        w = self.world_size
+        n, k = ids.shape
+        if w == 1:
+            return wts.contiguous(), ids.to(torch.int32).contiguous()
+        assert 2 * n * k * 4 <= self.meta_bytes, "more tokens than the context was sized for"
+        full = self.meta_buf[self.meta_state["calls"] & 1]   # [w, words]; slots are only written locally
+        self.meta_state["calls"] += 1
+        mine = full[self.rank]
+        mine[: n * k].copy_(ids.reshape(-1).to(torch.int32))
+        mine[n * k: 2 * n * k].copy_(wts.reshape(-1).float().contiguous().view(torch.int32))
+        fast_allgather(full, self.meta_ctx, mode="push_2d_ll")
+        ids_full = full[:, : n * k].reshape(w * n, k)
+        wts_full = full[:, n * k: 2 * n * k].view(torch.float32).reshape(w * n, k)
+        return wts_full, ids_full
+
+    @torch.inference_mode()
+    def dist_triton_fwd(self, x: torch.Tensor):
+        """x token-sharded [bsz / w, seq, H] (or [tokens / w, H]) -> same shape."""
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1]).contiguous()
+        wts, ids = self._route(x2)
+        full_w, full_ids = self._gather_meta(wts, ids)
+        h = self.ag_group_gemm(x2, self.gate_up_proj, ctx=self.ag_ctx, full_topk_ids=full_ids.contiguous())
+        h = self._act(h)
+        out = self.run_moe_reduce_rs(h, self.down_proj, full_ids.contiguous(), full_w.contiguous(), ctx=self.rs_ctx,
+                                     n_chunks=4)
+        return out.view(shape)
+
+    def fwd(self, x: torch.Tensor):
+        raise NotImplementedError("Please use torch_fwd or dist_triton_fwd instead.")

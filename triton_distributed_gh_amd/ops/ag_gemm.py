@@ -29,7 +29,7 @@ from typing import Any, List, Optional
 import torch
 
 from .. import _lib
-from ..utils.distributed import get_env
+from ..utils.distributed import default_num_ctas, get_env
 from .gemm import _DT, gemm_nt
 
 EPOCH_MOD = 4093
@@ -83,6 +83,7 @@ def create_ag_gemm_intra_node_context(max_M, N, K, input_dtype, output_dtype, ra
     """Collective.  ``N`` is the per-rank N of the weight shard; ``max_M`` the gathered row count."""
     env = env or get_env()
     assert max_M % num_ranks == 0, "max_M must be divisible by the number of ranks"
+    num_ctas = default_num_ctas(env, num_ranks, num_ctas)
     heap = env.heap
     min_chunk = 16
     max_chunks = num_ranks * max(1, (max_M // num_ranks + min_chunk - 1) // min_chunk)
@@ -97,6 +98,8 @@ def create_ag_gemm_intra_node_context(max_M, N, K, input_dtype, output_dtype, ra
     if env.backend == "hip":
         epoch_table = torch.arange(EPOCH_MOD + 2, dtype=torch.int32, device=env.device)
         scratch = torch.zeros(8 + max_chunks, dtype=torch.int32, device=env.device)
+        if ag_streams is None and num_ranks > 1 and getattr(env, "side_stream", None) is not None:
+            ag_streams = [env.side_stream]
         if ag_streams is None and num_ranks > 1:
             # one hardware queue per peer link for the copy engines; the push kernel needs one
             n_streams = num_ranks - 1 if producer == "copy_engine" else 1
@@ -213,8 +216,9 @@ def ag_gemm_intra_node_op(a, b, c, ctx: AllGatherGEMMTensorParallelContext):
     return c
 
 
-def _ag_gemm_host(a, b, c, ctx, parity, epoch, rpc):
-    """CPU emulation of the same protocol over the shared-memory heap."""
+def _all_gather_host(a, ctx, parity, epoch, rpc):
+    """CPU emulation of the push + flag protocol over the shared-memory heap; returns the per-source
+    row blocks of the gathered operand (own rows straight from ``a``)."""
     lib = _lib.host()
     w, rank = ctx.num_ranks, ctx.rank
     M_per_rank, K = a.shape
@@ -226,17 +230,23 @@ def _ag_gemm_host(a, b, c, ctx, parity, epoch, rpc):
             ctx.workspaces[parity][peer][r0:r0 + rpc].copy_(a[ch * rpc:(ch + 1) * rpc])
             lib.tdh_notify32(ctypes.c_void_p(ctx.flags[parity][peer].data_ptr() + 4 * (rank * cpr + ch)), epoch, 1)
     ws = ctx.workspaces[parity][rank]
+    blocks = []
     for s in range(w):
-        rows = slice(s * M_per_rank, (s + 1) * M_per_rank)
         if s == rank:
-            src = a
-        else:
-            rc = lib.tdh_wait32(ctypes.c_void_p(ctx.flags[parity][rank].data_ptr() + 4 * s * cpr), cpr, 0, epoch,
-                                ctypes.c_int64(60000))
-            if rc != 0:
-                raise RuntimeError(f"ag_gemm(host): rank {rank} timed out waiting for rank {s}")
-            src = ws[rows]
-        c[rows] = (src.float() @ b.float().t()).to(c.dtype)
+            blocks.append(a)
+            continue
+        rc = lib.tdh_wait32(ctypes.c_void_p(ctx.flags[parity][rank].data_ptr() + 4 * s * cpr), cpr, 0, epoch,
+                            ctypes.c_int64(60000))
+        if rc != 0:
+            raise RuntimeError(f"ag_gemm(host): rank {rank} timed out waiting for rank {s}")
+        blocks.append(ws[s * M_per_rank:(s + 1) * M_per_rank])
+    return blocks
+
+
+def _ag_gemm_host(a, b, c, ctx, parity, epoch, rpc):
+    M_per_rank = a.shape[0]
+    for s, src in enumerate(_all_gather_host(a, ctx, parity, epoch, rpc)):
+        c[s * M_per_rank:(s + 1) * M_per_rank] = (src.float() @ b.float().t()).to(c.dtype)
     return c
 
 

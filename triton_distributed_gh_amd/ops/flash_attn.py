@@ -133,14 +133,14 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, cache_seqlens=N
         # one "page" per sequence: page size = max_len
         kc = k_cache.view(B, max_len, Hkv, D)
         vc = v_cache.view(B, max_len, Hkv, D)
-        o = flash_decode.gqa_fwd_batch_decode_persistent(q.view(B, Hq, D), kc, vc, None, None, total, table, scale)
+        o = flash_decode.gqa_fwd_batch_decode_persistent(q[:, 0], kc, vc, None, None, total, table, scale)
         return o.view(B, 1, Hq, D)
     if native and D in (64, 128):
         # the cache rows of sequence b live at b * max_len + [0, total_b): express as varlen over the cache
         cu_q = torch.arange(0, (B + 1) * Sq, Sq, dtype=torch.int32, device=q.device)
         if B == 1:
             cu_k = torch.stack([torch.zeros((), dtype=torch.int32, device=q.device), total[0]]).int()
-            o = flash_attn_varlen_fwd(q.view(Sq, Hq, D), k_cache.view(-1, Hkv, D), v_cache.view(-1, Hkv, D), cu_q, cu_k,
+            o = flash_attn_varlen_fwd(q[0], k_cache.view(-1, Hkv, D), v_cache.view(-1, Hkv, D), cu_q, cu_k,
                                       Sq, softmax_scale=scale, causal=causal)
             return o.view(1, Sq, Hq, D)
         outs = []

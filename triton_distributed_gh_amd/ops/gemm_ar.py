@@ -18,7 +18,7 @@ from typing import Any, List, Optional
 import torch
 
 from .. import _lib
-from ..utils.distributed import get_env
+from ..utils.distributed import default_num_ctas, get_env
 from .gemm import _DT, gemm_nt
 
 EPOCH_MOD = 1 << 30
@@ -56,6 +56,7 @@ def create_gemm_ar_context(ar_stream, rank, world_size, local_world_size, max_M,
                            MIN_BLOCK_SIZE_N=16, NUM_COMM_SMS=0, num_ctas=0, env=None) -> GemmARContext:
     env = env or get_env()
     assert local_world_size == world_size, "single-node only"
+    num_ctas = default_num_ctas(env, world_size, num_ctas)
     heap = env.heap
     tiles = ((max_M + _TILE - 1) // _TILE) * ((N + _TILE - 1) // _TILE)
     tpo = (tiles + world_size - 1) // world_size

@@ -21,7 +21,7 @@ from typing import Any, List, Optional
 import torch
 
 from .. import _lib
-from ..utils.distributed import get_env
+from ..utils.distributed import default_num_ctas, get_env
 from .gemm import _DT, gemm_nt
 
 EPOCH_MOD = 4093
@@ -67,6 +67,7 @@ def create_gemm_rs_intra_node_context(max_M, N, output_dtype, rank, num_ranks, t
         raise NotImplementedError("weights are [N, K_local] (K contiguous)")
     env = env or get_env()
     assert max_M % num_ranks == 0
+    num_ctas = default_num_ctas(env, num_ranks, num_ctas)
     heap = env.heap
     max_chunks = num_ranks * max(1, (max_M // num_ranks + 15) // 16)
     scatter, flags = [], []

@@ -21,7 +21,7 @@ from typing import Any, Optional
 import torch
 
 from .. import _lib
-from ..utils.distributed import get_env
+from ..utils.distributed import default_num_ctas, get_env
 from .ag_gemm import (AllGatherGEMMTensorParallelContext, EPOCH_MOD, _push_kernel, _rows_per_chunk,
                       create_ag_gemm_intra_node_context)
 from .gemm import _DT
@@ -153,6 +153,7 @@ def create_ag_group_gemm_context(max_ntokens, N_per_rank, K, num_experts, topk, 
                                  num_local_ranks=8, BLOCK_SIZE_M=256, BLOCK_SIZE_N=256, BLOCK_SIZE_K=64,
                                  GROUP_SIZE_M=8, stages=2, num_warps=8, num_ctas=0, ag_streams=None, env=None):
     env = env or get_env()
+    num_ctas = default_num_ctas(env, num_ranks, num_ctas)
     ag = create_ag_gemm_intra_node_context(max_ntokens, N_per_rank, K, dtype, dtype, rank, num_ranks,
                                            producer="kernel", num_ctas=num_ctas, ag_streams=ag_streams, env=env)
     return MoEAllGatherGroupGEMMTensorParallelContext(ag, num_experts, topk, N_per_rank, K, rank, num_ranks, env, num_ctas)
@@ -169,9 +170,9 @@ def ag_group_gemm(a: torch.Tensor, b: torch.Tensor, ctx: MoEAllGatherGroupGEMMTe
     ntokens, topk = full_topk_ids.shape
     assert ntokens == M_per_rank * w and K == ctx.K
     N = ctx.N_per_rank
-    if env.backend == "host" or not a.is_cuda:
-        raise NotImplementedError("ag_group_gemm runs on the GPU backend")
     b = _as_enk(b, N, K)
+    if env.backend == "host" or not a.is_cuda:
+        return _ag_group_gemm_host(a, b, ctx, full_topk_ids)
     a = a.contiguous()
     idx = moe_align_block_size(full_topk_ids, ctx.num_experts, w, rank, M_per_rank)
     out = torch.empty((ntokens * topk, N), dtype=a.dtype, device=a.device)
@@ -203,6 +204,58 @@ def ag_group_gemm(a: torch.Tensor, b: torch.Tensor, ctx: MoEAllGatherGroupGEMMTe
     return out
 
 
+def _grouped_matmul_cpu(rows: torch.Tensor, b_enk: torch.Tensor, flat_ids: torch.Tensor) -> torch.Tensor:
+    """rows [R, K] with expert id per row -> [R, N] fp32 (masked per-expert matmul)."""
+    out = torch.zeros(rows.shape[0], b_enk.shape[1], dtype=torch.float32, device=rows.device)
+    for e in range(b_enk.shape[0]):
+        m = flat_ids == e
+        if bool(m.any()):
+            out[m] = rows[m].float() @ b_enk[e].float().t()
+    return out
+
+
+def _ag_group_gemm_host(a, b_enk, ctx, full_topk_ids):
+    """Host backend: same all-gather protocol as AG+GEMM, grouped GEMM in PyTorch."""
+    from .ag_gemm import _all_gather_host
+
+    ag = ctx.ag
+    parity = ag.call_count & 1
+    epoch = ag.call_count % EPOCH_MOD + 1
+    ag.call_count += 1
+    if ctx.num_ranks > 1:
+        a_full = torch.cat(_all_gather_host(a.contiguous(), ag, parity, epoch, a.shape[0]))
+    else:
+        a_full = a
+    topk = full_topk_ids.shape[1]
+    rows = a_full.repeat_interleave(topk, dim=0)
+    return _grouped_matmul_cpu(rows, b_enk, full_topk_ids.reshape(-1).long()).to(a.dtype)
+
+
+def _moe_reduce_rs_host(x, b_enk, chosen_experts, expert_weight, ctx):
+    lib = _lib.host()
+    w, rank = ctx.world_size, ctx.rank
+    ntokens, topk = chosen_experts.shape
+    part = _grouped_matmul_cpu(x, b_enk, chosen_experts.reshape(-1).long()) * expert_weight.reshape(-1, 1).float()
+    part = part.view(ntokens, topk, -1).sum(1).to(x.dtype)
+    if w == 1:
+        return part
+    parity = ctx.call_count & 1
+    epoch = ctx.call_count % EPOCH_MOD + 1
+    ctx.call_count += 1
+    tpr = ntokens // w
+    N = part.shape[1]
+    for i in range(1, w + 1):
+        d = (rank + i) % w
+        seg = ctx.scatter[parity][d].view(-1)[: w * tpr * N].view(w, tpr, N)
+        seg[rank].copy_(part[d * tpr:(d + 1) * tpr])
+        lib.tdh_notify32(ctypes.c_void_p(ctx.flags[parity][d].data_ptr() + 4 * rank), epoch, 1)
+    rc = lib.tdh_wait32(ctypes.c_void_p(ctx.flags[parity][rank].data_ptr()), w, 0, epoch, ctypes.c_int64(60000))
+    if rc != 0:
+        raise RuntimeError(f"moe_reduce_rs(host): rank {rank} timed out waiting for partials")
+    seg = ctx.scatter[parity][rank].view(-1)[: w * tpr * N].view(w, tpr, N)
+    return seg.float().sum(0).to(x.dtype)
+
+
 # ---- grouped GEMM + topk reduce + ReduceScatter -----------------------------------------------
 @dataclasses.dataclass(repr=False)
 class MoEReduceRSContext:
@@ -228,6 +281,7 @@ class MoEReduceRSContext:
 def create_moe_rs_context(rank, world_size, local_world_size, max_token_num, hidden_dim, num_experts, topk,
                           input_dtype, n_chunks_max=8, num_ctas=0, env=None) -> MoEReduceRSContext:
     env = env or get_env()
+    num_ctas = default_num_ctas(env, world_size, num_ctas)
     heap = env.heap
     scatter, flags = [], []
     for _ in range(2):
@@ -253,9 +307,9 @@ def run_moe_reduce_rs(x: torch.Tensor, weights: torch.Tensor, chosen_experts: to
     K = x.shape[1]
     N = ctx.hidden_dim
     assert x.shape[0] == ntokens * topk and ntokens % w == 0 and ntokens <= ctx.max_token_num
-    if env.backend == "host" or not x.is_cuda:
-        raise NotImplementedError("run_moe_reduce_rs runs on the GPU backend")
     b = _as_enk(weights, N, K)
+    if env.backend == "host" or not x.is_cuda:
+        return _moe_reduce_rs_host(x, b, chosen_experts, expert_weight, ctx)
     x = x.contiguous()
     idx = moe_align_block_size(chosen_experts, ctx.num_experts, 1, 0, ntokens)
     gemm_out = torch.empty((ntokens * topk, N), dtype=x.dtype, device=x.device)

@@ -41,6 +41,7 @@ class DistEnv:
     heap: SymmetricHeap
     shared_gpu: bool = False         # several ranks on one device
     has_rccl: bool = False
+    side_stream: Optional[object] = None   # virtual ranks: the one side stream that owns a hardware queue
 
     @property
     def num_ranks(self) -> int:
@@ -127,6 +128,17 @@ def create_virtual_node(world_size: int, heap_bytes: int = 1 << 28, sig_bytes: i
     heaps = SymmetricHeap.create_virtual(world_size, backend, heap_bytes, sig_bytes)
     return [DistEnv(r, r, world_size, world_size, device, backend, None, None, heaps[r], True, False)
             for r in range(world_size)]
+
+
+def default_num_ctas(env: "DistEnv", num_ranks: int, requested: int = 0) -> int:
+    """Workgroup budget of a persistent kernel.  0 (one workgroup per CU) is right when a rank owns
+    its GPU; ranks that share one device must all stay co-resident (each spins on its peers), so
+    they split the CUs between them."""
+    if requested:
+        return requested
+    if env is not None and env.shared_gpu and env.backend == "hip" and num_ranks > 1:
+        return max(8, 200 // num_ranks)
+    return 0
 
 
 def finalize_distributed() -> None:

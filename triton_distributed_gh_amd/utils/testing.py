@@ -53,6 +53,8 @@ class VirtualCluster:
                 _pool_streams("side", r + 1)
             self.streams = _pool_streams("main", world_size)
             self.side_streams = _pool_streams("side", world_size)
+            for r, env in enumerate(self.envs):
+                env.side_stream = self.side_streams[r]
         else:
             self.streams = self.side_streams = None
 
