@@ -41,7 +41,8 @@ def _mlp_ref(x, t):
     return h @ t.down_proj.weight.float().t()
 
 
-@pytest.mark.parametrize("w,M,H,I", [(2, 512, 1024, 2048), (4, 1024, 512, 4096), (8, 2048, 1024, 2048)])
+@pytest.mark.parametrize("w,M,H,I", [(2, 512, 1024, 2048), (4, 1024, 512, 4096), (8, 2048, 1024, 2048),
+                                     (4, 256, 512, 1024)])
 def test_tp_mlp_modes(w, M, H, I):
     torch.manual_seed(1)
     tree = _mlp_tree(H, I)
@@ -115,7 +116,8 @@ def _attn_ref(x, t, pos, cos_sin, past_k=None, past_v=None):
     return o @ t.o_proj.weight.float().t(), k, v
 
 
-@pytest.mark.parametrize("w,B,S,H,Hq,Hkv,D", [(2, 4, 64, 1024, 8, 4, 128), (4, 4, 32, 512, 16, 8, 64)])
+@pytest.mark.parametrize("w,B,S,H,Hq,Hkv,D", [(2, 4, 64, 1024, 8, 4, 128), (4, 4, 32, 512, 16, 8, 64),
+                                              (4, 8, 32, 512, 8, 8, 64)])
 def test_tp_attn_prefill_and_decode(w, B, S, H, Hq, Hkv, D):
     torch.manual_seed(2)
     tree = _attn_tree(H, Hq, Hkv, D)

@@ -103,11 +103,14 @@ _ARANGE = {}
 
 
 def _identity_table(device, bsz: int, pages: int) -> torch.Tensor:
-    key = (device, bsz, pages)
+    """[bsz, pages] page table 0..bsz*pages-1.  Cached per stream: the fill is ordered only against
+    the stream that created it, and creating it must not force a host synchronisation."""
+    key = (device, bsz, pages, torch.cuda.current_stream(device).cuda_stream)
     t = _ARANGE.get(key)
     if t is None:
         t = torch.arange(bsz * pages, dtype=torch.int32, device=device).view(bsz, pages)
-        _ARANGE[key] = t
+        if not torch.cuda.is_current_stream_capturing():
+            _ARANGE[key] = t
     return t
 
 

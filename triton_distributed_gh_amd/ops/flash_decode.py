@@ -23,10 +23,13 @@ _TICKETS = {}
 
 
 def _tickets(device, n: int) -> torch.Tensor:
-    t = _TICKETS.get(device)
+    """Arrival counters of the fused merge (self-resetting).  One array per (device, stream): two
+    decode launches that run concurrently on different streams must not share counters."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    t = _TICKETS.get(key)
     if t is None or t.numel() < n:
         t = torch.zeros(max(n, 4096), dtype=torch.int32, device=device)
-        _TICKETS[device] = t
+        _TICKETS[key] = t
     return t
 
 
