@@ -29,7 +29,7 @@ from typing import Any, List, Optional
 import torch
 
 from .. import _lib
-from ..utils.distributed import default_num_ctas, get_env
+from ..utils.distributed import default_num_ctas, forbid_graph_capture, get_env
 from .gemm import _DT, gemm_nt
 
 EPOCH_MOD = 4093
@@ -172,6 +172,7 @@ def ag_gemm_intra_node_op(a, b, c, ctx: AllGatherGEMMTensorParallelContext):
         gemm_nt(a, b, out=c)
         return c
     a = a.contiguous()
+    forbid_graph_capture("ag_gemm", w)
     parity = ctx.call_count & 1
     epoch = ctx.call_count % EPOCH_MOD + 1
     ctx.call_count += 1

@@ -21,7 +21,7 @@ from typing import Any, List, Optional
 import torch
 
 from .. import _lib
-from ..utils.distributed import get_env
+from ..utils.distributed import forbid_graph_capture, get_env
 
 
 class AllGatherMethod(enum.Enum):
@@ -88,6 +88,7 @@ def fast_allgather(symm_buffer: torch.Tensor, ctx: FastAllGatherContext, rank: O
     if w == 1:
         return symm_buffer
     bytes_per_rank = symm_buffer[0].numel() * symm_buffer.element_size()
+    forbid_graph_capture("fast_allgather", w)
     ctx.signal_target += 1
     epoch = ctx.signal_target
     if env.backend == "host":

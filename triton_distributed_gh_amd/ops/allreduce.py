@@ -21,7 +21,7 @@ from typing import Any, List, Optional
 import torch
 
 from .. import _lib
-from ..utils.distributed import get_env
+from ..utils.distributed import forbid_graph_capture, get_env
 
 EPOCH_MOD = 1 << 30
 _DT = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
@@ -129,6 +129,7 @@ def _all_reduce_chunk(x, out, method, ctx: AllReduceContext, max_sm: int):
     w, rank = ctx.world_size, ctx.rank
     n = x.numel()
     esize = x.element_size()
+    forbid_graph_capture("all_reduce", w)
     parity = ctx.call_count & 1
     epoch = ctx.call_count % EPOCH_MOD + 1
     ctx.call_count += 1

@@ -18,7 +18,7 @@ from typing import Any, List, Optional
 import torch
 
 from .. import _lib
-from ..utils.distributed import default_num_ctas, get_env
+from ..utils.distributed import default_num_ctas, forbid_graph_capture, get_env
 from .gemm import _DT, gemm_nt
 
 EPOCH_MOD = 1 << 30
@@ -93,6 +93,7 @@ def gemm_allreduce_op(ctx: GemmARContext, a: torch.Tensor, b: torch.Tensor, gemm
     w, rank = ctx.world_size, ctx.rank
     if w == 1:
         return gemm_nt(a, b)
+    forbid_graph_capture("gemm_allreduce", w)
     parity = ctx.call_count & 1
     epoch = ctx.call_count % EPOCH_MOD + 1
     ctx.call_count += 1

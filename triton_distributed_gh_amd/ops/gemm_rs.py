@@ -21,7 +21,7 @@ from typing import Any, List, Optional
 import torch
 
 from .. import _lib
-from ..utils.distributed import default_num_ctas, get_env
+from ..utils.distributed import default_num_ctas, forbid_graph_capture, get_env
 from .gemm import _DT, gemm_nt
 
 EPOCH_MOD = 4093
@@ -107,6 +107,7 @@ def gemm_rs_intra_node_op(a, b, ctx: GEMMReduceScatterTensorParallelContext, out
     if w == 1 and os.environ.get("TDIST_FORCE_FUSED", "0") != "1":
         gemm_nt(a, b, out=out)
         return out
+    forbid_graph_capture("gemm_rs", w)
     parity = ctx.call_count & 1
     epoch = ctx.call_count % EPOCH_MOD + 1
     ctx.call_count += 1

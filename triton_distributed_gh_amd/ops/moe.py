@@ -21,7 +21,7 @@ from typing import Any, Optional
 import torch
 
 from .. import _lib
-from ..utils.distributed import default_num_ctas, get_env
+from ..utils.distributed import default_num_ctas, forbid_graph_capture, get_env
 from .ag_gemm import (AllGatherGEMMTensorParallelContext, EPOCH_MOD, _push_kernel, _rows_per_chunk,
                       create_ag_gemm_intra_node_context)
 from .gemm import _DT
@@ -166,6 +166,7 @@ def ag_group_gemm(a: torch.Tensor, b: torch.Tensor, ctx: MoEAllGatherGroupGEMMTe
     token's activation through expert full_topk_ids[token, k]."""
     ag, env = ctx.ag, ctx.env
     w, rank = ctx.num_ranks, ctx.rank
+    forbid_graph_capture("ag_group_gemm", w)
     M_per_rank, K = a.shape
     ntokens, topk = full_topk_ids.shape
     assert ntokens == M_per_rank * w and K == ctx.K
@@ -303,6 +304,7 @@ def run_moe_reduce_rs(x: torch.Tensor, weights: torch.Tensor, chosen_experts: to
     weights.  Returns [ntokens/w, hidden] = ReduceScatter_tokens(sum_k w_k * x_k @ W[e_k])."""
     env = ctx.env
     w, rank = ctx.world_size, ctx.rank
+    forbid_graph_capture("run_moe_reduce_rs", w)
     ntokens, topk = chosen_experts.shape
     K = x.shape[1]
     N = ctx.hidden_dim

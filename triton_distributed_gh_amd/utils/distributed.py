@@ -141,6 +141,15 @@ def default_num_ctas(env: "DistEnv", num_ranks: int, requested: int = 0) -> int:
     return 0
 
 
+def forbid_graph_capture(op: str, world_size: int) -> None:
+    """The fused multi-rank ops number their calls with a host-side epoch (it selects the buffer
+    parity and the flag value a kernel waits for).  A captured graph would replay ONE epoch forever,
+    so peers' flags from the previous replay would satisfy the waits: refuse instead of racing."""
+    if world_size > 1 and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError(f"{op}: multi-rank fused ops cannot be captured into a HIP graph (per-call epochs are "
+                           "host state); run them eagerly")
+
+
 def finalize_distributed() -> None:
     """Tear down heap and process groups (reference: python/triton_dist/utils.py:145-148)."""
     global _ENV
