@@ -158,3 +158,20 @@ def test_two_process_gloo_shared_memory_heap(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"WORKER_OK {r}" in o, o[-2000:]
+
+
+@pytest.mark.parametrize("ntokens,E,topk,w,rank", [(64, 8, 2, 1, 0), (512, 8, 2, 4, 1), (2400, 32, 4, 8, 5)])
+def test_cpp_moe_align_oracle_matches_python_reference(ntokens, E, topk, w, rank):
+    from triton_distributed_gh_amd.ops.moe import _align_cpu, moe_align_reference
+
+    torch.manual_seed(ntokens)
+    ids = torch.stack([torch.randperm(E)[:topk] for _ in range(ntokens)]).int()
+    tpr = ntokens // w
+    got = moe_align_reference(ids, E, w, rank, tpr)
+    ref = _align_cpu(ids, E, w, rank, tpr, got.sorted_ids.numel())
+    nb = int(ref.meta[0])
+    assert torch.equal(got.meta, ref.meta)
+    assert torch.equal(got.sorted_ids, ref.sorted_ids)
+    assert torch.equal(got.expert_of_block[:nb], ref.expert_of_block[:nb])
+    assert torch.equal(got.seg_range[:nb], ref.seg_range[:nb])
+    assert torch.equal(got.order[:nb], ref.order[:nb])

@@ -29,6 +29,7 @@ from typing import Any, List, Optional
 import torch
 
 from .. import _lib
+from ..autotuner import tuning
 from ..utils.distributed import default_num_ctas, forbid_graph_capture, get_env
 from .gemm import _DT, gemm_nt
 
@@ -176,7 +177,7 @@ def ag_gemm_intra_node_op(a, b, c, ctx: AllGatherGEMMTensorParallelContext):
     parity = ctx.call_count & 1
     epoch = ctx.call_count % EPOCH_MOD + 1
     ctx.call_count += 1
-    rpc = _rows_per_chunk(M_per_rank, ctx.M_PER_CHUNK)
+    rpc = _rows_per_chunk(M_per_rank, tuning.get("ag_gemm.M_PER_CHUNK", ctx.M_PER_CHUNK))
     straddle = M_per_rank % _BM != 0
 
     if ctx.backend == "host":

@@ -70,24 +70,24 @@ def set_signal(signal: torch.Tensor | int, value: int, stream=None, bits: Option
 
 
 def wait_eq(signal: torch.Tensor | int, value: int, stream=None, bits: Optional[int] = None,
-            timeout_ms: int = 60000) -> None:
-    """Make ``stream`` wait until the signal word equals ``value``."""
+            timeout_ms: int = 60000, ge: bool = False) -> None:
+    """Make ``stream`` wait until the signal word equals (``ge``: is at least) ``value``."""
     addr = signal if isinstance(signal, int) else signal.data_ptr()
     if bits is None:
         bits = 64 if (not isinstance(signal, int) and signal.element_size() == 8) else 32
     if not torch.cuda.is_available():
         lib = _lib.host()
         fn = lib.tdh_wait64 if bits == 64 else lib.tdh_wait32
-        if fn(ctypes.c_void_p(addr), 1, 0, value, ctypes.c_int64(timeout_ms)) != 0:
+        if fn(ctypes.c_void_p(addr), 1, 5 if ge else 0, value, ctypes.c_int64(timeout_ms)) != 0:
             raise RuntimeError("wait_eq (host) timed out")
         return
     lib = _lib.hip()
     if bits == 64:
         _lib.check(lib.tdist_stream_wait_value64(_lib.stream_handle(stream), ctypes.c_void_p(addr),
-                                                 ctypes.c_ulonglong(value), 0), "hipStreamWaitValue64")
+                                                 ctypes.c_ulonglong(value), 1 if ge else 0), "hipStreamWaitValue64")
     else:
         _lib.check(lib.tdist_stream_wait_value32(_lib.stream_handle(stream), ctypes.c_void_p(addr),
-                                                 ctypes.c_uint(value), 0), "hipStreamWaitValue32")
+                                                 ctypes.c_uint(value), 1 if ge else 0), "hipStreamWaitValue32")
 
 
 def memcpy_async(dst: torch.Tensor | int, src: torch.Tensor | int, nbytes: int, stream=None,

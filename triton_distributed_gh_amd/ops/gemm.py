@@ -16,6 +16,7 @@ from typing import Optional
 import torch
 
 from .. import _lib
+from ..autotuner import tuning
 
 _DT = {torch.bfloat16: 0, torch.float16: 1}
 # main-loop schedule: 1 = four phases per K-step, 2 = two phases per K-step
@@ -33,9 +34,13 @@ def gemm_supported(a: torch.Tensor, b: torch.Tensor) -> bool:
             and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and M > 0 and N > 0)
 
 
-def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, group_m: int = 8,
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, group_m: Optional[int] = None,
             force_native: bool = False, variant: Optional[int] = None) -> torch.Tensor:
     assert a.shape[1] == b.shape[1], f"K mismatch: {tuple(a.shape)} vs {tuple(b.shape)}"
+    if group_m is None:
+        group_m = tuning.get("gemm.group_m", 8)
+    if variant is None:
+        variant = tuning.get("gemm.variant", GEMM_VARIANT)
     M, K = a.shape
     N = b.shape[0]
     if out is None:
@@ -49,5 +54,5 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     _lib.check(
         lib.tdist_gemm_nt(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), M, N, K, ctypes.c_longlong(a.stride(0)),
                           ctypes.c_longlong(b.stride(0)), ctypes.c_longlong(out.stride(0)), _DT[a.dtype], group_m,
-                          _lib.stream_handle(), variant if variant is not None else GEMM_VARIANT), "tdist_gemm_nt")
+                          _lib.stream_handle(), variant), "tdist_gemm_nt")
     return out

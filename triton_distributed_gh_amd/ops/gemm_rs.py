@@ -21,6 +21,7 @@ from typing import Any, List, Optional
 import torch
 
 from .. import _lib
+from ..autotuner import tuning
 from ..utils.distributed import default_num_ctas, forbid_graph_capture, get_env
 from .gemm import _DT, gemm_nt
 
@@ -111,7 +112,7 @@ def gemm_rs_intra_node_op(a, b, ctx: GEMMReduceScatterTensorParallelContext, out
     parity = ctx.call_count & 1
     epoch = ctx.call_count % EPOCH_MOD + 1
     ctx.call_count += 1
-    rpc = _rows_per_chunk(M_per_rank, ctx.M_PER_CHUNK)
+    rpc = _rows_per_chunk(M_per_rank, tuning.get("gemm_rs.M_PER_CHUNK", ctx.M_PER_CHUNK))
     if ctx.backend == "host":
         return _gemm_rs_host(a, b, out, ctx, parity, epoch)
     a = a.contiguous()

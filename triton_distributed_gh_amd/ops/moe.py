@@ -96,6 +96,26 @@ def _align_cpu(ids, E, w, rank, tpr, cap):
     return AlignedIndex(sorted_ids, eob, seg, ordv, meta)
 
 
+def moe_align_reference(topk_ids: torch.Tensor, num_experts: int, world_size: int = 1, rank: int = 0,
+                         tokens_per_rank: Optional[int] = None) -> AlignedIndex:
+    """The native C++ CPU oracle (csrc/runtime/moe_align_ref.cc) of ``moe_align_block_size``."""
+    ids = topk_ids.to(torch.int32).cpu().contiguous()
+    ntokens, topk = ids.shape
+    n = ntokens * topk
+    tpr = tokens_per_rank or max(1, ntokens // world_size)
+    cap = (n + num_experts * (BLOCK_M - 1) + BLOCK_M - 1) // BLOCK_M * BLOCK_M
+    nb = cap // BLOCK_M
+    out = AlignedIndex(torch.empty(cap, dtype=torch.int32), torch.zeros(nb, dtype=torch.int32),
+                       torch.zeros((nb, 2), dtype=torch.int32), torch.zeros(nb, dtype=torch.int32),
+                       torch.zeros(2 + num_experts, dtype=torch.int32))
+    rc = _lib.host().tdh_moe_align_reference(_lib.ptr(ids), n, num_experts, world_size, topk, tpr, rank, cap, BLOCK_M,
+                                             _lib.ptr(out.sorted_ids), _lib.ptr(out.expert_of_block),
+                                             _lib.ptr(out.seg_range), _lib.ptr(out.order), _lib.ptr(out.meta))
+    if rc != 0:
+        raise ValueError(f"moe_align_reference: invalid input (code {rc})")
+    return out
+
+
 def calc_gather_scatter_index(choosed_experts: torch.Tensor, num_experts: int):
     """(gather_index, scatter_index, splits): rows sorted by expert (stable)."""
     flat = choosed_experts.reshape(-1).long()
