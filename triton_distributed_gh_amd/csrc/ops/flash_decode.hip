@@ -18,253 +18,27 @@
 //   * "fused" launches merge the splits in the last workgroup to finish a (batch, head block)
 //     (atomic ticket), which replaces the reference's grid barrier + second phase.
 #include "tdist/common.hpp"
+#include "tdist/flash_decode_device.hpp"
 #include "tdist/gemm_gfx950.hpp"
 
 namespace {
 
-using tdist::gemm::f32x4;
-using tdist::gemm::Frag;
-
-struct DecodeArgs {
-  const uint16_t* q;         // [batch, q_heads, D]
-  const uint16_t* k_cache;   // [slots, kv_heads, D] (slot = page * page_size + offset)
-  const uint16_t* v_cache;
-  const int* block_table;    // [batch, max_pages]
-  const int* kv_len;         // [batch]
-  float* partial;            // [batch, q_heads, splits, D + 1]
-  void* out;                 // fused: [batch, q_heads, D] (16-bit) or [batch, q_heads, D + 1] (fp32, LSE last)
-  int* tickets;              // fused: [batch * gridDim.y], zero before the first launch (self-resetting)
-  long long q_stride_b, q_stride_h;
-  long long k_stride_slot, k_stride_h;
-  long long v_stride_slot, v_stride_h;
-  long long p_stride_b, p_stride_h, p_stride_s;
-  long long o_stride_b, o_stride_h;
-  int table_stride;
-  int page_size, page_shift;  // page_shift >= 0 when page_size is a power of two
-  int q_heads, kv_heads, splits;
-  int fused;                  // 0: partials only, 1: merged 16-bit out, 2: merged fp32 out + LSE column
-  float sm_scale, soft_cap;
-};
-
-__device__ __forceinline__ long long slot_of(const DecodeArgs& a, const int* table, int tok) {
-  if (a.page_shift >= 0) {
-    const int page = table[tok >> a.page_shift];
-    return ((long long)page << a.page_shift) + (tok & (a.page_size - 1));
-  }
-  const int pi = tok / a.page_size;
-  return (long long)table[pi] * a.page_size + (tok - pi * a.page_size);
-}
-
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-
-template <bool IS_BF16>
-__device__ __forceinline__ uint16_t to16(float f) {
-  if constexpr (IS_BF16) {
-    return __builtin_bit_cast(uint16_t, (__bf16)f);
-  } else {
-    return __builtin_bit_cast(uint16_t, (_Float16)f);
-  }
-}
-
-// merge `n` partial rows (stride `stride` floats, LSE at column D) for one head; thread t owns
-// columns t, t + nthreads, ...  Returns through out pointers.  lens (optional) skips empty items.
-template <bool IS_BF16>
-__device__ __forceinline__ void merge_rows(const float* part, long long stride, int n, int D, const int* lens,
-                                           int lens_stride, void* out, int out_mode, int tid, int nthreads) {
-  float mx = -INFINITY;
-  for (int s = 0; s < n; ++s) {
-    if (lens && lens[(long long)s * lens_stride] <= 0) continue;
-    mx = fmaxf(mx, part[s * stride + D]);
-  }
-  float den = 0.f;
-  for (int s = 0; s < n; ++s) {
-    if (lens && lens[(long long)s * lens_stride] <= 0) continue;
-    const float l = part[s * stride + D];
-    den += (l == -INFINITY) ? 0.f : __expf(l - mx);
-  }
-  const float inv = den > 0.f ? 1.f / den : 0.f;
-  for (int c = tid; c < D; c += nthreads) {
-    float acc = 0.f;
-    for (int s = 0; s < n; ++s) {
-      if (lens && lens[(long long)s * lens_stride] <= 0) continue;
-      const float l = part[s * stride + D];
-      if (l == -INFINITY) continue;
-      acc += __expf(l - mx) * part[s * stride + c];
-    }
-    acc *= inv;
-    if (out_mode == 2) {
-      ((float*)out)[c] = acc;
-    } else {
-      ((uint16_t*)out)[c] = to16<IS_BF16>(acc);
-    }
-  }
-  if (out_mode == 2 && tid == 0) ((float*)out)[D] = den > 0.f ? mx + __logf(den) : -INFINITY;
-}
+using namespace tdist::fdec;
 
 template <bool IS_BF16, int D>
 __global__ __launch_bounds__(256) void decode_split_kernel(DecodeArgs a) {
-  using F = Frag<IS_BF16>;
-  using VT = typename F::T;
-  constexpr int KS = D / 32;    // MFMA k-steps over the head dim for S
-  constexpr int NDV = D / 16;   // dv blocks == 16-bit elements of V per lane per token
-  constexpr int VW = NDV / 2;   // dwords of V per lane per token
-  constexpr float LOG2E = 1.4426950408889634f;
-
   extern __shared__ char smem[];
-  float* s_m = (float*)smem;                    // [4][16]
-  float* s_l = s_m + 64;                        // [4][16]
-  float* s_acc = s_l + 64;                      // [4][16][D]
   __shared__ int s_last;
-
   const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
   const int group = a.q_heads / a.kv_heads;
   const int hblocks = (group + 15) / 16;
   const int kvh = blockIdx.y / hblocks;
   const int hblk = blockIdx.y - kvh * hblocks;
   const int h0 = kvh * group + hblk * 16;
   const int valid_h = min(16, group - hblk * 16);
-  const int z = blockIdx.z;
-
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int li = lane & 15;   // head (S / O column), token row of K operand, dv column of V operand
-  const int lg = lane >> 4;   // k-group
-
-  const int kv_len = a.kv_len[b];
-  const int per = (((kv_len + a.splits - 1) / a.splits) + 31) & ~31;
-  const int start = z * per;
-  const int end = min(start + per, kv_len);
-  const int* table = a.block_table + (long long)b * a.table_stride;
-
-  // Q operand: lane (head li, k-group lg) holds Q[h0 + li][32 s + 8 lg .. +8]
-  VT qreg[KS];
-  {
-    const uint16_t* qp = a.q + b * a.q_stride_b + (long long)(h0 + li) * a.q_stride_h + lg * 8;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      uint4 v = uint4{0, 0, 0, 0};
-      if (li < valid_h) v = *(const uint4*)(qp + 32 * s);
-      qreg[s] = __builtin_bit_cast(VT, v);
-    }
-  }
-
-  float m_run = -INFINITY, l_run = 0.f;
-  f32x4 acc[NDV];
-#pragma unroll
-  for (int j = 0; j < NDV; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const float qk_scale = a.soft_cap > 0.f ? a.sm_scale / a.soft_cap : a.sm_scale * LOG2E;
-  const uint16_t* kbase = a.k_cache + (long long)kvh * a.k_stride_h + lg * 8;
-  const uint16_t* vbase = a.v_cache + (long long)kvh * a.v_stride_h + li * NDV;
-
-  for (int n0 = start + wave * 32; n0 < end; n0 += 128) {
-    // ---- issue all loads of this block (16 x 16 B per lane for D = 128)
-    uint4 kreg[2][KS];
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-      const int tok = min(n0 + 16 * blk + li, kv_len - 1);
-      const uint16_t* kp = kbase + slot_of(a, table, tok) * a.k_stride_slot;
-#pragma unroll
-      for (int s = 0; s < KS; ++s) kreg[blk][s] = *(const uint4*)(kp + 32 * s);
-    }
-    uint32_t vreg[8][VW];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int tok = min(n0 + 16 * (t >> 2) + 4 * lg + (t & 3), kv_len - 1);
-      const uint16_t* vp = vbase + slot_of(a, table, tok) * a.v_stride_slot;
-      if constexpr (VW >= 4) {
-#pragma unroll
-        for (int c = 0; c < VW / 4; ++c) {
-          const uint4 v = *(const uint4*)(vp + 8 * c);
-          vreg[t][4 * c] = v.x, vreg[t][4 * c + 1] = v.y, vreg[t][4 * c + 2] = v.z, vreg[t][4 * c + 3] = v.w;
-        }
-      } else {
-        const uint2 v = *(const uint2*)vp;
-        vreg[t][0] = v.x, vreg[t][1] = v.y;
-      }
-    }
-
-    // ---- S^T = K . Q^T  (lane: head li, tokens 16 blk + 4 lg + i)
-    f32x4 st[2];
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-      st[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < KS; ++s) st[blk] = F::mfma(__builtin_bit_cast(VT, kreg[blk][s]), qreg[s], st[blk]);
-    }
-    float sc[8];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      float s = st[t >> 2][t & 3] * qk_scale;
-      if (a.soft_cap > 0.f) s = a.soft_cap * LOG2E * tanhf(s);
-      const int tok = n0 + 16 * (t >> 2) + 4 * lg + (t & 3);
-      s = tok < end ? s : -INFINITY;
-      sc[t] = s;
-      mx = fmaxf(mx, s);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);   // finite: the block holds at least one valid token
-    const float alpha = fast_exp2(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.f;
-    uint32_t pw[4];
-#pragma unroll
-    for (int t = 0; t < 8; t += 2) {
-      const float p0 = fast_exp2(sc[t] - m_new), p1 = fast_exp2(sc[t + 1] - m_new);
-      psum += p0 + p1;
-      pw[t >> 1] = F::pack2(p0, p1);
-    }
-    l_run = l_run * alpha + psum;
-    const VT pfrag = __builtin_bit_cast(VT, uint4{pw[0], pw[1], pw[2], pw[3]});
-
-    // ---- O^T += V^T . P^T, one dv block per MFMA; V operand by in-register transpose
-#pragma unroll
-    for (int j = 0; j < NDV; ++j) {
-      const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
-      uint32_t vw[4];
-#pragma unroll
-      for (int p = 0; p < 4; ++p) vw[p] = __builtin_amdgcn_perm(vreg[2 * p + 1][j >> 1], vreg[2 * p][j >> 1], sel);
-      f32x4 c = acc[j];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) c[i] *= alpha;
-      acc[j] = F::mfma(__builtin_bit_cast(VT, uint4{vw[0], vw[1], vw[2], vw[3]}), pfrag, c);
-    }
-  }
-
-  // ---- merge the four waves: lane (head li, group lg) holds dv = NDV * (4 lg + i) + j
-  l_run += __shfl_xor(l_run, 16);
-  l_run += __shfl_xor(l_run, 32);
-  if (lg == 0) {
-    s_m[wave * 16 + li] = m_run;
-    s_l[wave * 16 + li] = l_run;
-  }
-#pragma unroll
-  for (int j = 0; j < NDV; ++j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s_acc[(wave * 16 + li) * D + NDV * (4 * lg + i) + j] = acc[j][i];
-  __syncthreads();
-
-  float* prow = a.partial + b * a.p_stride_b + z * a.p_stride_s;
-  for (int idx = threadIdx.x; idx < 16 * D; idx += 256) {
-    const int h = idx / D, c = idx - h * D;
-    if (h >= valid_h) continue;
-    float M = -INFINITY;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) M = fmaxf(M, s_m[w * 16 + h]);
-    float L = 0.f, o = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const float mw = s_m[w * 16 + h];
-      const float f = mw == -INFINITY ? 0.f : fast_exp2(mw - M);
-      L += s_l[w * 16 + h] * f;
-      o += s_acc[(w * 16 + h) * D + c] * f;
-    }
-    float* dst = prow + (long long)(h0 + h) * a.p_stride_h;
-    dst[c] = L > 0.f ? o / L : 0.f;
-    if (c == 0) dst[D] = L > 0.f ? (M + __log2f(L)) * 0.6931471805599453f : -INFINITY;
-  }
+  decode_split_body<IS_BF16, D>(a, b, (int)blockIdx.y, (int)blockIdx.z, smem);
 
   if (!a.fused) return;
   // ---- last workgroup of this (batch, head block) merges the splits

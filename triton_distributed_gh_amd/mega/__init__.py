@@ -1,1 +1,6 @@
-
+"""Task-graph -> single persistent kernel runtime (reference: python/triton_dist/mega_triton_kernel/)."""
+from . import core  # noqa: F401
+from .core import (Task, TaskDependency, TaskType, check_schedule, register_task, registered_task_types,  # noqa: F401
+                   round_robin_scheduler, zig_zag_scheduler)
+from .model_builder import ModelBuilder  # noqa: F401
+from .qwen3 import Qwen3Model  # noqa: F401

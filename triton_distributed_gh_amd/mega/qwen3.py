@@ -1,0 +1,102 @@
+"""Qwen3-style dense decoder as ONE persistent-kernel launch per decode step.
+
+Reference: python/triton_dist/mega_triton_kernel/models/qwen3.py (``Qwen3Model`` :191-201
+``mega_forwrad``), models/layers/tp_attn.py, tp_mlp.py and models/paged_kv_cache.py.  The graph is
+built once from the tensor-parallel shards of a ``DenseLLM``; every step writes the token embeddings
+into the input buffer, launches the interpreter kernel and bumps the KV lengths.
+
+Per layer: [add +] rms_norm -> qkv_proj -> qk_norm + rope + kv-cache update -> split-KV attention ->
+combine -> o_proj [-> all-reduce] -> add + rms_norm -> fc1 (gate/up GEMM with fused SiLU*up) -> fc2
+[-> all-reduce]; residual adds are folded into the norm tasks."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from ..models.kv_cache import PagedKVCache
+from .model_builder import ModelBuilder
+
+
+class Qwen3Model:
+
+    def __init__(self, model, batch_size: int, max_length: Optional[int] = None, page_size: int = 64,
+                 num_queues: int = 256, scheduler: str = "round_robin", env=None, prefetch_weights: bool = False):
+        assert batch_size <= 16, "decode batch of at most 16 tokens per step"
+        self.model, self.batch_size = model, batch_size
+        self.env = env or model.env
+        w, dev, dt = model.world_size, model.device, model.dtype
+        assert dt == torch.bfloat16, "mega-kernel tasks are bf16"
+        self.world_size = w
+        H, D = model.hidden_size, model.head_dim
+        Hq, Hkv = model.num_heads // w, model.num_key_value_heads // w
+        self.max_length = max_length or model.max_length
+        self.kv_cache = PagedKVCache(model.num_layers, batch_size, self.max_length, model.num_key_value_heads, D,
+                                     page_size=page_size, dtype=dt, world_size=w, device=dev)
+        self.kv_lens = self.kv_cache.kv_offset
+        b = self.builder = ModelBuilder(model.rank, w, w, num_queues=num_queues, scheduler=scheduler, env=self.env)
+        B = batch_size
+        new = lambda *s: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
+        symm = (lambda *s: b.create_symm_tensor(s, dt)) if w > 1 else new
+        self.hidden = new(B, H)                  # residual stream (input: token embeddings)
+        xn, qkv = new(B, H), new(B, (Hq + 2 * Hkv) * D)
+        q, attn = new(B, Hq, D), new(B, Hq, D)
+        o_buf, mlp_buf = symm(B, H), symm(B, H)
+        o_red = new(B, H) if w > 1 else o_buf
+        mlp_red = new(B, H) if w > 1 else mlp_buf
+        inter = model.layers[0].mlp.gate_up_proj.shape[0] // 2
+        act = new(B, inter)
+        cos, sin = model.cos_sin_cache
+        delta = None
+        for li, layer in enumerate(model.layers):
+            a, m = layer.attn, layer.mlp
+            if prefetch_weights:
+                b.make_prefetch(m.gate_up_proj, name=f"l{li}.prefetch_fc1")
+            b.make_rms_norm(self.hidden if delta is None else delta, layer.input_norm_w, xn, layer.input_norm_eps,
+                            residual=None if delta is None else self.hidden,
+                            residual_out=None if delta is None else self.hidden, name=f"l{li}.norm1")
+            b.make_qkv_proj(xn, a.wqkv, qkv, name=f"l{li}.qkv")
+            b.make_qk_norm_rope_update_kvcache(qkv, getattr(a, "q_norm_w", None), getattr(a, "k_norm_w", None), cos, sin,
+                                               self.kv_lens, self.kv_cache.k_cache[li], self.kv_cache.v_cache[li],
+                                               self.kv_cache.block_table, q, getattr(a, "q_norm_eps", 1e-6),
+                                               name=f"l{li}.qk_norm_rope_kv")
+            b.make_attn(q, self.kv_cache.k_cache[li], self.kv_cache.v_cache[li], self.kv_cache.block_table, self.kv_lens,
+                        attn, name=f"l{li}.attn")
+            b.make_o_proj(attn.view(B, Hq * D), a.wo, o_buf, name=f"l{li}.o_proj")
+            if w > 1:
+                b.make_allreduce(o_buf, o_red, name=f"l{li}.attn_ar")
+            b.make_rms_norm(o_red, layer.post_norm_w, xn, layer.post_norm_eps, residual=self.hidden,
+                            residual_out=self.hidden, name=f"l{li}.norm2")
+            b.make_fc1(xn, m.gate_up_proj, act, name=f"l{li}.fc1")
+            b.make_fc2(act, m.down_proj, mlp_buf, name=f"l{li}.fc2")
+            if w > 1:
+                b.make_allreduce(mlp_buf, mlp_red, name=f"l{li}.mlp_ar")
+            delta = mlp_red
+        self.final = new(B, H)
+        b.make_rms_norm(delta, model.norm_weight, self.final, model.norm_variance_epsilon, residual=self.hidden,
+                        residual_out=self.hidden, name="final_norm")
+        V = model.lm_head.shape[0]
+        self.logits = new(B, V)
+        b.make_linear(self.final, model.lm_head, self.logits, name="lm_head")
+        self.compiled = b.compile()
+
+    @property
+    def num_tasks(self) -> int:
+        return self.compiled["num_tasks"]
+
+    def set_kv_len(self, n: int):
+        self.kv_lens.fill_(n)
+
+    @torch.inference_mode()
+    def mega_forward(self, input_ids: torch.Tensor) -> torch.Tensor:
+        """input_ids [B, 1] -> fp32 logits [B, 1, V]; appends the tokens to the KV cache."""
+        self.hidden.copy_(F.embedding(input_ids.view(-1), self.model.embed_tokens))
+        self.builder.run()
+        self.kv_lens += 1
+        return self.logits.float().unsqueeze(1)
+
+    mega_forwrad = mega_forward     # the reference's spelling
+
+    def check_error(self):
+        self.builder.check_error()
