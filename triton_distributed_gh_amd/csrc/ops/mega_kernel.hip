@@ -83,6 +83,37 @@ __device__ __forceinline__ uint4 pack8(const float* v) {
   return r;
 }
 
+// Write-through (sc1) stores: the bytes leave this XCD's L2 at once, so a hand-off needs no release
+// fence - only a drain (s_waitcnt vmcnt(0)) in every storing wave before the flag.  4 / 8 bytes per
+// store (agent-scope relaxed atomic stores lower to global_store ... sc1).
+__device__ __forceinline__ void st_wt32(void* p, uint32_t v) {
+  __hip_atomic_store((uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_wt128(void* p, const uint4& v) {
+  __hip_atomic_store((uint64_t*)p, ((uint64_t)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store((uint64_t*)p + 1, ((uint64_t)v.w << 32) | v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// L1-bypassing (sc1) 16-byte load of handed-off bytes: with write-through producer stores and every
+// consumer load of this form, a hand-off needs no acquire fence (no L1 invalidate) either.
+__device__ __forceinline__ uint4 ld_sc1_128(const void* p) {
+  const uint64_t lo = __hip_atomic_load((const uint64_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint64_t hi = __hip_atomic_load((const uint64_t*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return uint4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+}
+__device__ __forceinline__ float ld_sc1_bf16(const uint16_t* p) {
+  // 4-byte aligned container load, then pick the half
+  const uint32_t w = __hip_atomic_load((const uint32_t*)((uintptr_t)p & ~(uintptr_t)3), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+  return bf2f((uint16_t)(((uintptr_t)p & 2) ? (w >> 16) : (w & 0xffffu)));
+}
+
+// Streamed-once weights: non-temporal loads keep them from evicting the activations in L2.
+__device__ __forceinline__ uint4 ld_nt128(const void* p) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  const u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
+  return uint4{v[0], v[1], v[2], v[3]};
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -120,13 +151,13 @@ __device__ __forceinline__ void task_linear(const MegaOp& op, int tile, float* s
   for (; ks + U <= ks1; ks += U) {
     uint4 wv[U], xv[U], uv[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) wv[u] = *(const uint4*)(wr + (ks + u) * 32);
+    for (int u = 0; u < U; ++u) wv[u] = ld_nt128(wr + (ks + u) * 32);
     if (mode == 1) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) uv[u] = *(const uint4*)(ur + (ks + u) * 32);
+      for (int u = 0; u < U; ++u) uv[u] = ld_nt128(ur + (ks + u) * 32);
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) xv[u] = xvalid ? *(const uint4*)(xr + (ks + u) * 32) : uint4{0, 0, 0, 0};
+    for (int u = 0; u < U; ++u) xv[u] = xvalid ? ld_sc1_128(xr + (ks + u) * 32) : uint4{0, 0, 0, 0};
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const VT a = __builtin_bit_cast(VT, xv[u]);
@@ -135,12 +166,12 @@ __device__ __forceinline__ void task_linear(const MegaOp& op, int tile, float* s
     }
   }
   for (; ks < ks1; ++ks) {
-    const uint4 wv = *(const uint4*)(wr + ks * 32);
-    const uint4 xv = xvalid ? *(const uint4*)(xr + ks * 32) : uint4{0, 0, 0, 0};
+    const uint4 wv = ld_nt128(wr + ks * 32);
+    const uint4 xv = xvalid ? ld_sc1_128(xr + ks * 32) : uint4{0, 0, 0, 0};
     const VT a = __builtin_bit_cast(VT, xv);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(VT, wv), acc, 0, 0, 0);
     if (mode == 1) {
-      const uint4 uv = *(const uint4*)(ur + ks * 32);
+      const uint4 uv = ld_nt128(ur + ks * 32);
       acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(VT, uv), acc2, 0, 0, 0);
     }
   }
@@ -166,21 +197,24 @@ __device__ __forceinline__ void task_linear(const MegaOp& op, int tile, float* s
       }
     }
   }
+  // Epilogue: lanes li and li^1 hold neighbouring columns; the even lane stores both as one 4-byte
+  // write-through store (N and the row strides are even).
   const int col = n0 + li;
-  if (col >= N) return;
   uint16_t* out = (uint16_t*)op.p[2];
   const uint16_t* res = (const uint16_t*)op.p[3];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = 4 * lg + r;
-    if (row >= M) continue;
     float v = acc[r];
     if (mode == 1) {
       const float g = v;
       v = g / (1.f + __expf(-g)) * acc2[r];
     }
-    if (res) v += bf2f(res[(long long)row * ldr + col]);
-    out[(long long)row * ldo + col] = f2bf(v);
+    const bool ok = row < M && col < N;
+    if (res && ok) v += ld_sc1_bf16(res + (long long)row * ldr + col);
+    const uint32_t mine = f2bf(v);
+    const uint32_t other = __shfl_xor((int)mine, 1);
+    if (ok && (li & 1) == 0) st_wt32(out + (long long)row * ldo + col, mine | (other << 16));
   }
 }
 
@@ -196,12 +230,11 @@ __device__ __forceinline__ void task_rms_norm(const MegaOp& op, int row, float* 
   float ss = 0.f;
   for (int c = threadIdx.x * 8; c < H; c += 256 * 8) {
     float v[8], r[8];
-    unpack8(*(const uint4*)(x + c), v);
+    unpack8(ld_sc1_128(x + c), v);
     if (rin) {
-      unpack8(*(const uint4*)(rin + c), r);
+      unpack8(ld_sc1_128(rin + c), r);
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] = bf2f(f2bf(v[k] + r[k]));
-      if (rout) *(uint4*)(rout + c) = pack8(v);
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) ss += v[k] * v[k];
@@ -213,21 +246,19 @@ __device__ __forceinline__ void task_rms_norm(const MegaOp& op, int row, float* 
   const float inv = rsqrtf(tot / (float)H + op.f[0]);
   for (int c = threadIdx.x * 8; c < H; c += 256 * 8) {
     float v[8], r[8], g[8];
-    if (rout) {
-      // the sum was stored by this same thread in the first pass (rout may alias rin: in place)
-      unpack8(*(const uint4*)(rout + c), v);
-    } else {
-      unpack8(*(const uint4*)(x + c), v);
-      if (rin) {
-        unpack8(*(const uint4*)(rin + c), r);
+    unpack8(ld_sc1_128(x + c), v);
+    if (rin) {
+      // recomputed rather than re-read: rout may alias rin (in place), and it is written here, after
+      // this thread's own read of the same 16 bytes
+      unpack8(ld_sc1_128(rin + c), r);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = bf2f(f2bf(v[k] + r[k]));
-      }
+      for (int k = 0; k < 8; ++k) v[k] = bf2f(f2bf(v[k] + r[k]));
+      if (rout) st_wt128(rout + c, pack8(v));
     }
     unpack8(*(const uint4*)(w + c), g);
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = v[k] * inv * g[k];
-    *(uint4*)(out + c) = pack8(v);
+    st_wt128(out + c, pack8(v));
   }
 }
 
@@ -239,11 +270,11 @@ __device__ __forceinline__ void task_add(const MegaOp& op, int row) {
   uint16_t* o = (uint16_t*)op.p[2] + (long long)row * H;
   for (int c = threadIdx.x * 8; c < H; c += 256 * 8) {
     float x[8], y[8];
-    unpack8(*(const uint4*)(a + c), x);
-    unpack8(*(const uint4*)(b + c), y);
+    unpack8(ld_sc1_128(a + c), x);
+    unpack8(ld_sc1_128(b + c), y);
 #pragma unroll
     for (int k = 0; k < 8; ++k) x[k] += y[k];
-    *(uint4*)(o + c) = pack8(x);
+    st_wt128(o + c, pack8(x));
   }
 }
 
@@ -253,11 +284,11 @@ __device__ __forceinline__ void task_silu_mul(const MegaOp& op, int row) {
   uint16_t* o = (uint16_t*)op.p[2] + (long long)row * I;
   for (int c = threadIdx.x * 8; c < I; c += 256 * 8) {
     float x[8], y[8];
-    unpack8(*(const uint4*)(g + c), x);
-    unpack8(*(const uint4*)(g + I + c), y);
+    unpack8(ld_sc1_128(g + c), x);
+    unpack8(ld_sc1_128(g + I + c), y);
 #pragma unroll
     for (int k = 0; k < 8; ++k) x[k] = x[k] / (1.f + __expf(-x[k])) * y[k];
-    *(uint4*)(o + c) = pack8(x);
+    st_wt128(o + c, pack8(x));
   }
 }
 
@@ -398,7 +429,7 @@ __device__ __forceinline__ void task_allreduce(const MegaParams& P, const MegaOp
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc[k] += v[k];
     }
-    *(uint4*)(out + c) = pack8(acc);
+    st_wt128(out + c, pack8(acc));
   }
 }
 
@@ -422,15 +453,28 @@ __global__ __launch_bounds__(256) void mega_kernel(MegaParams P) {
   const int q = blockIdx.x;
   const int ntask = P.queue_len[q];
   const int* myq = P.queues + (long long)q * P.max_tasks * TASK_WORDS;
+  int seen_op[MAX_DEPS] = {-1, -1, -1}, seen_lo[MAX_DEPS] = {0, 0, 0}, seen_hi[MAX_DEPS] = {0, 0, 0};
+  int seen_next = 0;
   for (int t = 0; t < ntask; ++t) {
     __syncthreads();
     if (threadIdx.x < TASK_WORDS) s_task[threadIdx.x] = myq[t * TASK_WORDS + threadIdx.x];
     __syncthreads();
     const int type = s_task[0], opi = s_task[1], tile = s_task[2], ndeps = s_task[3];
     // ---- wait for the dependencies (contiguous tile ranges of producer ops) ----
+    // A range this workgroup has already waited for (typical: consecutive column tiles of one
+    // linear op) is complete for good and its data was acquired then: skip the poll and the fence.
+    // Tasks that read handed-off bytes only through sc1 loads skip the L1 invalidate.
+    const bool acquire = !(type == TASK_LINEAR || type == TASK_RMS_NORM || type == TASK_ADD || type == TASK_SILU_MUL);
     for (int d = 0; d < ndeps && d < MAX_DEPS; ++d) {
       const int dop = s_task[4 + 3 * d], lo = s_task[5 + 3 * d], hi = s_task[6 + 3 * d];
-      wait(P.scoreboard + (long long)dop * P.max_tiles + lo, hi - lo, SCOPE_GPU, SEM_ACQUIRE, P.epoch, P.err);
+      bool seen = false;
+#pragma unroll
+      for (int k = 0; k < MAX_DEPS; ++k) seen |= (dop == seen_op[k] && lo >= seen_lo[k] && hi <= seen_hi[k]);
+      if (seen) continue;
+      wait(P.scoreboard + (long long)dop * P.max_tiles + lo, hi - lo, SCOPE_GPU, acquire ? SEM_ACQUIRE : SEM_RELAXED,
+           P.epoch, P.err);
+      seen_op[seen_next] = dop, seen_lo[seen_next] = lo, seen_hi[seen_next] = hi;
+      seen_next = (seen_next + 1) % MAX_DEPS;
     }
     const MegaOp& op = P.ops[opi];
     switch (type) {
@@ -449,11 +493,15 @@ __global__ __launch_bounds__(256) void mega_kernel(MegaParams P) {
       default: atomicOr(P.err, 4); break;
     }
     // ---- publish the tile ----
+    // Tasks whose outputs are all write-through stores need only the drain + barrier; the attention
+    // and rope/kv-cache tasks store plain and pay one agent-scope release (L2 write-back).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (type == TASK_ATTN_SPLIT || type == TASK_ATTN_COMBINE || type == TASK_QK_NORM_ROPE_KV) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       store_relaxed_agent(P.scoreboard + (long long)opi * P.max_tiles + tile, P.epoch);
     }
   }

@@ -23,9 +23,10 @@ from .core import (MAX_DEPS, SCHEDULERS, MegaOpStruct, OpRecord, Task, TaskDepen
 
 
 def _linear_bn(N: int, num_queues: int) -> int:
-    """Columns per task: prefer enough tiles to keep every queue busy."""
+    """Columns per linear task.  Fewer, larger tasks amortise the per-task overhead; more tasks keep
+    every CU streaming: take the largest BN that still yields >= 256 tasks (one per CU)."""
     for bn in (64, 32, 16):
-        if (N + bn - 1) // bn >= num_queues or bn == 16:
+        if (N + bn - 1) // bn >= 256 or bn == 16:
             return bn
     return 16
 
