@@ -91,25 +91,29 @@ class Runner:
         for _ in range(warmup):
             self.run(fn)
         self.barrier()
-        cuda = self.device.type == "cuda"
-        if cuda:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            e0.record()
         import time as _t
 
-        t0 = _t.perf_counter()
+        cuda = self.device.type == "cuda"
         if self.virtual:
+            # the ranks run on several streams: wall clock around a device-wide synchronise
+            t0 = _t.perf_counter()
             for _ in range(iters):
                 self.vc.run(fn, sync=False)
-        else:
-            env = self.envs[0]
+            if cuda:
+                torch.cuda.synchronize()
+            return (_t.perf_counter() - t0) * 1e3 / iters
+        env = self.envs[0]
+        if cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             for _ in range(iters):
                 fn(env.rank, env)
-        if cuda:
             e1.record()
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / iters
+        t0 = _t.perf_counter()
+        for _ in range(iters):
+            fn(env.rank, env)
         return (_t.perf_counter() - t0) * 1e3 / iters
 
     def barrier(self):
