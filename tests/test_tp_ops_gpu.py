@@ -26,8 +26,15 @@ def _ctas(w):
     (8, 4096, 2048, 256, 256, "kernel"),
     (8, 2048, 1024, 128, 128, "kernel"),
     (4, 256, 1536, 512, 256, "kernel"),       # 384 columns per rank: partial N tile
+    (2, 1024, 1024, 512, 256, "copy_engine"),
+    (4, 1024, 1024, 1024, 256, "kernel:split2"),
+    (4, 1024, 2048, 2048, 128, "kernel:split4"),
+    (4, 256, 1024, 512, 256, "kernel:split2"),   # straddling tiles + split-K
 ])
-def test_ag_gemm_virtual_ranks(w, M, N, K, chunk, producer):
+def test_ag_gemm_virtual_ranks(w, M, N, K, chunk, producer, monkeypatch):
+    if ":split" in producer:
+        producer, split = producer.split(":split")
+        monkeypatch.setenv("TDIST_AG_SPLIT_K", split)
     vc = VirtualCluster(w, heap_bytes=1 << 27)
     try:
         ctxs = vc.collective(lambda r, env: create_ag_gemm_intra_node_context(
@@ -85,5 +92,26 @@ def test_gemm_rs_virtual_ranks(w, M, N, K, chunk):
                 ref = partial[r * Mr:(r + 1) * Mr]
                 rel = (outs[r].float() - ref).abs().max().item() / ref.abs().max().item()
                 assert rel < 1e-2, f"rank {r} iteration {it}: {rel}"
+    finally:
+        vc.close()
+
+
+@pytest.mark.parametrize("split", [1, 2, 3, 4])
+def test_ag_gemm_split_k_single_rank(split, monkeypatch):
+    """The fused kernel on one rank (no peers): split-K partial sums + last-arriver fix-up vs fp32."""
+    monkeypatch.setenv("TDIST_FORCE_FUSED", "1")
+    monkeypatch.setenv("TDIST_AG_SPLIT_K", str(split))
+    vc = VirtualCluster(1, heap_bytes=1 << 26)
+    try:
+        M, N, K = 520, 776, 4096        # partial tiles in both directions
+        ctx = create_ag_gemm_intra_node_context(M, N, K, torch.bfloat16, torch.bfloat16, 0, 1, env=vc.envs[0])
+        for _ in range(2):
+            a = (torch.rand(M, K, device="cuda") * 2 - 1).bfloat16()
+            b = (torch.rand(N, K, device="cuda") * 2 - 1).bfloat16()
+            out = vc.run(lambda r, env: ag_gemm_intra_node(a, b, False, ctx))[0]
+            ctx.check_error()
+            ref = a.float() @ b.float().t()
+            rel = (out.float() - ref).abs().max().item() / ref.abs().max().item()
+            assert rel < 1e-2, rel
     finally:
         vc.close()

@@ -31,6 +31,8 @@ KNOWN_KNOBS: Dict[str, Sequence[Any]] = {
     "gemm.group_m": (8, 4, 16),        # tile rows per L2 group
     "ag_gemm.M_PER_CHUNK": (256, 512, 1024),
     "ag_gemm.producer": ("kernel", "copy_engine"),
+    "ag_gemm.PUSH_WGS": (0, 8, 16, 32),          # 0 = 8 per outgoing link
+    "ag_gemm.SPLIT_K": (0, 1, 2, 4),             # 0 = fill the CUs
     "gemm_rs.M_PER_CHUNK": (256, 512),
 }
 

@@ -391,11 +391,13 @@ __device__ __forceinline__ void mainloop_256_2ph(const TileArgs& t, char* smem, 
   if (!late_group) __builtin_amdgcn_s_barrier();
 }
 
-// Convert the accumulators to 16-bit, stage the 256x256 tile in LDS and hand 16-byte row pieces to
+// Convert accumulators to 16-bit, stage the 256x256 tile in LDS and hand 16-byte row pieces to
 // `store(row_in_tile, col_in_tile, uint4)`; every thread calls store 16 times with rows
-// (pass*16 + tid/32) and columns (tid%32)*8.  Ends with a workgroup barrier so LDS may be reused.
-template <bool IS_BF16, class StoreFn>
-__device__ __forceinline__ void epilogue_256(const Acc<IS_BF16>& acc, char* smem, StoreFn&& store) {
+// (pass*16 + tid/32) and columns (tid%32)*8.  `get(m, v)` fills v[0..3] with the calling thread's
+// fp32 values of accumulator tiles (m, 0..3) in the Acc layout.  Ends with a workgroup barrier so
+// LDS may be reused.
+template <bool IS_BF16, class GetFn, class StoreFn>
+__device__ __forceinline__ void epilogue_256_from(GetFn&& get, char* smem, StoreFn&& store) {
   using F = Frag<IS_BF16>;
   const int tid = threadIdx.x;
   const int w = tid >> 6, l = tid & 63;
@@ -403,15 +405,17 @@ __device__ __forceinline__ void epilogue_256(const Acc<IS_BF16>& acc, char* smem
   // all waves are past their last fragment read (mainloop ends on a barrier)
   char* base = smem + (wr * 128 + (l & 15)) * C_STRIDE + (wc * 64 + (l >> 4) * 4) * 2;
 #pragma unroll
-  for (int m = 0; m < 8; ++m)
+  for (int m = 0; m < 8; ++m) {
+    f32x4 v[4];
+    get(m, v);
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
-      const f32x4 v = acc.v[m][n];
       uint2 p;
-      p.x = F::pack2(v[0], v[1]);
-      p.y = F::pack2(v[2], v[3]);
+      p.x = F::pack2(v[n][0], v[n][1]);
+      p.y = F::pack2(v[n][2], v[n][3]);
       *(uint2*)(base + m * 16 * C_STRIDE + n * 32) = p;
     }
+  }
   __syncthreads();
   const int r0 = tid >> 5, cc = tid & 31;
 #pragma unroll 4
@@ -421,6 +425,16 @@ __device__ __forceinline__ void epilogue_256(const Acc<IS_BF16>& acc, char* smem
     store(row, cc * 8, v);
   }
   __syncthreads();
+}
+
+template <bool IS_BF16, class StoreFn>
+__device__ __forceinline__ void epilogue_256(const Acc<IS_BF16>& acc, char* smem, StoreFn&& store) {
+  epilogue_256_from<IS_BF16>(
+      [&](int m, f32x4(&v)[4]) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) v[n] = acc.v[m][n];
+      },
+      smem, store);
 }
 
 // Bijective remap of a linear workgroup id so that each group of ids that shares an XCD

@@ -1,11 +1,22 @@
-// AllGather + GEMM consumer:  C[M, N_local] = AllGather_M(A[M/w, K]) * B[N_local, K]^T.
+// AllGather + GEMM, one persistent kernel per rank:  C[M, N_local] = AllGather_M(A[M/w, K]) * B[N_local, K]^T.
 //
-// The producer side (copy-engine pushes over xGMI, or the push kernel below) writes every peer's
-// shard of A into this rank's symmetric workspace [M, K] chunk by chunk and raises one int32 flag
-// per (source rank, chunk) to the call's epoch value.  This persistent kernel pulls 256x256 tile
-// jobs from a device-side ticket counter in expected-arrival order (own rows first, then chunk 0
-// of every peer, chunk 1 of every peer, ...), waits - workgroup-collectively, system scope,
-// acquire - for the flags covering the tile's rows, and runs the MFMA main loop.
+// Work items are handed out by a device-side ticket counter.  The first `push_wgs` tickets are
+// PRODUCER items: they store this rank's shard of A into every peer's symmetric workspace [M, K]
+// over xGMI, chunk by chunk, and raise one int32 flag per (source rank, chunk) to the call's epoch
+// value on every peer.  All later tickets are 256x256 tile jobs in expected-arrival order (own
+// rows first, then chunk 0 of every peer, chunk 1 of every peer, ...); a tile job waits -
+// workgroup-collectively, system scope, acquire - for the flags covering its rows and runs the
+// MFMA main loop.  Producer and consumer share one launch because the GEMM workgroups fill the
+// register file of every CU: a separate push kernel that reaches the GPU after the GEMM could
+// not be scheduled until GEMM workgroups exit, and those are waiting for the peers' pushes.
+// Producer items never wait and hold the lowest tickets, so progress does not depend on dispatch
+// order.  (With push_wgs == 0 the data is expected from the SDMA copy engines instead.)
+//
+// When the problem has fewer tiles than the chip has CUs (large TP degree), K is cut into
+// `split_k` ranges, one work item each: every item parks its fp32 accumulators in a scratch
+// buffer (register layout, coalesced) and whichever item of a tile finishes last sums them and
+// runs the epilogue - nobody waits.  This also divides the exposed tail after the last chunk
+// lands by split_k.
 //
 // Differences from the reference's consumer
 // (reference: python/triton_dist/kernels/amd/all_gather_gemm.py:127-245, 401-433):
@@ -14,6 +25,7 @@
 //   * tiles are handed out dynamically, so a workgroup stalled on a late chunk never holds back
 //     tiles whose data already arrived;
 //   * every spin is bounded and reports through an error word instead of hanging the GPU.
+#include "tdist/cache_policy.hpp"
 #include "tdist/common.hpp"
 #include "tdist/gemm_gfx950.hpp"
 #include "tdist/primitives.hpp"
@@ -23,22 +35,89 @@ using namespace tdist;
 using namespace tdist::gemm;
 
 struct AgGemmParams {
+  SymmCtx ctx;               // only read when push_wgs > 0
   const uint16_t* a_local;   // [M_per_rank, K] own shard (never copied unless straddle)
-  const uint16_t* ws;        // [M, K] symmetric workspace of this call's parity
+  uint16_t* ws;              // [M, K] symmetric workspace of this call's parity
   const uint16_t* B;         // [N_local, K]
   uint16_t* C;               // [M, N_local]
-  const int* flags;          // [w * chunks_per_rank] of this call's parity
+  int* flags;                // [w * chunks_per_rank] of this call's parity (symmetric, signal arena)
   int* ticket;               // zeroed before launch
   int* err;                  // sticky error word (bit 0 = wait timeout)
+  int* push_done;            // [chunks_per_rank] zeroed before launch (push_wgs > 0)
+  int* tile_flags;           // [tiles] arrival counters, zeroed before launch (split_k > 1)
+  float* partial;            // [tiles * split_k][32][512] f32x4 (split_k > 1)
   long long lda_local, ld_ws, ldb, ldc;
   int M_per_rank, N_local, K;
   int rank, world;
   int rows_per_chunk;
   int epoch;
   int straddle;              // 1: tiles walk the whole [M, K] workspace (own rows copied in too)
+  int push_wgs;              // first push_wgs tickets push the local shard to every peer
+  int split_k;               // K is cut into split_k ranges, one work item each
 };
 
-constexpr int TICKET_SLOT = LDS_BYTES;  // 16 bytes after the tile staging area
+constexpr int TICKET_SLOT = LDS_BYTES;  // 16 bytes after the tile staging area: [0] ticket, [1] split-K arrival
+
+// Producer work item `pw` of `p.push_wgs`: for every chunk in order, copy slice pw of the chunk
+// to every peer's workspace.  Each thread keeps eight 16-byte pieces in flight; every piece is
+// loaded once and stored w-1 times with write-through stores, peers rotated per workgroup so all
+// xGMI links carry traffic at any moment.  The workgroup that completes a chunk raises that
+// chunk's flag on every peer.  Chunks go out in order so the consumers of every peer can start on
+// chunk 0 while chunk 1 is still on the wire.
+__device__ __forceinline__ void push_item(const AgGemmParams& p, int pw) {
+  constexpr int U = 8;
+  const int w = p.world, rank = p.rank;
+  const int cpr = p.M_per_rank / p.rows_per_chunk;
+  const long long row_bytes = (long long)p.K * 2;
+  const long long chunk_bytes = (long long)p.rows_per_chunk * row_bytes;   // multiple of 16 (K % 64 == 0)
+  const long long per = (((chunk_bytes + p.push_wgs - 1) / p.push_wgs) + 15) & ~15ll;
+  const long long b0 = min((long long)pw * per, chunk_bytes);
+  const long long b1 = min(b0 + per, chunk_bytes);
+  const int n16 = (int)((b1 - b0) >> 4);
+  const int first_piece = (int)(b0 >> 4);
+  const int pieces_per_row = (int)(row_bytes >> 4);
+  const int first_peer = p.straddle ? 0 : 1;
+  for (int chunk = 0; chunk < cpr; ++chunk) {
+    const long long src_row = (long long)chunk * p.rows_per_chunk;
+    const long long dst_off = ((long long)rank * p.M_per_rank + src_row) * row_bytes + b0;
+    for (int base = 0; base < n16; base += U * THREADS) {
+      uint4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + u * THREADS + (int)threadIdx.x;
+        if (i < n16) {
+          // the local shard may be strided (lda_local >= K): address it row by row
+          const int q = first_piece + i, r = q / pieces_per_row;
+          v[u] = *(const uint4*)((const char*)(p.a_local + (src_row + r) * p.lda_local) +
+                                 ((long long)(q - r * pieces_per_row) << 4));
+        }
+      }
+      for (int j = first_peer; j < w; ++j) {
+        const int peer = j == 0 ? rank : (rank + 1 + (j - 1 + pw) % (w - 1)) % w;
+        char* dst = (char*)(peer == rank ? p.ws : symm_at(p.ctx, p.ws, peer)) + dst_off;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int i = base + u * THREADS + (int)threadIdx.x;
+          if (i < n16) st_wt128_sys(dst + ((long long)i << 4), v[u]);
+        }
+      }
+    }
+    drain_stores();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      // every slice's stores completed before its own add; the completing add is ordered after
+      // all earlier adds on the word, so the flags follow all of the chunk's data
+      const int prev = atom_add_relaxed_agent(p.push_done + chunk, 1);
+      if (prev == p.push_wgs - 1) {
+        for (int j = first_peer; j < w; ++j) {
+          const int peer = (rank + j) % w;
+          int* f = (peer == rank ? p.flags : symm_at(p.ctx, p.flags, peer)) + rank * cpr + chunk;
+          store_relaxed_system(f, p.epoch);
+        }
+      }
+    }
+  }
+}
 
 template <bool IS_BF16>
 __global__ __launch_bounds__(THREADS, 2) void ag_gemm_consumer_kernel(AgGemmParams p) {
@@ -56,13 +135,22 @@ __global__ __launch_bounds__(THREADS, 2) void ag_gemm_consumer_kernel(AgGemmPara
     mb_per_rank = (p.M_per_rank + BM - 1) / BM;
     total_mb = mb_per_rank * w;
   }
-  const int total = total_mb * num_pid_n;
+  const int S = p.split_k;
+  const int total = p.push_wgs + total_mb * num_pid_n * S;
+  const int ksteps = p.K / BK;
 
   while (true) {
-    const int item = fetch_ticket_block(p.ticket, s_ticket);
+    int item = fetch_ticket_block(p.ticket, s_ticket);
     if (item >= total) break;
-    const int o = item / num_pid_n;
-    const int pid_n = item - o * num_pid_n;
+    if (item < p.push_wgs) {
+      push_item(p, item);
+      continue;
+    }
+    item -= p.push_wgs;
+    const int tile = item / S;
+    const int ks = item - tile * S;           // K range; the item with ks == S-1 owns the tile
+    const int o = tile / num_pid_n;
+    const int pid_n = tile - o * num_pid_n;
 
     // ---- which rows does this tile cover -----------------------------------------------
     int g0, rows;          // first global row, valid rows (<= 256)
@@ -105,26 +193,84 @@ __global__ __launch_bounds__(THREADS, 2) void ag_gemm_consumer_kernel(AgGemmPara
       const int g1 = g0 + rows - 1;
       const int f0 = (g0 / p.M_per_rank) * cpr + (g0 % p.M_per_rank) / p.rows_per_chunk;
       const int f1 = (g1 / p.M_per_rank) * cpr + (g1 % p.M_per_rank) / p.rows_per_chunk;
-      const int token = wait(p.flags + f0, f1 - f0 + 1, SCOPE_SYS, SEM_ACQUIRE, p.epoch, p.err);
+      const int token = wait((const int*)p.flags + f0, f1 - f0 + 1, SCOPE_SYS, SEM_ACQUIRE, p.epoch, p.err);
       a_ptr = consume_token(a_ptr, token);
     }
 
+    const int k0 = (int)((long long)ksteps * ks / S) * BK;
+    const int k1 = (int)((long long)ksteps * (ks + 1) / S) * BK;
     TileArgs t;
-    t.A = a_ptr;
-    t.B = p.B + (long long)pid_n * BN * p.ldb;
+    t.A = a_ptr + k0;
+    t.B = p.B + (long long)pid_n * BN * p.ldb + k0;
     t.lda = lda;
     t.ldb = p.ldb;
     t.a_rows = rows;
     t.b_rows = p.N_local - pid_n * BN;
-    t.K = p.K;
+    t.K = k1 - k0;
     Acc<IS_BF16> acc;
     mainloop_256_2ph<IS_BF16>(t, smem, acc);
+
     const int nrem = p.N_local - pid_n * BN;
     uint16_t* cbase = p.C + (long long)g0 * p.ldc + pid_n * BN;
     const long long ldc = p.ldc;
-    epilogue_256<IS_BF16>(acc, smem, [&](int r, int c, const uint4& v) {
+    auto store_c = [&](int r, int c, const uint4& v) {
       if (r < rows && c < nrem) *(uint4*)(cbase + (long long)r * ldc + c) = v;
-    });
+    };
+    if (S == 1) {
+      epilogue_256<IS_BF16>(acc, smem, store_c);
+      continue;
+    }
+    // Split-K fix-up, wait-free: every item parks its fp32 accumulators (register layout, so both
+    // directions are fully coalesced) and counts itself; whichever item of the tile counts last
+    // sums the split_k partials piece by piece straight into the epilogue's LDS staging.  The
+    // accumulators are dead after the store, which keeps the fix-up out of the main loop's
+    // register budget.  The per-thread offset is made opaque so it is not hoisted out of the
+    // persistent loop (it would stay live across the main loop).
+    unsigned voff = threadIdx.x * 16u;
+    asm volatile("" : "+v"(voff));
+    char* tbase = (char*)p.partial + (long long)tile * S * (32 * THREADS * 16);
+    {
+      char* mine = tbase + (long long)ks * (32 * THREADS * 16);
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) st_wt128_agent(mine + (voff + (unsigned)((m * 4 + n) * THREADS * 16)), acc.v[m][n]);
+    }
+    // write-through stores: drain, barrier, count - no release fence
+    drain_stores();
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket[1] = atom_add_relaxed_agent(p.tile_flags + tile, 1);
+    __syncthreads();
+    const int arrived = __builtin_amdgcn_readfirstlane(s_ticket[1]);
+    if (arrived != S - 1) continue;
+    // last arriver: one acquire drops this CU's stale L1 lines, then plain loads
+    if (threadIdx.x < 64) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    epilogue_256_from<IS_BF16>(
+        [&](int m, f32x4(&v)[4]) {
+          // all 4 * split_k loads of this row of accumulator tiles are issued before the first add
+          f32x4 x[4][4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (q < S) {
+#pragma unroll
+              for (int n = 0; n < 4; ++n)
+                x[q][n] = *(const f32x4*)(tbase + (long long)q * (32 * THREADS * 16) +
+                                          (voff + (unsigned)((m * 4 + n) * THREADS * 16)));
+            }
+#pragma unroll
+          for (int n = 0; n < 4; ++n) v[n] = x[0][n];
+#pragma unroll
+          for (int q = 1; q < 4; ++q)
+            if (q < S) {
+#pragma unroll
+              for (int n = 0; n < 4; ++n) v[n] += x[q][n];
+            }
+        },
+        smem, store_c);
   }
 }
 
@@ -185,26 +331,43 @@ static int check_common(const void* B, const void* C, int N_local, int K, long l
   return 0;
 }
 
-TDIST_API int tdist_ag_gemm_consumer(const void* a_local, const void* ws, const void* B, void* C, const int* flags,
-                                     int* ticket, int* err, long long lda_local, long long ld_ws, long long ldb,
-                                     long long ldc, int M_per_rank, int N_local, int K, int rank, int world,
-                                     int rows_per_chunk, int epoch, int straddle, int num_ctas, int dtype,
-                                     void* stream) {
+// scratch layout (int32): [0] error word (sticky, never cleared here), [4] ticket,
+// [8, 8 + cpr) push counters, [8 + cpr, 8 + cpr + tiles) split-K arrival counters.
+TDIST_API int tdist_ag_gemm_consumer(const tdist::SymmCtx* ctx, const void* a_local, void* ws, const void* B, void* C,
+                                     int* flags, int* scratch, long long scratch_ints, void* partial,
+                                     long long partial_bytes, long long lda_local, long long ld_ws, long long ldb,
+                                     long long ldc, int M_per_rank, int N_local, int K, int rows_per_chunk, int epoch,
+                                     int straddle, int push_wgs, int split_k, int num_ctas, int dtype, void* stream) {
   if (check_common(B, C, N_local, K, ldb, ldc)) return -1;
+  const int world = ctx->num_ranks, rank = ctx->rank;
   TDIST_REQUIRE(world >= 1 && world <= TDIST_MAX_RANKS && rank >= 0 && rank < world, "bad rank/world");
   TDIST_REQUIRE(M_per_rank > 0 && rows_per_chunk > 0 && M_per_rank % rows_per_chunk == 0,
                 "M_per_rank must be a positive multiple of rows_per_chunk");
   TDIST_REQUIRE(lda_local % 8 == 0 && ld_ws % 8 == 0, "lda must be a multiple of 8");
   TDIST_REQUIRE((((uintptr_t)a_local | (uintptr_t)ws) & 15) == 0, "A operands must be 16-byte aligned");
-  TDIST_REQUIRE(straddle || world == 1 || true, "");
+  TDIST_REQUIRE(push_wgs >= 0 && push_wgs <= 64, "push_wgs must be in [0, 64]");
+  TDIST_REQUIRE(push_wgs == 0 || ld_ws == K, "the in-kernel producer needs a dense [M, K] workspace");
+  TDIST_REQUIRE(split_k >= 1 && split_k <= 4 && K / BK >= 2 * split_k, "split_k must be in [1, 4] with >= 128 of K each");
+  const int M = M_per_rank * world;
+  const int cpr = M_per_rank / rows_per_chunk;
+  const int total_mb = straddle ? (M + BM - 1) / BM : ((M_per_rank + BM - 1) / BM) * world;
+  const int tiles = total_mb * ((N_local + BN - 1) / BN);
+  const long long need_ints = 8 + cpr + (split_k > 1 ? tiles : 0);
+  TDIST_REQUIRE(scratch_ints >= ((need_ints + 3) & ~3ll), "scratch too small");
+  TDIST_REQUIRE(split_k == 1 || (partial && partial_bytes >= (long long)tiles * split_k * 32 * THREADS * 16),
+                "split-K partial buffer too small");
   AgGemmParams p;
+  p.ctx = *ctx;
   p.a_local = (const uint16_t*)a_local;
-  p.ws = (const uint16_t*)ws;
+  p.ws = (uint16_t*)ws;
   p.B = (const uint16_t*)B;
   p.C = (uint16_t*)C;
   p.flags = flags;
-  p.ticket = ticket;
-  p.err = err;
+  p.err = scratch;
+  p.ticket = scratch + 4;
+  p.push_done = scratch + 8;
+  p.tile_flags = scratch + 8 + cpr;
+  p.partial = (float*)partial;
   p.lda_local = lda_local;
   p.ld_ws = ld_ws;
   p.ldb = ldb;
@@ -217,9 +380,9 @@ TDIST_API int tdist_ag_gemm_consumer(const void* a_local, const void* ws, const 
   p.rows_per_chunk = rows_per_chunk;
   p.epoch = epoch;
   p.straddle = straddle;
-  const int M = M_per_rank * world;
-  const int total_mb = straddle ? (M + BM - 1) / BM : ((M_per_rank + BM - 1) / BM) * world;
-  const int total = total_mb * ((N_local + BN - 1) / BN);
+  p.push_wgs = world > 1 ? push_wgs : 0;
+  p.split_k = split_k;
+  const int total = p.push_wgs + tiles * split_k;
   int grid = num_ctas > 0 ? num_ctas : 256;
   if (grid > total) grid = total;
   static bool attr_set = false;
@@ -230,7 +393,8 @@ TDIST_API int tdist_ag_gemm_consumer(const void* a_local, const void* ws, const 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 16));
     attr_set = true;
   }
-  TDIST_HIP_TRY(hipMemsetAsync(ticket, 0, 16, (hipStream_t)stream));
+  // one memset, 16-byte granular, covers the ticket and every counter (the error word is sticky)
+  TDIST_HIP_TRY(hipMemsetAsync(scratch + 4, 0, (size_t)((need_ints - 4 + 3) & ~3ll) * sizeof(int), (hipStream_t)stream));
   if (dtype == 0)
     hipLaunchKernelGGL(ag_gemm_consumer_kernel<true>, dim3(grid), dim3(THREADS), LDS_BYTES + 16, (hipStream_t)stream, p);
   else

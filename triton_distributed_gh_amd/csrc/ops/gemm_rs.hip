@@ -18,6 +18,7 @@
 // (kernels/nvidia/gemm_reduce_scatter.py:121-250, reduce_scatter.py:600-697).  Here scatter
 // buffers and flags are double-buffered by call parity and flags carry the call's epoch, so no
 // cross-rank barrier is needed at all.
+#include "tdist/cache_policy.hpp"
 #include "tdist/common.hpp"
 #include "tdist/gemm_gfx950.hpp"
 #include "tdist/primitives.hpp"
@@ -179,20 +180,21 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_rs_kernel(GemmRsParams p) {
     uint16_t* cbase = dst_buf + ((long long)rank * p.M_per_rank + r_in) * p.N + pid_n * BN;
     const int nrem = p.N - pid_n * BN;
     const long long ldn = p.N;
+    // Tile stores are write-through (they leave this XCD's L2 at once, bound for a peer over xGMI
+    // or for the local reduction on another XCD), so publishing needs no release fence: drain,
+    // barrier, count.
     epilogue_256<IS_BF16>(acc, smem, [&](int r, int cc, const uint4& v) {
-      if (r < rows && cc < nrem) *(uint4*)(cbase + (long long)r * ldn + cc) = v;
+      if (r < rows && cc < nrem) st_wt128_sys(cbase + (long long)r * ldn + cc, v);
     });
     if (p.dbg && threadIdx.x == 0) p.dbg[blockIdx.x * 4 + 1] = 3;
-    // publish: every wave drains and writes back its stores, then one thread counts the tile
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    drain_stores();
     __syncthreads();
     if (threadIdx.x == 0) {
-      const int prev = atom_add_acqrel_agent(p.counters + d * cpr + c, 1);
+      // Every tile's stores completed before its own add; the add that completes the chunk is
+      // ordered after all earlier adds on the same word, so the flag follows all of the chunk's data.
+      const int prev = atom_add_relaxed_agent(p.counters + d * cpr + c, 1);
       if (prev == tiles_per_dc - 1) {
         int* flag = ((d == rank) ? p.flags : symm_at(p.ctx, p.flags, d)) + rank * cpr + c;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         store_relaxed_system(flag, p.epoch);
       }
     }

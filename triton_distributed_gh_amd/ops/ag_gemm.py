@@ -48,7 +48,7 @@ class AllGatherGEMMTensorParallelContext:
     workspaces: List[List[torch.Tensor]]        # [parity][rank] -> [max_M, K]
     flags: List[List[torch.Tensor]]             # [parity][rank] -> int32 [max chunks]
     epoch_table: Optional[torch.Tensor]
-    scratch: Optional[torch.Tensor]             # int32: [0:4] ticket, [4:8] error word, [8:] push counters
+    scratch: Optional[torch.Tensor]             # int32: [0] error word, [4] ticket, [8:] push / split-K counters
     env: Any = None
     ag_streams: Optional[List["torch.cuda.Stream"]] = None
     serial: bool = False
@@ -63,6 +63,7 @@ class AllGatherGEMMTensorParallelContext:
     num_ctas: int = 0                           # 0 = one workgroup per CU
     call_count: int = 0
     backend: str = "hip"
+    partial: Optional[torch.Tensor] = None      # split-K fp32 partial tiles (allocated on first use)
 
     # names the reference exposes on its context
     @property
@@ -74,7 +75,7 @@ class AllGatherGEMMTensorParallelContext:
         return self.flags[self.call_count & 1]
 
     def check_error(self) -> None:
-        if self.scratch is not None and int(self.scratch[4]) != 0:
+        if self.scratch is not None and int(self.scratch[0]) != 0:
             raise RuntimeError("ag_gemm: a device-side wait timed out (peer data never arrived)")
 
 
@@ -186,18 +187,20 @@ def ag_gemm_intra_node_op(a, b, c, ctx: AllGatherGEMMTensorParallelContext):
     lib = _lib.hip()
     cur = torch.cuda.current_stream()
     used = []
+    push_wgs = 0
     if w > 1:
-        if ctx.producer == "kernel":
-            side = ctx.ag_streams[0]
-            side.wait_stream(cur)
-            _push_kernel(ctx, a, parity, epoch, rpc, straddle, side)
-            used = [side]
+        if ctx.producer == "none":
+            pass    # the caller gathers (copy engines, another op) and raises the flags itself
+        elif ctx.producer == "kernel":
+            # producer work items ride in the consumer launch (see csrc/ops/ag_gemm.hip)
+            # one workgroup moves ~12-16 GB/s; 8 per outgoing xGMI link keeps every link saturated
+            push_wgs = tuning.get("ag_gemm.PUSH_WGS", 0) or max(8, min(32, 8 * (w - 1)))
         else:
             for s in ctx.ag_streams:
                 s.wait_stream(cur)
             _push_copy_engine(ctx, a, parity, epoch, rpc, straddle)
             used = ctx.ag_streams
-        if ctx.serial:
+        if ctx.serial and used:
             for s in used:
                 cur.wait_stream(s)
             torch.cuda.synchronize()
@@ -205,17 +208,46 @@ def ag_gemm_intra_node_op(a, b, c, ctx: AllGatherGEMMTensorParallelContext):
                 torch.distributed.barrier(group=env.cpu_group)
 
     ws = ctx.workspaces[parity][rank]
+    straddle = straddle and w > 1
+    tiles = _num_tiles(M_per_rank, w, N_local, straddle)
+    split_k = _pick_split_k(tiles, K, ctx.num_ctas or 256)
+    cpr = M_per_rank // rpc
+    need = (8 + cpr + (tiles if split_k > 1 else 0) + 3) & ~3
+    if ctx.scratch.numel() < need:
+        ctx.scratch = torch.zeros(need, dtype=torch.int32, device=env.device)
+    partial, partial_bytes = None, 0
+    if split_k > 1:
+        partial_bytes = tiles * split_k * _BM * _BM * 4
+        if ctx.partial is None or ctx.partial.numel() < partial_bytes:
+            ctx.partial = torch.empty(partial_bytes, dtype=torch.uint8, device=env.device)
+        partial = ctx.partial
     _lib.check(
-        lib.tdist_ag_gemm_consumer(_lib.ptr(a), _lib.ptr(ws), _lib.ptr(b), _lib.ptr(c), _lib.ptr(ctx.flags[parity][rank]),
-                                   _lib.ptr(ctx.scratch), _lib.ptr(ctx.scratch[4:]), ctypes.c_longlong(a.stride(0)),
+        lib.tdist_ag_gemm_consumer(ctypes.byref(env.heap.ctx_struct()), _lib.ptr(a), _lib.ptr(ws), _lib.ptr(b),
+                                   _lib.ptr(c), _lib.ptr(ctx.flags[parity][rank]), _lib.ptr(ctx.scratch),
+                                   ctypes.c_longlong(ctx.scratch.numel()),
+                                   _lib.ptr(partial) if partial is not None else ctypes.c_void_p(0),
+                                   ctypes.c_longlong(partial_bytes), ctypes.c_longlong(a.stride(0)),
                                    ctypes.c_longlong(ws.stride(0)), ctypes.c_longlong(b.stride(0)),
-                                   ctypes.c_longlong(c.stride(0)), M_per_rank, N_local, K, rank, w, rpc, epoch,
-                                   1 if (straddle and w > 1) else 0, ctx.num_ctas, _DT[a.dtype],
+                                   ctypes.c_longlong(c.stride(0)), M_per_rank, N_local, K, rpc, epoch,
+                                   1 if straddle else 0, push_wgs, split_k, ctx.num_ctas, _DT[a.dtype],
                                    _lib.stream_handle(cur)), "tdist_ag_gemm_consumer")
-    # `a` is read by the side streams; joining them keeps the caller free to reuse it in stream order
+    # `a` is read by the copy-engine streams; joining them keeps the caller free to reuse it in stream order
     for s in used:
         cur.wait_stream(s)
     return c
+
+
+def _num_tiles(M_per_rank: int, w: int, N_local: int, straddle: bool) -> int:
+    mb = -(-(M_per_rank * w) // _BM) if straddle else -(-M_per_rank // _BM) * w
+    return mb * -(-N_local // _BM)
+
+
+def _pick_split_k(tiles: int, K: int, grid: int) -> int:
+    """Cut K when there are fewer tiles than workgroups (large TP degree): up to 4 ranges, each at
+    least 512 deep.  ``ag_gemm.SPLIT_K`` (tuning knob / TDIST_AG_SPLIT_K) overrides."""
+    forced = int(os.environ.get("TDIST_AG_SPLIT_K", "0")) or tuning.get("ag_gemm.SPLIT_K", 0)
+    s = forced if forced else max(1, min(4, grid // max(tiles, 1), K // 512))
+    return max(1, min(s, 4, K // 128))
 
 
 def _all_gather_host(a, ctx, parity, epoch, rpc):

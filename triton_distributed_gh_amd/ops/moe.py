@@ -202,12 +202,12 @@ def ag_group_gemm(a: torch.Tensor, b: torch.Tensor, ctx: MoEAllGatherGroupGEMMTe
     ag.call_count += 1
     rpc = _rows_per_chunk(M_per_rank, ag.M_PER_CHUNK)
     cur = torch.cuda.current_stream()
-    used = []
     if w > 1:
-        side = ag.ag_streams[0]
-        side.wait_stream(cur)
-        _push_kernel(ag, a, parity, epoch, rpc, True, side)      # own shard goes into the workspace too
-        used = [side]
+        # The push runs on the SAME stream, ahead of the grouped GEMM: the GEMM's workgroups fill
+        # every CU's register file, so a push kernel on another stream that reached the GPU after
+        # them could never start while they spin on the peers' flags.  Own push first, then compute
+        # while the peers' shards are still arriving.  (own shard goes into the workspace too)
+        _push_kernel(ag, a, parity, epoch, rpc, True, cur)
         A, flags = ag.workspaces[parity][rank], ag.flags[parity][rank]
     else:
         A, flags = a, None
@@ -215,13 +215,11 @@ def ag_group_gemm(a: torch.Tensor, b: torch.Tensor, ctx: MoEAllGatherGroupGEMMTe
         _lib.hip().tdist_moe_group_gemm(_lib.ptr(A), _lib.ptr(b), _lib.ptr(out), _lib.ptr(idx.sorted_ids),
                                         _lib.ptr(idx.expert_of_block), _lib.ptr(idx.seg_range) if w > 1 else None,
                                         _lib.ptr(idx.order) if w > 1 else None, _lib.ptr(idx.meta), None,
-                                        _lib.ptr(flags), _lib.ptr(ag.scratch), _lib.ptr(ag.scratch[4:]),
+                                        _lib.ptr(flags), _lib.ptr(ag.scratch[4:]), _lib.ptr(ag.scratch),
                                         ctypes.c_longlong(A.stride(0)), ctypes.c_longlong(b.stride(1)),
                                         ctypes.c_longlong(out.stride(0)), ctypes.c_longlong(b.stride(0)), N, K, topk, 0,
                                         M_per_rank // rpc, epoch, ctx.num_ctas, _DT[a.dtype], _lib.stream_handle(cur)),
         "tdist_moe_group_gemm")
-    for s in used:
-        cur.wait_stream(s)
     return out
 
 

@@ -5,7 +5,7 @@ Reference: kernels/nvidia/sp_ag_attention_intra_node.py - ``create_sp_ag_attenti
 K and V (contiguous or zig-zag: rank r owns half-blocks r and 2w-1-r of each sequence); K/V are
 gathered into symmetric buffers in global order and a varlen causal flash attention runs over them.
 
-MI355X design: the gather is a push kernel on a side stream that raises one arrival flag per
+MI355X design: the gather is a push kernel (same stream, ahead of the attention) that raises one arrival flag per
 source rank on every peer; the attention kernel waits on a source's flag only when it first
 reaches that rank's slab, so attention over early slabs overlaps the rest of the gather (the
 reference joins the copy stream before launching attention).  Buffers and flags are double
@@ -122,9 +122,12 @@ def fused_sp_ag_attn_intra_node(ctx: SPAllGatherAttentionContextIntraNode, q_sha
     epoch = ctx.call_count % EPOCH_MOD + 1
     ctx.call_count += 1
     kf, vf, fl = ctx.ag_k_buffers[parity], ctx.ag_v_buffers[parity], ctx.flags[parity]
+    # The KV push runs on the SAME stream, ahead of the attention kernel: attention workgroups that
+    # spin on a peer's arrival flag keep their CU slots, so a push kernel on another stream could be
+    # locked out by them on every rank at once.  Own push first, then attention over the local KV
+    # while the peers' slabs are still arriving.
     cur = torch.cuda.current_stream()
-    side = ctx.ag_stream
-    side.wait_stream(cur)
+    side = cur
     cstruct = ctx.env.heap.ctx_struct()
     _lib.check(
         _lib.hip().tdist_sp_kv_push(ctypes.byref(cstruct), _lib.ptr(k_shard), _lib.ptr(v_shard), _lib.ptr(kf),
@@ -134,7 +137,6 @@ def fused_sp_ag_attn_intra_node(ctx: SPAllGatherAttentionContextIntraNode, q_sha
     flash_attn_varlen_fwd(q_shard, kf, vf, cu_q, cu_k, max_seqlen_q, out=output, softmax_scale=softmax_scale,
                           causal=is_causal, pos_mode=2 if enable_zig_zag else 1, rank=rank, world_size=w, flags=fl,
                           epoch=epoch, err=ctx.scratch[4:])
-    cur.wait_stream(side)
     return output
 
 
