@@ -119,3 +119,10 @@ def test_shmem_put_get_signal(w):
             assert backs[r].view(w, n)[:, 0].tolist() == [100 + r] * w                  # our slot read back from every peer
     finally:
         vc.close()
+
+
+@pytest.mark.parametrize("blocks", [8, 256, 1024])
+def test_grid_barrier(blocks):
+    from triton_distributed_gh_amd.ops.common_ops import barrier_on_this_grid_smoke
+    stale, timeouts = barrier_on_this_grid_smoke(blocks, rounds=16)
+    assert (stale, timeouts) == (0, 0)

@@ -17,6 +17,7 @@
 // double-buffered context (:73-91).  xGMI has no in-fabric reduction, hence owner-reduces-then-
 // broadcasts; the low-latency entry point is the same kernel because every context is already
 // double-buffered.
+#include "tdist/cache_policy.hpp"
 #include "tdist/common.hpp"
 #include "tdist/gemm_gfx950.hpp"
 #include "tdist/primitives.hpp"
@@ -91,11 +92,11 @@ __device__ __forceinline__ void reduce_tile(const GemmArParams& p, int t, int ti
     for (int i = 0; i < w; ++i) {
       const int peer = (rank + i) % w;
       uint16_t* dst = (i == 0) ? p.out : symm_at(p.ctx, p.out, peer);
-      *(uint4*)(dst + off) = o;
+      st_wt128_sys(dst + off, o);
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // write-through stores: drain + barrier publish them, no release fence
+  drain_stores();
   __syncthreads();
   if ((int)threadIdx.x < w) {
     int* f2 = ((int)threadIdx.x == rank ? p.flags : symm_at(p.ctx, p.flags, (int)threadIdx.x)) + tiles_per_owner * w + t;
@@ -139,10 +140,9 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_ar_kernel(GemmArParams p) {
     uint16_t* slot_base = (owner == rank) ? p.slots : symm_at(p.ctx, p.slots, owner);
     uint16_t* dst = slot_base + ((long long)rank * tiles_per_owner + local) * TILE_ELEMS;
     epilogue_256<IS_BF16>(acc, smem, [&](int r, int c, const uint4& v) {
-      if (r < rows) *(uint4*)(dst + r * BN + c) = v;
+      if (r < rows) st_wt128_sys(dst + r * BN + c, v);
     });
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    drain_stores();
     __syncthreads();
     if (threadIdx.x == 0) {
       int* f1 = ((owner == rank) ? p.flags : symm_at(p.ctx, p.flags, owner)) + local * w + rank;

@@ -13,6 +13,7 @@
 // (topk reduce + reduce-scatter), kernels/nvidia/threadblock_swizzle_ag_moe.cu (tile order by
 // arrival stage: here tiles are simply SORTED by the last source rank they need, in arrival
 // order, on the device side of `moe_align`).
+#include "tdist/cache_policy.hpp"
 #include "tdist/common.hpp"
 #include "tdist/gemm_gfx950.hpp"
 #include "tdist/primitives.hpp"
@@ -243,16 +244,15 @@ __global__ __launch_bounds__(256) void moe_topk_reduce_rs_kernel(TopkRsParams p)
           o.y = Frag<true>::pack2(acc[2], acc[3]);
           o.z = Frag<true>::pack2(acc[4], acc[5]);
           o.w = Frag<true>::pack2(acc[6], acc[7]);
-          *(uint4*)(dst + c) = o;
+          st_wt128_sys(dst + c, o);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // write-through stores: drain + barrier publish them, no release fence; the add that
+        // completes an owner's rows is ordered after every earlier add on that word
+        drain_stores();
         __syncthreads();
         if (threadIdx.x == 0) {
-          const int prev = atom_add_acqrel_agent(p.counters + d, 1);
+          const int prev = atom_add_relaxed_agent(p.counters + d, 1);
           if (prev == p.tpr - 1) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             store_relaxed_system(((d == rank) ? p.flags : symm_at(p.ctx, p.flags, d)) + rank, p.epoch);
           }
         }

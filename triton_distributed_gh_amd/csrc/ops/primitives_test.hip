@@ -5,6 +5,7 @@
 // (reference: python/triton_dist/test/amd/test_distributed-notify-wait.py:39-212 ring queue,
 //  test_wait_and_notify.py, test_barrier_all.py, test_libdevice.py, test_rocshmem_api.py).
 #include "tdist/common.hpp"
+#include "tdist/grid_barrier.hpp"
 #include "tdist/primitives.hpp"
 #include "tdist/shmem_device.hpp"
 
@@ -91,6 +92,33 @@ __global__ void atomics_kernel(int* word, int* out) {
     store_relaxed_workgroup(word, 20);
     out[5] = load_acquire_workgroup(word);
   }
+}
+
+// Grid barrier check: in round r every workgroup publishes r+1 in its own word, crosses the
+// barrier, and must then read r+1 from EVERY workgroup's word; a second barrier keeps round r+1's
+// stores behind round r's reads.  bad[0] counts stale reads, bad[1] timeouts.
+__global__ void grid_barrier_kernel(unsigned* state, int* words, int rounds, int* bad) {
+  for (int r = 0; r < rounds; ++r) {
+    if (threadIdx.x == 0) words[blockIdx.x] = r + 1;
+    if (!barrier_on_this_grid(state)) {
+      if (threadIdx.x == 0) atomicAdd(bad + 1, 1);
+      return;
+    }
+    int stale = 0;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) stale += words[b] != r + 1;
+    if (stale) atomicAdd(bad, stale);
+    if (!barrier_on_this_grid(state)) {
+      if (threadIdx.x == 0) atomicAdd(bad + 1, 1);
+      return;
+    }
+  }
+}
+
+TDIST_API int tdist_test_grid_barrier(unsigned* state, int* words, int rounds, int* bad, int grid, void* stream) {
+  TDIST_REQUIRE(grid >= 1 && grid <= 2048, "grid must fit the chip (all workgroups resident)");
+  hipLaunchKernelGGL(grid_barrier_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, state, words, rounds, bad);
+  TDIST_HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 TDIST_API int tdist_test_wait_flag(const int* flag, int value, int scope, long long* status, void* stream) {

@@ -96,3 +96,21 @@ def memcpy_async(dst: torch.Tensor | int, src: torch.Tensor | int, nbytes: int, 
     s = src if isinstance(src, int) else src.data_ptr()
     _lib.check(_lib.hip().tdist_memcpy_async(ctypes.c_void_p(d), ctypes.c_void_p(s), ctypes.c_size_t(nbytes),
                                              1 if use_copy_engine else 0, _lib.stream_handle(stream)), "memcpy_async")
+
+
+def barrier_on_this_grid_smoke(num_blocks: int = 256, rounds: int = 8, stream=None):
+    """Runs the device-side grid barrier (csrc/include/tdist/grid_barrier.hpp - the counterpart of
+    the reference's ``barrier_on_this_grid`` device function, kernels/nvidia/common_ops.py:56-130)
+    ``2 * rounds`` times over ``num_blocks`` resident workgroups.  Returns (stale_reads, timeouts)."""
+    import ctypes
+
+    from .. import _lib
+    dev = torch.device("cuda", torch.cuda.current_device())
+    state = torch.zeros(4, dtype=torch.int32, device=dev)
+    words = torch.zeros(num_blocks, dtype=torch.int32, device=dev)
+    bad = torch.zeros(2, dtype=torch.int32, device=dev)
+    s = stream or torch.cuda.current_stream()
+    _lib.check(_lib.hip().tdist_test_grid_barrier(_lib.ptr(state), _lib.ptr(words), rounds, _lib.ptr(bad), num_blocks,
+                                                  _lib.stream_handle(s)), "tdist_test_grid_barrier")
+    s.synchronize()
+    return int(bad[0]), int(bad[1])
