@@ -54,36 +54,56 @@ __device__ __forceinline__ uint16_t to16(float f) {
   }
 }
 
-// merge `n` partial rows (stride `stride` floats, LSE at column D) for one head; thread t owns
-// columns t, t + nthreads, ...  Returns through out pointers.  lens (optional) skips empty items.
+// Merge `n` partial rows (stride `stride` floats, LSE at column D) of one head, cooperatively by a
+// group of `nthreads` (16 or 64) consecutive lanes of one wave, `tid` = lane inside the group.
+// The LSE maximum and the denominator are computed with the splits spread over the lanes and
+// folded by cross-lane shuffles; the weighted sum keeps four columns per lane in flight per split
+// so the loads of one pass overlap instead of queueing behind each other.  `lens` (optional)
+// skips empty items, whose rows may never have been written.
 template <bool IS_BF16>
 __device__ __forceinline__ void merge_rows(const float* part, long long stride, int n, int D, const int* lens,
                                            int lens_stride, void* out, int out_mode, int tid, int nthreads) {
   float mx = -INFINITY;
-  for (int s = 0; s < n; ++s) {
+  for (int s = tid; s < n; s += nthreads) {
     if (lens && lens[(long long)s * lens_stride] <= 0) continue;
     mx = fmaxf(mx, part[s * stride + D]);
   }
+  for (int off = nthreads >> 1; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
   float den = 0.f;
-  for (int s = 0; s < n; ++s) {
+  for (int s = tid; s < n; s += nthreads) {
     if (lens && lens[(long long)s * lens_stride] <= 0) continue;
     const float l = part[s * stride + D];
     den += (l == -INFINITY) ? 0.f : __expf(l - mx);
   }
+  for (int off = nthreads >> 1; off > 0; off >>= 1) den += __shfl_xor(den, off);
   const float inv = den > 0.f ? 1.f / den : 0.f;
-  for (int c = tid; c < D; c += nthreads) {
-    float acc = 0.f;
+  for (int c0 = tid; c0 < D; c0 += 4 * nthreads) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
     for (int s = 0; s < n; ++s) {
-      if (lens && lens[(long long)s * lens_stride] <= 0) continue;
-      const float l = part[s * stride + D];
-      if (l == -INFINITY) continue;
-      acc += __expf(l - mx) * part[s * stride + c];
+      const bool skip = lens && lens[(long long)s * lens_stride] <= 0;
+      const float* row = part + s * stride;
+      const float l = skip ? -INFINITY : row[D];
+      const float wgt = (l == -INFINITY) ? 0.f : __expf(l - mx);
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = c0 + k * nthreads;
+        v[k] = (c < D && wgt != 0.f) ? row[c] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] += wgt * v[k];
     }
-    acc *= inv;
-    if (out_mode == 2) {
-      ((float*)out)[c] = acc;
-    } else {
-      ((uint16_t*)out)[c] = to16<IS_BF16>(acc);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + k * nthreads;
+      if (c >= D) continue;
+      const float r = acc[k] * inv;
+      if (out_mode == 2) {
+        ((float*)out)[c] = r;
+      } else {
+        ((uint16_t*)out)[c] = to16<IS_BF16>(r);
+      }
     }
   }
   if (out_mode == 2 && tid == 0) ((float*)out)[D] = den > 0.f ? mx + __logf(den) : -INFINITY;
@@ -248,8 +268,17 @@ __device__ __forceinline__ void decode_split_body(const DecodeArgs& a, const int
       o += s_acc[(w * 16 + h) * D + c] * f;
     }
     float* dst = prow + (long long)(h0 + h) * a.p_stride_h;
-    dst[c] = L > 0.f ? o / L : 0.f;
-    if (c == 0) dst[D] = L > 0.f ? (M + __log2f(L)) * 0.6931471805599453f : -INFINITY;
+    const float val = L > 0.f ? o / L : 0.f;
+    const float lse = L > 0.f ? (M + __log2f(L)) * 0.6931471805599453f : -INFINITY;
+    if (a.fused) {
+      // read by another workgroup of this launch: write-through stores (they leave this XCD's L2
+      // at once), so the hand-off needs no release fence, only a drain before the ticket
+      __hip_atomic_store(dst + c, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (c == 0) __hip_atomic_store(dst + D, lse, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      dst[c] = val;
+      if (c == 0) dst[D] = lse;
+    }
   }
 }
 

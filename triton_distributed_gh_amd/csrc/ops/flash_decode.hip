@@ -30,7 +30,6 @@ __global__ __launch_bounds__(256) void decode_split_kernel(DecodeArgs a) {
   extern __shared__ char smem[];
   __shared__ int s_last;
   const int b = blockIdx.x;
-  const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int group = a.q_heads / a.kv_heads;
   const int hblocks = (group + 15) / 16;
@@ -41,22 +40,33 @@ __global__ __launch_bounds__(256) void decode_split_kernel(DecodeArgs a) {
   decode_split_body<IS_BF16, D>(a, b, (int)blockIdx.y, (int)blockIdx.z, smem);
 
   if (!a.fused) return;
-  // ---- last workgroup of this (batch, head block) merges the splits
-  __threadfence();
+  // ---- last workgroup of this (batch, head block) merges the splits.  The partial rows were
+  // stored write-through: every wave drains its stores, the workgroup barriers, one lane takes a
+  // ticket; the workgroup that draws the last ticket drops its stale L1 lines with ONE acquire
+  // and reads the rows with plain loads.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     int* t = a.tickets + b * gridDim.y + blockIdx.y;
-    const int prev = atomicAdd(t, 1);
+    const int prev = __hip_atomic_fetch_add(t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = prev == a.splits - 1;
-    if (s_last) *t = 0;
+    if (s_last) __hip_atomic_store(t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
   }
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
-  for (int h = wave; h < valid_h; h += 4) {
-    const float* part = a.partial + b * a.p_stride_b + (long long)(h0 + h) * a.p_stride_h;
-    char* o = (char*)a.out + (b * a.o_stride_b + (long long)(h0 + h) * a.o_stride_h) * (a.fused == 2 ? 4 : 2);
-    merge_rows<IS_BF16>(part, a.p_stride_s, a.splits, D, nullptr, 0, o, a.fused, lane, 64);
+  if (wave == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  // 16 threads per head, all heads of the block at once
+  {
+    const int h = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    if (h < valid_h) {
+      const float* part = a.partial + b * a.p_stride_b + (long long)(h0 + h) * a.p_stride_h;
+      char* o = (char*)a.out + (b * a.o_stride_b + (long long)(h0 + h) * a.o_stride_h) * (a.fused == 2 ? 4 : 2);
+      merge_rows<IS_BF16>(part, a.p_stride_s, a.splits, D, nullptr, 0, o, a.fused, sub, 16);
+    }
   }
 }
 

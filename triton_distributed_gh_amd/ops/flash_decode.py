@@ -150,7 +150,11 @@ def gqa_fwd_batch_decode_intra_rank(q, k_cache, v_cache, workspace, q_lens, kv_l
     part = _partial(q, splits, output_split)
     out = output_combine if (output_combine is not None and output_combine.dtype == torch.float32) else \
         torch.empty((batch, q_heads, D + 1), dtype=torch.float32, device=q.device)
-    _launch(q, k_cache, v_cache, kv_lens, block_table, scale, soft_cap, splits, 2, part, out)
+    # two launches: at small batch the split workgroups are so short that the in-kernel hand-off
+    # of the fused form (drain + ticket per workgroup) costs more than the kernel boundary it
+    # saves (batch 1, 32k tokens: 40 us vs 65 us on MI355X)
+    _launch(q, k_cache, v_cache, kv_lens, block_table, scale, soft_cap, splits, 0, part, None)
+    _combine(part, (D + 1, q_heads * splits * (D + 1), splits * (D + 1)), splits, batch, q_heads, D, None, out, 2, _dt(q))
     return out
 
 
