@@ -1,41 +1,63 @@
-"""GPU probe: multi-process symmetric heap on ONE device (hipIpc), copy engine, stream values."""
-import ctypes, os, sys, time, torch
-sys.path.insert(0, "/root/repo")
-import torch.distributed as dist
-from triton_distributed_gh_amd.utils import initialize_distributed, finalize_distributed
-from triton_distributed_gh_amd import _lib
+"""Minimal two-process hipIpc probe (run through scripts/dev/mp_debug.sh): which allocation kinds
+and sizes can be exported / opened between two processes on this machine, and how long it takes."""
+import ctypes
+import os
+import sys
+import time
 
-env = initialize_distributed(heap_bytes=1 << 28)
-r, w = env.rank, env.world_size
-print(f"rank {r}/{w} dev {env.device} shared_gpu {env.shared_gpu} rccl {env.has_rccl}", flush=True)
-heap = env.heap
-ts = heap.create_tensor_list([w, 1024], torch.float32)
-sig = heap.create_tensor_list([64], torch.int32, arena="sig")
-dist.barrier(group=env.cpu_group)
-# 1. plain peer store through torch
-for p in range(w):
-    ts[p][r].fill_(float(r + 1))
-torch.cuda.synchronize(); dist.barrier(group=env.cpu_group)
-ok = all(float(ts[r][s][0]) == s + 1 for s in range(w))
-print(f"rank {r} peer stores visible: {ok}", flush=True)
-# 2. copy engine
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch  # noqa: E402
+
+from triton_distributed_gh_amd import _lib  # noqa: E402
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+tag = os.environ.get("MASTER_PORT", "0")
+ndev = torch.cuda.device_count()
+torch.cuda.set_device(rank % ndev)
 lib = _lib.hip()
-src = torch.full((1024,), 100.0 + r, device="cuda")
-st = torch.cuda.Stream()
-for p in range(w):
-    dst_ptr = heap.peer_ptr(ts[r], p) + r * 1024 * 4
-    _lib.check(lib.tdist_memcpy_async(ctypes.c_void_p(dst_ptr), _lib.ptr(src), ctypes.c_size_t(4096), 1, _lib.stream_handle(st)), "memcpy nocu")
-    _lib.check(lib.tdist_stream_write_value32(_lib.stream_handle(st), ctypes.c_void_p(heap.peer_ptr(sig[r], p) + 4 * r), 7), "write value")
-st.synchronize(); dist.barrier(group=env.cpu_group)
-ok = all(float(ts[r][s][5]) == 100.0 + s for s in range(w)) and all(int(sig[r][s]) == 7 for s in range(w))
-print(f"rank {r} copy-engine + write_value visible: {ok}  sig={sig[r][:w].tolist()}", flush=True)
-# 3. wait value on stream: peer sets, we wait
-_lib.check(lib.tdist_stream_wait_value32(_lib.stream_handle(st), _lib.ptr(sig[r][32:]), 5, 0), "wait value")
-time.sleep(0.2 * r)
-nxt = (r + 1) % w
-_lib.check(lib.tdist_stream_write_value32(_lib.stream_handle(), ctypes.c_void_p(heap.peer_ptr(sig[r], nxt) + 4 * 32), 5), "write value2")
-st.synchronize()
-print(f"rank {r} stream wait_value released", flush=True)
-dist.barrier(group=env.cpu_group)
-finalize_distributed()
-print(f"rank {r} done", flush=True)
+hsz = lib.tdist_ipc_handle_size()
+
+
+def log(*a):
+    print(f"[rank {rank} t={time.time() % 1000:8.3f}]", *a, flush=True)
+
+
+def exchange(name, payload: bytes) -> bytes:
+    path = f"/tmp/ipc_{tag}_{name}_{rank}"
+    with open(path + ".tmp", "wb") as f:
+        f.write(payload)
+    os.rename(path + ".tmp", path)
+    peer = f"/tmp/ipc_{tag}_{name}_{(rank + 1) % world}"
+    while not os.path.exists(peer):
+        time.sleep(0.01)
+    return open(peer, "rb").read()
+
+
+log(f"devices={ndev} HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}")
+cases = [("hipMalloc 1MiB", 1 << 20, 0), ("finegrained 1MiB", 1 << 20, 1), ("hipMalloc 256MiB", 1 << 28, 0),
+         ("hipMalloc 2GiB", 1 << 31, 0)]
+if os.environ.get("IPC_SIZES"):
+    cases = [(f"hipMalloc {int(x, 0)} B", int(x, 0), 0) for x in os.environ["IPC_SIZES"].split(",")]
+only = os.environ.get("IPC_CASE")
+for i, (name, nbytes, mode) in enumerate(cases):
+    if only is not None and str(i) != only:
+        continue
+    p = ctypes.c_void_p()
+    _lib.check(lib.tdist_malloc(ctypes.byref(p), ctypes.c_size_t(nbytes), mode), "malloc")
+    h = ctypes.create_string_buffer(hsz)
+    t0 = time.time()
+    _lib.check(lib.tdist_ipc_get_handle(p, h), "get_handle")
+    log(f"{name}: exported in {time.time() - t0:.3f}s")
+    peer_h = exchange(f"h{i}", bytes(h.raw))
+    if os.environ.get("IPC_SERIAL") == "1" and rank == 1:
+        exchange(f"turn{i}", b"x")            # rank 1 opens only after rank 0 is done
+    q = ctypes.c_void_p()
+    t0 = time.time()
+    log(f"{name}: opening peer handle ...")
+    rc = lib.tdist_ipc_open_handle(peer_h, ctypes.byref(q))
+    log(f"{name}: open rc={rc} ptr={q.value} in {time.time() - t0:.3f}s")
+    if os.environ.get("IPC_SERIAL") == "1" and rank == 0:
+        exchange(f"turn{i}", b"x")
+    exchange(f"done{i}", b"x")
+log("all cases done")

@@ -28,6 +28,10 @@ from .. import _lib
 MAX_RANKS = 16
 
 
+# largest allocation that can be shared through hipIpc (see SymmetricHeap.__init__)
+MAX_IPC_BYTES = (1 << 31) - (1 << 21)
+
+
 class SymmCtxStruct(ctypes.Structure):
     """Mirror of ``tdist::SymmCtx`` (csrc/include/tdist/common.hpp); passed to kernels by value."""
 
@@ -126,8 +130,12 @@ class SymmetricHeap:
     ):
         assert world_size <= MAX_RANKS, f"at most {MAX_RANKS} ranks per node"
         self.rank, self.world_size, self.group, self.backend = rank, world_size, group, backend
-        default_heap = (1 << 31) if backend == "hip" else (1 << 26)
+        default_heap = MAX_IPC_BYTES if backend == "hip" else (1 << 26)
         self.heap_bytes = int(heap_bytes or os.environ.get("TDIST_SYMM_HEAP_BYTES", default_heap))
+        if backend == "hip" and world_size > 1 and self.heap_bytes > MAX_IPC_BYTES:
+            # hipIpcOpenMemHandle never returns for an allocation of 2 GiB or more on this stack
+            # (measured: 2^31 - 4 KiB opens in < 1 ms, 2^31 and 3 GiB hang), so one arena stays below
+            self.heap_bytes = MAX_IPC_BYTES
         self.sig_bytes = int(sig_bytes or os.environ.get("TDIST_SYMM_SIG_BYTES", 1 << 22))
         self._alloc = {"data": _FreeList(self.heap_bytes), "sig": _FreeList(self.sig_bytes)}
         self._bases = {"data": [0] * world_size, "sig": [0] * world_size}
