@@ -67,12 +67,7 @@ def rocshmem_ptr(ptr_or_tensor, pe: int) -> int:
     heap = get_env().heap
     if isinstance(ptr_or_tensor, torch.Tensor):
         return heap.peer_ptr(ptr_or_tensor, pe)
-    for arena in ("data", "sig"):
-        base = heap.base(arena, heap.rank)
-        size = heap.heap_bytes if arena == "data" else heap.sig_bytes
-        if base <= ptr_or_tensor < base + size:
-            return heap.base(arena, pe) + (ptr_or_tensor - base)
-    raise ValueError("pointer is not inside the symmetric heap")
+    return heap.translate(int(ptr_or_tensor), pe)
 
 
 class SymmHeap:

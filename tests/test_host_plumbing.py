@@ -140,6 +140,13 @@ out = gemm_rs_intra_node(a2, b2, ctx2)
 full = a2 @ b2.t()
 dist.all_reduce(full, group=env.cpu_group)
 assert torch.allclose(out, full[r * (M // w):(r + 1) * (M // w)], atol=1e-4)
+# heap growth across processes: 4 MiB segments, three 3 MiB tensors -> two extra segments
+big = [env.heap.create_tensor([3 << 20], torch.uint8) for _ in range(3)]
+assert [env.heap.info(t).arena for t in big][1:] == ["data1", "data2"] or env.heap.info(big[0]).arena != "data"
+big[2].fill_(10 + r)
+dist.barrier(group=env.cpu_group)
+assert int(env.heap.peer_view(big[2], (r + 1) %% w)[123]) == 10 + (r + 1) %% w
+dist.barrier(group=env.cpu_group)
 finalize_distributed()
 print("WORKER_OK", r)
 """
@@ -175,3 +182,23 @@ def test_cpp_moe_align_oracle_matches_python_reference(ntokens, E, topk, w, rank
     assert torch.equal(got.expert_of_block[:nb], ref.expert_of_block[:nb])
     assert torch.equal(got.seg_range[:nb], ref.seg_range[:nb])
     assert torch.equal(got.order[:nb], ref.order[:nb])
+
+
+def test_symmetric_heap_grows_by_segments():
+    """A heap of 1 MiB segments: the third 600 KiB tensor does not fit segments 0 / 1 and lands in a
+    new one; peer views, pointer translation and the device context follow it."""
+    vc = VirtualCluster(2, heap_bytes=1 << 20, backend="host")
+    try:
+        ts = [vc.collective(lambda r, env: env.heap.create_tensor([600 * 1024], torch.uint8)) for _ in range(3)]
+        heaps = [e.heap for e in vc.envs]
+        assert [heaps[0].info(t[0]).arena for t in ts] == ["data", "data1", "data2"]
+        for r in range(2):
+            ts[2][r].fill_(r + 7)
+        assert int(heaps[0].peer_view(ts[2][0], 1)[5]) == 8 and int(heaps[1].peer_view(ts[2][1], 0)[5]) == 7
+        c = heaps[0].ctx_struct()
+        assert c.num_extra == 2 and c.extra_base[1][1] == heaps[0].peer_ptr(ts[2][0], 1)
+        assert heaps[0].translate(ts[1][0].data_ptr() + 16, 1) == heaps[0].peer_ptr(ts[1][0], 1) + 16
+        with pytest.raises(MemoryError):
+            vc.collective(lambda r, env: env.heap.create_tensor([2 << 20], torch.uint8))     # larger than a segment
+    finally:
+        vc.close()

@@ -115,3 +115,35 @@ def test_ag_gemm_split_k_single_rank(split, monkeypatch):
             assert rel < 1e-2, rel
     finally:
         vc.close()
+
+
+def test_fused_ops_on_a_grown_heap():
+    """3 MiB segments: the GEMM-RS scatter buffers do not fit segment 0 next to the AG workspaces, so
+    the kernels translate pointers that live in growth segments."""
+    w, M, N, K = 2, 1024, 1024, 512
+    vc = VirtualCluster(w, heap_bytes=3 << 20)
+    try:
+        ag = vc.collective(lambda r, env: create_ag_gemm_intra_node_context(M, N // w, K, torch.bfloat16, torch.bfloat16,
+                                                                            r, w, num_ctas=_ctas(w), env=env))
+        rs = vc.collective(lambda r, env: create_gemm_rs_intra_node_context(M, N, torch.bfloat16, r, w,
+                                                                            num_ctas=_ctas(w), env=env))
+        assert vc.envs[0].heap.ctx_struct().num_extra >= 1
+        for it in range(3):
+            a = [(torch.rand(M // w, K, device="cuda") - 0.5).bfloat16() for _ in range(w)]
+            b = [(torch.rand(N // w, K, device="cuda") - 0.5).bfloat16() for _ in range(w)]
+            a2 = [(torch.rand(M, K // w, device="cuda") - 0.5).bfloat16() for _ in range(w)]
+            b2 = [(torch.rand(N, K // w, device="cuda") - 0.5).bfloat16() for _ in range(w)]
+            torch.cuda.synchronize()
+            o1 = vc.run(lambda r, env: ag_gemm_intra_node(a[r], b[r], False, ag[r]))
+            o2 = vc.run(lambda r, env: gemm_rs_intra_node(a2[r], b2[r], rs[r]))
+            a_full = torch.cat(a).float()
+            part = sum((a2[r].float() @ b2[r].float().t()).bfloat16().float() for r in range(w))
+            for r in range(w):
+                ag[r].check_error()
+                rs[r].check_error()
+                ref = a_full @ b[r].float().t()
+                assert (o1[r].float() - ref).abs().max().item() / ref.abs().max().item() < 1e-2
+                ref2 = part[r * (M // w):(r + 1) * (M // w)]
+                assert (o2[r].float() - ref2).abs().max().item() / ref2.abs().max().item() < 1e-2
+    finally:
+        vc.close()

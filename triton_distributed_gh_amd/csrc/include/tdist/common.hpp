@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #define TDIST_MAX_RANKS 16
+#define TDIST_MAX_EXTRA_SEGMENTS 7
 #define TDIST_WAVE 64
 
 #define TDIST_API extern "C" __attribute__((visibility("default")))
@@ -41,6 +42,11 @@ struct SymmCtx {
   uint64_t sig_base[TDIST_MAX_RANKS];
   uint64_t heap_bytes;
   uint64_t sig_bytes;
+  // Growth segments of the data arena (each heap_bytes long): one hipIpc mapping cannot reach
+  // 2 GiB, so a larger heap is a list of equal segments added on demand.
+  int num_extra;
+  int pad_;
+  uint64_t extra_base[TDIST_MAX_EXTRA_SEGMENTS][TDIST_MAX_RANKS];
 };
 
 // Spin budget: every device-side wait gives up after this many 100 MHz ticks

@@ -26,7 +26,7 @@ enum MemSemantic : int { SEM_RELAXED = 0, SEM_ACQUIRE = 1 };
 __device__ __forceinline__ int rank(const SymmCtx& ctx) { return ctx.rank; }
 __device__ __forceinline__ int num_ranks(const SymmCtx& ctx) { return ctx.num_ranks; }
 
-// Translate a pointer into this rank's symmetric arena (data or signal arena) to the
+// Translate a pointer into this rank's symmetric arena (data segment or signal arena) to the
 // same object inside `peer`'s arena.  Pointers outside both arenas are returned unchanged
 // when peer == rank and are otherwise invalid.
 template <typename T>
@@ -36,6 +36,10 @@ __device__ __forceinline__ T* symm_at(const SymmCtx& ctx, T* ptr, int peer) {
   if (p - hb < ctx.heap_bytes) return reinterpret_cast<T*>(ctx.heap_base[peer] + (p - hb));
   const uint64_t sb = ctx.sig_base[ctx.rank];
   if (p - sb < ctx.sig_bytes) return reinterpret_cast<T*>(ctx.sig_base[peer] + (p - sb));
+  for (int k = 0; k < ctx.num_extra; ++k) {
+    const uint64_t eb = ctx.extra_base[k][ctx.rank];
+    if (p - eb < ctx.heap_bytes) return reinterpret_cast<T*>(ctx.extra_base[k][peer] + (p - eb));
+  }
   return ptr;
 }
 

@@ -7,6 +7,12 @@ arena and ONE small signal arena at start-up, the handles are exchanged once ove
 ``torch.distributed`` and symmetric tensors are carved at identical offsets on every rank.
 ``symm_at(ptr, peer)`` on the device is then a base-pointer translation.
 
+One hipIpc mapping cannot reach 2 GiB on this stack (``MAX_IPC_BYTES``), so the data arena GROWS
+in equal segments of at most that size, on demand and collectively: when a symmetric tensor does
+not fit the segments that exist, every rank allocates one more, the handles are exchanged, and the
+tensor is carved from it.  A tensor lives inside ONE segment (so it must be smaller than a
+segment); the device-side translation checks the segments in turn.
+
 Two backends share this file:
 * ``hip``  - ``hipMalloc`` / ``hipExtMallocWithFlags`` + ``hipIpcGet/OpenMemHandle``;
 * ``host`` - POSIX shared memory (``/dev/shm``) so the full stack runs on a CPU-only machine.
@@ -26,6 +32,7 @@ import torch.distributed as dist
 from .. import _lib
 
 MAX_RANKS = 16
+MAX_EXTRA_SEGMENTS = 7          # data arena = 1 + up to 7 growth segments of equal size
 
 
 # largest allocation that can be shared through hipIpc (see SymmetricHeap.__init__)
@@ -42,6 +49,9 @@ class SymmCtxStruct(ctypes.Structure):
         ("sig_base", ctypes.c_uint64 * MAX_RANKS),
         ("heap_bytes", ctypes.c_uint64),
         ("sig_bytes", ctypes.c_uint64),
+        ("num_extra", ctypes.c_int),
+        ("_pad", ctypes.c_int),
+        ("extra_base", (ctypes.c_uint64 * MAX_RANKS) * MAX_EXTRA_SEGMENTS),
     ]
 
 
@@ -132,10 +142,14 @@ class SymmetricHeap:
         self.rank, self.world_size, self.group, self.backend = rank, world_size, group, backend
         default_heap = MAX_IPC_BYTES if backend == "hip" else (1 << 26)
         self.heap_bytes = int(heap_bytes or os.environ.get("TDIST_SYMM_HEAP_BYTES", default_heap))
-        if backend == "hip" and world_size > 1 and self.heap_bytes > MAX_IPC_BYTES:
+        # total capacity the arena may grow to (segments are added on demand)
+        if backend == "hip" and self.heap_bytes > MAX_IPC_BYTES:
             # hipIpcOpenMemHandle never returns for an allocation of 2 GiB or more on this stack
-            # (measured: 2^31 - 4 KiB opens in < 1 ms, 2^31 and 3 GiB hang), so one arena stays below
+            # (measured: 2^31 - 4 KiB opens in < 1 ms, 2^31 and 3 GiB hang), so a segment stays below
             self.heap_bytes = MAX_IPC_BYTES
+        # total capacity the arena may grow to (equal segments are added on demand)
+        self.max_heap_bytes = int(os.environ.get("TDIST_SYMM_HEAP_MAX_BYTES", 0)) or \
+            (1 + MAX_EXTRA_SEGMENTS) * self.heap_bytes
         self.sig_bytes = int(sig_bytes or os.environ.get("TDIST_SYMM_SIG_BYTES", 1 << 22))
         self._alloc = {"data": _FreeList(self.heap_bytes), "sig": _FreeList(self.sig_bytes)}
         self._bases = {"data": [0] * world_size, "sig": [0] * world_size}
@@ -173,8 +187,11 @@ class SymmetricHeap:
                     p = ctypes.c_void_p(ctypes.addressof(buf))
                 bases[arena].append(p.value)
         heaps = []
+        vgroup = {"segments": [], "owned": owned}       # growth segments shared by the virtual ranks
         for r in range(world_size):
             h = cls.__new__(cls)
+            h._vgroup = vgroup
+            h.max_heap_bytes = (1 + MAX_EXTRA_SEGMENTS) * heap_bytes
             h.rank, h.world_size, h.group, h.backend = r, world_size, None, backend
             h.heap_bytes, h.sig_bytes = heap_bytes, sig_bytes
             h._alloc = {"data": _FreeList(heap_bytes), "sig": _FreeList(sig_bytes)}
@@ -231,7 +248,7 @@ class SymmetricHeap:
 
     def _init_host(self) -> None:
         lib = _lib.host()
-        token = self._exchange(uuid.uuid4().hex[:12] if self.rank == 0 else None)[0]
+        token = self._token = self._exchange(uuid.uuid4().hex[:12] if self.rank == 0 else None)[0]
         for arena, nbytes in (("data", self.heap_bytes), ("sig", self.sig_bytes)):
             name = f"/tdist_{token}_{arena}_{self.rank}"
             p = ctypes.c_void_p()
@@ -256,11 +273,98 @@ class SymmetricHeap:
                 self._flat[arena][r] = _wrap_host(self._bases[arena][r], nbytes, self)
 
     # ------------------------------------------------------------------ allocation
+    def _data_arenas(self) -> List[str]:
+        return [a for a in self._alloc if a.startswith("data")]
+
     def _carve(self, arena: str, shape: Sequence[int], dtype: torch.dtype, align: int):
+        """Returns (arena name actually used, offset, nbytes)."""
         numel = math.prod(shape) if len(shape) else 1
         nbytes = numel * torch.empty((), dtype=dtype).element_size()
-        off = self._alloc[arena].alloc(nbytes, align)
-        return off, nbytes
+        if arena != "data":
+            return arena, self._alloc[arena].alloc(nbytes, align), nbytes
+        for name in self._data_arenas():
+            try:
+                return name, self._alloc[name].alloc(nbytes, align), nbytes
+            except MemoryError:
+                continue
+        n_seg = len(self._data_arenas())
+        if nbytes > self.heap_bytes or n_seg > MAX_EXTRA_SEGMENTS or (n_seg + 1) * self.heap_bytes > self.max_heap_bytes:
+            raise MemoryError(
+                f"symmetric heap exhausted: need {nbytes} bytes, {n_seg} segment(s) of {self.heap_bytes} bytes in use "
+                f"(a tensor must fit one segment; capacity {self.max_heap_bytes}: raise TDIST_SYMM_HEAP_BYTES / "
+                "TDIST_SYMM_HEAP_MAX_BYTES)")
+        name = self._grow()
+        return name, self._alloc[name].alloc(nbytes, align), nbytes
+
+    def _grow(self) -> str:
+        """Collective: add one data segment on every rank (same order everywhere, because symmetric
+        allocations are collective)."""
+        k = len(self._data_arenas())
+        name = f"data{k}"
+        nbytes, w = self.heap_bytes, self.world_size
+        bases = [0] * w
+        if getattr(self, "_virtual", False):
+            segs = self._vgroup["segments"]
+            if len(segs) < k:                       # first virtual rank to need it allocates for all
+                row = []
+                for _ in range(w):
+                    if self.backend == "hip":
+                        p = ctypes.c_void_p()
+                        _lib.check(_lib.hip().tdist_malloc(ctypes.byref(p), ctypes.c_size_t(nbytes), 0), "segment")
+                        _lib.check(_lib.hip().tdist_memset(p, 0, ctypes.c_size_t(nbytes)), "segment memset")
+                        row.append(p.value)
+                    else:
+                        buf = ctypes.create_string_buffer(nbytes)
+                        self._vgroup["owned"].append(buf)
+                        row.append(ctypes.addressof(buf))
+                segs.append(row)
+            bases = list(segs[k - 1])
+            if self.backend == "hip":
+                self._owned.append(bases[self.rank])
+            wrap = _wrap_device if self.backend == "hip" else _wrap_host
+        elif self.backend == "hip":
+            lib = _lib.hip()
+            p = ctypes.c_void_p()
+            _lib.check(lib.tdist_malloc(ctypes.byref(p), ctypes.c_size_t(nbytes),
+                                        int(os.environ.get("TDIST_HEAP_ALLOC_MODE", "0"))), f"symmetric {name} segment")
+            _lib.check(lib.tdist_memset(p, 0, ctypes.c_size_t(nbytes)), "segment memset")
+            self._owned.append(p.value)
+            bases[self.rank] = p.value
+            handle = None
+            if w > 1:
+                h = ctypes.create_string_buffer(lib.tdist_ipc_handle_size())
+                _lib.check(lib.tdist_ipc_get_handle(p, h), f"hipIpcGetMemHandle({name})")
+                handle = bytes(h.raw)
+            for r, hs in enumerate(self._exchange(handle)):
+                if r == self.rank:
+                    continue
+                q = ctypes.c_void_p()
+                _lib.check(lib.tdist_ipc_open_handle(hs, ctypes.byref(q)), f"hipIpcOpenMemHandle(rank {r}, {name})")
+                bases[r] = q.value
+                self._opened.append(q.value)
+            wrap = _wrap_device
+        else:
+            lib = _lib.host()
+
+            def shm_map(r, create):
+                p = ctypes.c_void_p()
+                _lib.check_host(lib.tdh_shm_map(f"/tdist_{self._token}_{name}_{r}".encode(), ctypes.c_uint64(nbytes),
+                                                1 if create else 0, ctypes.byref(p)), "shm segment")
+                return p.value
+
+            bases[self.rank] = shm_map(self.rank, True)
+            ctypes.memset(bases[self.rank], 0, nbytes)
+            self._exchange("created")               # everyone's segment exists before anyone opens one
+            for r in range(w):
+                if r != self.rank:
+                    bases[r] = shm_map(r, False)
+            self._exchange("mapped")
+            lib.tdh_shm_unlink(f"/tdist_{self._token}_{name}_{self.rank}".encode())
+            wrap = _wrap_host
+        self._bases[name] = bases
+        self._flat[name] = [wrap(bases[r], nbytes, self) for r in range(w)]
+        self._alloc[name] = _FreeList(nbytes)
+        return name
 
     def _view(self, arena: str, r: int, off: int, nbytes: int, shape, dtype) -> torch.Tensor:
         flat = self._flat[arena][r][off : off + nbytes]
@@ -270,7 +374,7 @@ class SymmetricHeap:
     def create_tensor(self, shape, dtype, arena: str = "data", align: int = 256, zero: bool = True) -> torch.Tensor:
         """Collective: returns this rank's tensor; ``peer_views`` gives the other ranks' copies."""
         shape = tuple(int(s) for s in shape)
-        off, nbytes = self._carve(arena, shape, dtype, align)
+        arena, off, nbytes = self._carve(arena, shape, dtype, align)
         t = self._view(arena, self.rank, off, max(nbytes, 0), shape, dtype)
         self._tensor_info[t.data_ptr()] = SymmTensorInfo(arena, off, nbytes)
         if zero and nbytes:
@@ -284,9 +388,9 @@ class SymmetricHeap:
 
     def info(self, t: torch.Tensor) -> SymmTensorInfo:
         base = t.data_ptr()
-        for arena in ("data", "sig"):
+        for arena in self._alloc:
             b = self._bases[arena][self.rank]
-            size = self.heap_bytes if arena == "data" else self.sig_bytes
+            size = self.sig_bytes if arena == "sig" else self.heap_bytes
             if b <= base < b + size:
                 return SymmTensorInfo(arena, base - b, t.numel() * t.element_size())
         raise ValueError("tensor is not inside this rank's symmetric heap")
@@ -323,7 +427,21 @@ class SymmetricHeap:
             c.heap_base[r] = self._bases["data"][r]
             c.sig_base[r] = self._bases["sig"][r]
         c.heap_bytes, c.sig_bytes = self.heap_bytes, self.sig_bytes
+        extra = [a for a in self._data_arenas() if a != "data"]
+        c.num_extra = len(extra)
+        for k, name in enumerate(extra):
+            for r in range(self.world_size):
+                c.extra_base[k][r] = self._bases[name][r]
         return c
+
+    def translate(self, ptr: int, peer: int) -> int:
+        """Host-side twin of the device ``symm_at``: the address of the same symmetric byte on ``peer``."""
+        for arena in self._alloc:
+            b = self._bases[arena][self.rank]
+            size = self.sig_bytes if arena == "sig" else self.heap_bytes
+            if b <= ptr < b + size:
+                return self._bases[arena][peer] + (ptr - b)
+        raise ValueError("pointer is not inside this rank's symmetric heap")
 
     def base(self, arena: str, r: int) -> int:
         return self._bases[arena][r]
@@ -348,7 +466,8 @@ class SymmetricHeap:
                 pass
         else:
             lib = _lib.host()
-            for arena, nbytes in (("data", self.heap_bytes), ("sig", self.sig_bytes)):
+            for arena in list(self._bases):
+                nbytes = self.sig_bytes if arena == "sig" else self.heap_bytes
                 for r in range(self.world_size):
                     b = self._bases[arena][r]
                     if b:
