@@ -81,11 +81,15 @@ def test_fast_allgather(w, mode):
         vc.close()
 
 
-@pytest.mark.parametrize("w,with_scale", [(2, False), (4, True), (8, True)])
-def test_fast_all_to_all(w, with_scale):
-    max_m, hidden, epr = 256, 1024, 4
+@pytest.mark.parametrize("w,with_scale,max_m,hidden", [
+    (2, False, 256, 1024), (4, True, 256, 1024), (8, True, 256, 1024),
+    (4, True, 1024, 2048),       # ~1 MiB per destination: 8 workgroups per destination
+    (8, False, 1024, 7168),      # DeepSeek-shaped rows (128 tokens x topk 8 per rank)
+])
+def test_fast_all_to_all(w, with_scale, max_m, hidden):
+    epr = 4
     E = w * epr
-    vc = VirtualCluster(w, heap_bytes=1 << 27)
+    vc = VirtualCluster(w, heap_bytes=1 << 28)
     try:
         ctxs = vc.collective(lambda r, env: create_all_to_all_context(max_m, hidden, r, E, w, epr, torch.bfloat16, env=env))
         for it in range(3):

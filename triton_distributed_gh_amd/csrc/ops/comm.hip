@@ -127,50 +127,78 @@ __global__ __launch_bounds__(512) void allgather_ll_kernel(AgLLParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Low-latency all-to-all.  Workgroup `pid` serves destination rank pid.
+// Low-latency all-to-all.  `slices` workgroups serve each destination rank `pid`, each moving a
+// 16-byte-aligned byte range of
 //   rows [cum[pid*EPR], cum[(pid+1)*EPR]) of send_buf -> peer recv[half][rank*max_m ...]
-//   per-expert splits (EPR ints)              -> peer split[half][rank*EPR ...]
 //   optional per-row scales (scale_elems f32) -> peer scale[half][rank*max_m ...]
-//   signal[half][rank] := call_count on the peer, then wait for signal[half][pid] == call_count.
+// slice 0 also writes the per-expert splits (EPR ints) -> peer split[half][rank*EPR ...].
+// One workgroup moves 12-16 GB/s, an xGMI link several times that, so a destination needs a few
+// workgroups to be link-bound.  The slice that finishes last (local counter `done[pid]`, zero at
+// rest: the last slice re-arms it, so the launch needs no memset) raises signal[half][rank] := call_count on the peer; slice 0 of every destination
+// then waits for signal[half][pid] == call_count, so kernel completion = everything has arrived.
 // ------------------------------------------------------------------------------------------------
 struct A2AParams {
   SymmCtx ctx;
-  const char* send_buf;     // [max_m, row_bytes]
+  const char* send_buf;     // [<= max_m, row_bytes]
   char* recv_buf;           // symmetric [2][w*max_m, row_bytes]
-  const float* send_scale;  // [max_m, scale_elems] or null
+  const float* send_scale;  // [<= max_m, scale_elems] or null
   float* recv_scale;        // symmetric [2][w*max_m, scale_elems]
   const int* cumsum;        // [num_tot_experts + 1] exclusive cumsum of tokens per expert
   int* split_buf;           // symmetric [2][w*EPR]
   unsigned long long* signal;  // symmetric [2][w]
   int* err;
+  int* done;                // local [w], zero between launches
   long long row_bytes;
-  int max_m, epr, scale_elems;
+  int max_m, epr, scale_elems, slices;
+  int n_rows;               // rows present in send_buf
   unsigned long long call_count;
 };
 
+__device__ __forceinline__ void a2a_copy_slice(char* dst, const char* src, long long total, int slice, int slices) {
+  const long long per = ((total + slices - 1) / slices + 15) & ~15ll;
+  const long long b0 = min((long long)slice * per, total), b1 = min(b0 + per, total);
+  if (b1 > b0) shmem::copy_bytes(dst + b0, src + b0, (size_t)(b1 - b0), threadIdx.x, blockDim.x);
+}
+
 __global__ __launch_bounds__(1024) void all_to_all_kernel(A2AParams p) {
-  const int w = p.ctx.num_ranks, rank = p.ctx.rank, pid = blockIdx.x;
+  const int w = p.ctx.num_ranks, rank = p.ctx.rank;
+  const int pid = blockIdx.x / p.slices, slice = blockIdx.x % p.slices;
   const int half = (int)(p.call_count & 1);
-  const int m_st = p.cumsum[pid * p.epr], m_ed = p.cumsum[(pid + 1) * p.epr];
+  const int c_st = p.cumsum[pid * p.epr], c_ed = p.cumsum[(pid + 1) * p.epr];
+  // a malformed cumsum must not turn into an out-of-range read or peer write
+  const int m_st = min(max(c_st, 0), p.n_rows);
+  const int rows = min(min(max(c_ed - m_st, 0), p.max_m), p.n_rows - m_st);
+  if ((m_st != c_st || rows != c_ed - c_st) && threadIdx.x == 0) atomicOr(p.err, 2);
   const long long slot_row = (long long)half * w * p.max_m + (long long)rank * p.max_m;
   char* dst = symm_at(p.ctx, p.recv_buf, pid) + slot_row * p.row_bytes;
-  shmem::copy_bytes(dst, p.send_buf + (long long)m_st * p.row_bytes, (size_t)(m_ed - m_st) * p.row_bytes, threadIdx.x,
-                    blockDim.x);
+  a2a_copy_slice(dst, p.send_buf + (long long)m_st * p.row_bytes, (long long)rows * p.row_bytes, slice, p.slices);
   if (p.send_scale) {
     float* sd = symm_at(p.ctx, p.recv_scale, pid) + slot_row * p.scale_elems;
-    shmem::copy_bytes(sd, p.send_scale + (long long)m_st * p.scale_elems,
-                      (size_t)(m_ed - m_st) * p.scale_elems * sizeof(float), threadIdx.x, blockDim.x);
+    a2a_copy_slice((char*)sd, (const char*)(p.send_scale + (long long)m_st * p.scale_elems),
+                   (long long)rows * p.scale_elems * (long long)sizeof(float), slice, p.slices);
   }
-  int* sp = symm_at(p.ctx, p.split_buf, pid) + half * w * p.epr + rank * p.epr;
-  for (int e = threadIdx.x; e < p.epr; e += blockDim.x)
-    sp[e] = p.cumsum[pid * p.epr + e + 1] - p.cumsum[pid * p.epr + e];
+  if (slice == 0) {
+    int* sp = symm_at(p.ctx, p.split_buf, pid) + half * w * p.epr + rank * p.epr;
+    for (int e = threadIdx.x; e < p.epr; e += blockDim.x)
+      sp[e] = p.cumsum[pid * p.epr + e + 1] - p.cumsum[pid * p.epr + e];
+  }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    store_relaxed_system(symm_at(p.ctx, p.signal, pid) + half * w + rank, p.call_count);
-    if (!spin_until_eq(p.signal + half * w + pid, p.call_count, SCOPE_SYS)) atomicOr(p.err, 1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    const int prev = atom_add_acqrel_agent(p.done + pid, 1);
+    if (prev == p.slices - 1) {
+      // last slice of this destination: re-arm the counter for the next call (nobody else touches
+      // it any more in this launch), then publish
+      store_relaxed_agent(p.done + pid, 0);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      store_relaxed_system(symm_at(p.ctx, p.signal, pid) + half * w + rank, p.call_count);
+    }
+    if (slice == 0) {
+      if (!spin_until_eq(p.signal + half * w + pid, p.call_count, SCOPE_SYS)) atomicOr(p.err, 1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    }
   }
 }
 
@@ -350,10 +378,17 @@ TDIST_API int tdist_allgather_ll(const SymmCtx* ctx, void* buf, void* stage, int
   return 0;
 }
 
+// scratch: local int32 [4 + TDIST_MAX_RANKS]: [0] sticky error word (bit 0 wait timeout, bit 1 bad
+// cumsum), [4 ...] per-destination slice counters (zero-initialised by the caller, self-resetting).
 TDIST_API int tdist_all_to_all(const SymmCtx* ctx, const void* send_buf, void* recv_buf, const float* send_scale,
-                               float* recv_scale, const int* cumsum, int* split_buf, void* signal, int* err,
-                               long long row_bytes, int max_m, int epr, int scale_elems,
+                               float* recv_scale, const int* cumsum, int* split_buf, void* signal, int* scratch,
+                               long long row_bytes, int n_rows, int max_m, int epr, int scale_elems, int slices,
                                unsigned long long call_count, void* stream) {
+  const int w = ctx->num_ranks;
+  TDIST_REQUIRE(w >= 1 && w <= TDIST_MAX_RANKS, "bad world size");
+  TDIST_REQUIRE(slices >= 1 && slices <= 32, "slices must be in [1, 32]");
+  TDIST_REQUIRE(row_bytes > 0 && max_m > 0 && epr > 0 && scale_elems >= 0 && n_rows >= 0 && n_rows <= max_m,
+                "bad a2a shape");
   A2AParams p;
   p.ctx = *ctx;
   p.send_buf = (const char*)send_buf;
@@ -363,13 +398,16 @@ TDIST_API int tdist_all_to_all(const SymmCtx* ctx, const void* send_buf, void* r
   p.cumsum = cumsum;
   p.split_buf = split_buf;
   p.signal = (unsigned long long*)signal;
-  p.err = err;
+  p.err = scratch;
+  p.done = scratch + 4;
   p.row_bytes = row_bytes;
   p.max_m = max_m;
   p.epr = epr;
   p.scale_elems = scale_elems;
+  p.slices = slices;
+  p.n_rows = n_rows;
   p.call_count = call_count;
-  hipLaunchKernelGGL(all_to_all_kernel, dim3(ctx->num_ranks), dim3(1024), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(all_to_all_kernel, dim3(w * slices), dim3(1024), 0, (hipStream_t)stream, p);
   TDIST_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -3,16 +3,17 @@ fp8 group quantisation that goes with it.
 
 API of the reference (reference: python/triton_dist/kernels/nvidia/low_latency_all_to_all.py -
 ``create_all_to_all_context`` :176-195, ``fast_all_to_all`` :198-257, ``all_to_all_post_process``
-:260-279; fp8 helpers tutorials/04-deepseek-infer-all2all.py:334-427).  One workgroup per
-destination rank moves that rank's contiguous token rows (tokens are pre-sorted by expert), the
-per-expert splits and the optional fp32 scales straight into the peer's receive buffer over xGMI,
-then raises a 64-bit signal with the call count; receive buffers are double-buffered by call parity
+:260-279; fp8 helpers tutorials/04-deepseek-infer-all2all.py:334-427).  A few workgroups
+per destination rank move that rank's contiguous token rows (tokens are pre-sorted by expert), the
+per-expert splits and the optional fp32 scales straight from the caller's tensors into the peer's
+receive buffer over xGMI (no staging copy), then raise a 64-bit signal with the call count; receive buffers are double-buffered by call parity
 so the sender never waits for the receiver to have consumed the previous message.
 """
 from __future__ import annotations
 
 import ctypes
 import dataclasses
+import os
 from typing import Any, List, Optional, Tuple
 
 import torch
@@ -47,7 +48,10 @@ class AllToAllContext:
     MOD_VALUE: int = 1000000
 
     def check_error(self) -> None:
-        if self.err is not None and int(self.err[0]) != 0:
+        code = int(self.err[0]) if self.err is not None else 0
+        if code & 2:
+            raise RuntimeError("fast_all_to_all: send_split_cumsum is inconsistent with the send tensor / max_m")
+        if code:
             raise RuntimeError("fast_all_to_all: a device-side wait timed out")
 
 
@@ -66,7 +70,7 @@ def create_all_to_all_context(max_m, hidden, rank, num_tot_experts, WORLD_SIZE, 
     split_send = torch.zeros((num_tot_experts + 1,), dtype=torch.int32, device=dev)
     split_recv = heap.create_tensor_list([2, w * experts_per_rank], torch.int32)
     signal = heap.create_tensor_list([2 * w], torch.int64, arena="sig")
-    err = torch.zeros(4, dtype=torch.int32, device=dev) if env.backend == "hip" else None
+    err = torch.zeros(4 + 16, dtype=torch.int32, device=dev)   # error word + per-destination slice counters if env.backend == "hip" else None
     if env.backend == "hip":
         torch.cuda.synchronize()
     if env.cpu_group is not None:
@@ -84,30 +88,59 @@ def fast_all_to_all(ctx: AllToAllContext, send_tensor: torch.Tensor, send_split_
     w, rank = ctx.world_size, ctx.rank
     n = send_tensor.shape[0]
     assert n <= ctx.max_m and send_tensor.shape[1] == ctx.hidden
+    assert send_split_cumsum.numel() == ctx.num_tot_experts + 1
     half = ctx.call_count & 1
-    ctx.send_buf[:n].copy_(send_tensor)
-    ctx.split_send_buf.copy_(send_split_cumsum.to(torch.int32))
     with_scale = send_scale is not None
-    if with_scale:
-        ctx.scale_send_buf[:n].copy_(send_scale)
     if env.backend == "host":
+        ctx.send_buf[:n].copy_(send_tensor)
+        ctx.split_send_buf.copy_(send_split_cumsum.to(torch.int32))
+        if with_scale:
+            ctx.scale_send_buf[:n].copy_(send_scale)
         _a2a_host(ctx, n, half, with_scale)
     else:
+        # The kernel pushes straight from the caller's tensors (stream order keeps them alive); the
+        # context's staging buffers are only used when a tensor has to be converted first.
+        assert send_tensor.dtype == ctx.dtype and send_tensor.is_cuda
+        src = send_tensor if send_tensor.is_contiguous() else ctx.send_buf[:n].copy_(send_tensor)
+        cum = send_split_cumsum
+        if cum.dtype != torch.int32 or not cum.is_contiguous() or not cum.is_cuda:
+            cum = ctx.split_send_buf.copy_(cum)
+        scale = None
+        if with_scale:
+            assert send_scale.shape == (n, ctx.scale_elems)
+            scale = send_scale
+            if scale.dtype != ctx.scale_dtype or not scale.is_contiguous():
+                scale = ctx.scale_send_buf[:n].copy_(send_scale)
         cs = env.heap.ctx_struct()
-        row_bytes = ctx.hidden * ctx.send_buf.element_size()
+        row_bytes = ctx.hidden * src.element_size()
         _lib.check(
-            _lib.hip().tdist_all_to_all(ctypes.byref(cs), _lib.ptr(ctx.send_buf), _lib.ptr(ctx.recv_buf[rank]),
-                                        _lib.ptr(ctx.scale_send_buf) if with_scale else ctypes.c_void_p(0),
-                                        _lib.ptr(ctx.scale_recv_buf[rank]), _lib.ptr(ctx.split_send_buf),
+            _lib.hip().tdist_all_to_all(ctypes.byref(cs), _lib.ptr(src), _lib.ptr(ctx.recv_buf[rank]),
+                                        _lib.ptr(scale) if with_scale else ctypes.c_void_p(0),
+                                        _lib.ptr(ctx.scale_recv_buf[rank]), _lib.ptr(cum),
                                         _lib.ptr(ctx.split_recv_buf[rank]), _lib.ptr(ctx.signal_buf[rank]),
-                                        _lib.ptr(ctx.err), ctypes.c_longlong(row_bytes), ctx.max_m,
-                                        ctx.experts_per_rank, ctx.scale_elems, ctypes.c_ulonglong(ctx.call_count),
-                                        _lib.stream_handle()), "tdist_all_to_all")
+                                        _lib.ptr(ctx.err), ctypes.c_longlong(row_bytes), n, ctx.max_m,
+                                        ctx.experts_per_rank, ctx.scale_elems, _a2a_slices(n * row_bytes, w, env.shared_gpu),
+                                        ctypes.c_ulonglong(ctx.call_count), _lib.stream_handle()), "tdist_all_to_all")
     ctx.call_count = (ctx.call_count + 1) % ctx.MOD_VALUE or 1
     recv = ctx.recv_buf[rank][half].view(w, ctx.max_m, ctx.hidden)
     splits = ctx.split_recv_buf[rank][half].view(w, ctx.experts_per_rank)
     scale = ctx.scale_recv_buf[rank][half].view(w, ctx.max_m, ctx.scale_elems) if with_scale else None
     return splits, recv, scale
+
+
+def _a2a_slices(total_bytes: int, w: int, shared_gpu: bool = False) -> int:
+    """Workgroups per destination: ~128 KiB each, at most 4 (measured on MI355X for the 900 KiB
+    per destination of the DeepSeek decode shape: 1 / 2 / 4 / 8 / 16 workgroups per destination
+    take 43 / 32 / 26-30 / 34 / 45 us - more 1024-thread workgroups cost more to launch than they
+    gain), and never more than 128 workgroups in the launch.  ``TDIST_A2A_SLICES`` overrides.  When all ranks share one GPU (virtual ranks) the 128 are
+    shared too: every rank's waiting workgroups must be resident together with every producer."""
+    forced = int(os.environ.get("TDIST_A2A_SLICES", "0"))
+    if forced:
+        return max(1, min(32, forced))
+    w = max(w, 1)
+    per_dest = max(1, total_bytes // w)
+    budget = 128 // w if shared_gpu else 128
+    return max(1, min(4, budget // w, per_dest // 131072))
 
 
 def _a2a_host(ctx, n, half, with_scale):

@@ -37,7 +37,13 @@ class Runner:
         self.args = args
         self.vc = None
         if args.virtual_ranks and args.virtual_ranks > 0 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
-            os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(8, 2 * args.virtual_ranks + 4)))
+            # Every virtual rank's two streams need hardware queues of their own: kernels that
+            # share a queue start in order with limited overlap, so a rank spinning on a peer
+            # queued behind it in the same hardware queue would wait for its spin budget.
+            # A smaller value in the environment (some machines export HIP's default of 4) is raised.
+            need = max(8, 2 * args.virtual_ranks + 4)
+            if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < need:
+                os.environ["GPU_MAX_HW_QUEUES"] = str(need)
             self.vc = VirtualCluster(args.virtual_ranks, heap_bytes=args.heap_mb << 20)
             self.world_size, self.envs = args.virtual_ranks, self.vc.envs
             self.device = self.envs[0].device
@@ -94,13 +100,14 @@ class Runner:
         import time as _t
 
         cuda = self.device.type == "cuda"
+        if self.virtual and cuda:
+            # gate-released, one call per rank in flight; median over the iterations (host clock)
+            per_iter = sorted(self.vc.timed_run(fn) for _ in range(iters))
+            return per_iter[len(per_iter) // 2]
         if self.virtual:
-            # the ranks run on several streams: wall clock around a device-wide synchronise
             t0 = _t.perf_counter()
             for _ in range(iters):
-                self.vc.run(fn, sync=False)
-            if cuda:
-                torch.cuda.synchronize()
+                self.vc.run(fn)
             return (_t.perf_counter() - t0) * 1e3 / iters
         env = self.envs[0]
         if cuda:

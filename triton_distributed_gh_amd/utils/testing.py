@@ -29,7 +29,7 @@ import torch
 from .. import _lib
 from .distributed import create_virtual_node
 
-_POOL = {"main": [], "side": []}
+_POOL = {"main": [], "side": [], "gate": []}
 
 
 def _pool_streams(kind: str, n: int):
@@ -84,6 +84,35 @@ class VirtualCluster:
             if e is not None:
                 raise e
         return outs
+
+    def timed_run(self, fn: Callable, gate_cycles: int = 5_000_000) -> float:
+        """One call of ``fn(rank, env)`` per rank, all released at the same instant; returns the
+        milliseconds from the release until every rank has finished.
+
+        The host enqueues the ranks one after the other, so without a gate rank 0 would start
+        early and the time would include the launch skew of the others.  Here every rank's stream
+        first waits for one event that a gate stream records after a ~2 ms sleep kernel; by then
+        all ranks' work is queued.  The clock is the host's (it wakes on the gate event, then on
+        the device going idle), good to ~10 us; per-kernel times come from ``rocprofv3
+        --kernel-trace``.  No event is recorded on the rank streams: an event is a barrier packet,
+        and when virtual ranks share a hardware queue it would hold a peer's kernel behind the
+        kernel that waits for it.  Exactly one call per rank is in flight for the same reason."""
+        assert self.backend == "hip"
+        import time
+
+        gate = _pool_streams("gate", 1)[0]
+        ev_gate = torch.cuda.Event()
+        with torch.cuda.stream(gate):
+            torch.cuda._sleep(gate_cycles)
+            ev_gate.record()
+        for r, env in enumerate(self.envs):
+            with torch.cuda.stream(self.streams[r]):
+                self.streams[r].wait_event(ev_gate)
+                fn(r, env)
+        ev_gate.synchronize()
+        t0 = time.perf_counter()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3
 
     def collective(self, fn: Callable) -> List:
         """Run a collective constructor (symmetric allocation) rank by rank on the host."""
