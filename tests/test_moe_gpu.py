@@ -67,7 +67,8 @@ def test_ag_group_gemm(w, ntokens, N, K, E, topk):
 
 
 @pytest.mark.parametrize("w,ntokens,hidden,K,E,topk", [(1, 128, 512, 256, 4, 2), (2, 256, 512, 512, 8, 2),
-                                                       (4, 512, 1024, 1024, 8, 2), (8, 512, 768, 2048, 16, 4)])
+                                                       (4, 512, 1024, 1024, 8, 2), (8, 512, 768, 2048, 16, 4),
+                                                       (4, 88, 520, 512, 8, 2)])   # 22 tokens per rank: partial token group
 def test_moe_reduce_rs(w, ntokens, hidden, K, E, topk):
     vc = VirtualCluster(w, heap_bytes=1 << 27)
     try:

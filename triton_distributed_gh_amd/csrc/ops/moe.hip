@@ -22,7 +22,7 @@ using namespace tdist;
 using namespace tdist::gemm;
 
 // ------------------------------------------------------------------------------------------------
-// align: ONE workgroup of 1024 threads.  LDS: hist[E*w], base[E*w], pad_off[E+1]
+// align: ONE workgroup of 1024 threads.  LDS: hist[E*w], base[E*w], pad_off[E+1], stage_of[cap/256]
 // ------------------------------------------------------------------------------------------------
 struct AlignParams {
   const int* topk_ids;    // [n] expert of flat pair i = token*topk + k
@@ -39,6 +39,7 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(AlignParams p) {
   int* hist = lds;                       // [E*w] counts, later cursors
   int* base = lds + p.E * p.w;           // [E*w] start row of (e, s)
   int* pad_off = base + p.E * p.w;       // [E+1]
+  int* stage_of = pad_off + p.E + 1;     // [cap / 256] arrival stage of every block
   const int EW = p.E * p.w;
   for (int i = threadIdx.x; i < EW; i += blockDim.x) hist[i] = 0;
   for (int i = threadIdx.x; i < p.cap; i += blockDim.x) p.sorted_ids[i] = -1;
@@ -93,18 +94,24 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(AlignParams p) {
     const int slot = base[e * p.w + s] + atomicAdd(&hist[e * p.w + s], 1);
     p.sorted_ids[slot] = i;
   }
-  __syncthreads();
   // arrival order: a block is ready once its LAST needed source (in push-arrival order: own rank
-  // first, then rank+1, rank+2, ... as pushed by the producers) has landed.  Counting sort on
-  // stage = max over [smin, smax] of ((s - rank + w) % w).
-  if (threadIdx.x == 0) {
+  // first, then rank+1, rank+2, ... as pushed by the producers) has landed.  Stable counting sort
+  // on stage = max over [smin, smax] of ((s - rank + w) % w), one thread per block: its position is
+  // the number of blocks of an earlier stage plus the number of lower-numbered blocks of its own.
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+    int stage = 0;
+    for (int s = p.seg_range[2 * b]; s <= p.seg_range[2 * b + 1]; ++s) stage = max(stage, (s - p.rank + p.w) % p.w);
+    stage_of[b] = stage;     // seg_range[b] was written by this same thread above
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+    const int mine = stage_of[b];
     int pos = 0;
-    for (int st = 0; st < p.w; ++st)
-      for (int b = 0; b < nblocks; ++b) {
-        int stage = 0;
-        for (int s = p.seg_range[2 * b]; s <= p.seg_range[2 * b + 1]; ++s) stage = max(stage, (s - p.rank + p.w) % p.w);
-        if (stage == st) p.order[pos++] = b;
-      }
+    for (int o = 0; o < nblocks; ++o) {
+      const int st = stage_of[o];
+      pos += (st < mine || (st == mine && o < b)) ? 1 : 0;
+    }
+    p.order[pos] = b;
   }
 }
 
@@ -196,8 +203,15 @@ __global__ __launch_bounds__(THREADS, 2) void moe_group_gemm_kernel(GroupGemmPar
 
 // ------------------------------------------------------------------------------------------------
 // topk reduce + reduce-scatter.  gemm_out [ntokens*topk, N] (already weight-scaled).
-// items 0 .. ntokens-1          : sum topk rows of token t, push to owner d = t / tpr slot [rank]
-// items ntokens .. ntokens+tpr-1: wait all sources, out[t_local] = sum over w slots
+// Work items hold RS_TG consecutive tokens of one owner (per-item costs - ticket, drain, barrier,
+// counter - are paid once per group, and a thread keeps 4 x topk 16-byte loads in flight):
+//   push items   [0, w*gpo)      : item -> owner d = (rank+1 + item%w) % w, group item/w of that
+//                                  owner's tpr tokens: sum the topk rows of each token, store to
+//                                  the owner's scatter slot [rank]; the group that completes an
+//                                  owner raises flags[rank] := epoch there
+//   reduce items [w*gpo, w*gpo+gpo): wait for all w sources, out[t_local] = sum over the w slots
+// (gpo = groups per owner).  Push items come first in ticket order, so a workgroup that waits in
+// a reduce item can only be waiting for other ranks, never for unclaimed local work.
 // ------------------------------------------------------------------------------------------------
 struct TopkRsParams {
   SymmCtx ctx;
@@ -210,73 +224,98 @@ struct TopkRsParams {
   int ntokens, topk, N, tpr, epoch;
 };
 
+constexpr int RS_TG = 8;
+
+__device__ __forceinline__ void acc_bf16x8(float (&acc)[8], const uint4& v) {
+  const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    acc[2 * i] += __builtin_bit_cast(float, x[i] << 16);
+    acc[2 * i + 1] += __builtin_bit_cast(float, x[i] & 0xffff0000u);
+  }
+}
+
+__device__ __forceinline__ uint4 pack_bf16x8(const float (&acc)[8]) {
+  uint4 o;
+  o.x = Frag<true>::pack2(acc[0], acc[1]);
+  o.y = Frag<true>::pack2(acc[2], acc[3]);
+  o.z = Frag<true>::pack2(acc[4], acc[5]);
+  o.w = Frag<true>::pack2(acc[6], acc[7]);
+  return o;
+}
+
 __global__ __launch_bounds__(256) void moe_topk_reduce_rs_kernel(TopkRsParams p) {
   __shared__ int s_item;
   const int w = p.ctx.num_ranks, rank = p.ctx.rank;
-  const int total = p.ntokens + p.tpr;
+  const int gpo = (p.tpr + RS_TG - 1) / RS_TG;
+  const int n_push = w * gpo;
+  const int total = n_push + gpo;
+  const int cpr = p.N >> 3;                     // 16-byte pieces per row
   while (true) {
     __syncthreads();
     if (threadIdx.x == 0) s_item = atomicAdd(p.counters + w, 1);
     __syncthreads();
     const int item = __builtin_amdgcn_readfirstlane(s_item);
     if (item >= total) break;
-    if (item < p.ntokens) {
-      // visit tokens so that consecutive items go to different owners
+    if (item < n_push) {
+      // consecutive items go to different owners, so all links carry traffic at any moment
       const int d = (rank + 1 + item % w) % w;
-      const int tl = item / w;
-      // items are laid out as tpr rounds of w owners: (tl, d)
-      if (tl < p.tpr) {
-        const int t = d * p.tpr + tl;
-        uint16_t* dst = ((d == rank) ? p.scatter : symm_at(p.ctx, p.scatter, d)) + ((long long)rank * p.tpr + tl) * p.N;
-        for (int c = threadIdx.x * 8; c < p.N; c += blockDim.x * 8) {
-          float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          for (int k = 0; k < p.topk; ++k) {
-            const uint4 v = *(const uint4*)(p.gemm_out + ((long long)t * p.topk + k) * p.N + c);
-            const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+      const int tl0 = (item / w) * RS_TG;
+      const int ntl = min(RS_TG, p.tpr - tl0);  // >= 1
+      const uint16_t* src = p.gemm_out + ((long long)d * p.tpr + tl0) * p.topk * p.N;
+      uint16_t* dst = ((d == rank) ? p.scatter : symm_at(p.ctx, p.scatter, d)) + ((long long)rank * p.tpr + tl0) * p.N;
+      const int units = ntl * cpr;              // one unit = one 16-byte output piece
+      for (int u0 = threadIdx.x; u0 < units; u0 += 4 * blockDim.x) {
+        float acc[4][8];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              acc[2 * i] += __builtin_bit_cast(float, x[i] << 16);
-              acc[2 * i + 1] += __builtin_bit_cast(float, x[i] & 0xffff0000u);
-            }
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
+          const int u = u0 + j * blockDim.x;
+          if (u < units) {
+            const int tl = u / cpr, c = (u - tl * cpr) << 3;
+            for (int k = 0; k < p.topk; ++k)
+              acc_bf16x8(acc[j], *(const uint4*)(src + ((long long)tl * p.topk + k) * p.N + c));
           }
-          uint4 o;
-          o.x = Frag<true>::pack2(acc[0], acc[1]);
-          o.y = Frag<true>::pack2(acc[2], acc[3]);
-          o.z = Frag<true>::pack2(acc[4], acc[5]);
-          o.w = Frag<true>::pack2(acc[6], acc[7]);
-          st_wt128_sys(dst + c, o);
         }
-        // write-through stores: drain + barrier publish them, no release fence; the add that
-        // completes an owner's rows is ordered after every earlier add on that word
-        drain_stores();
-        __syncthreads();
-        if (threadIdx.x == 0) {
-          const int prev = atom_add_relaxed_agent(p.counters + d, 1);
-          if (prev == p.tpr - 1) {
-            store_relaxed_system(((d == rank) ? p.flags : symm_at(p.ctx, p.flags, d)) + rank, p.epoch);
-          }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int u = u0 + j * blockDim.x;
+          if (u < units) st_wt128_sys(dst + ((long long)u << 3), pack_bf16x8(acc[j]));   // rows of a group are contiguous
+        }
+      }
+      // write-through stores: drain + barrier publish them, no release fence; the add that
+      // completes an owner's groups is ordered after every earlier add on that word
+      drain_stores();
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const int prev = atom_add_relaxed_agent(p.counters + d, 1);
+        if (prev == gpo - 1) {
+          store_relaxed_system(((d == rank) ? p.flags : symm_at(p.ctx, p.flags, d)) + rank, p.epoch);
         }
       }
     } else {
-      const int tl = item - p.ntokens;
+      const int tl0 = (item - n_push) * RS_TG;
+      const int ntl = min(RS_TG, p.tpr - tl0);
       wait(p.flags, w, SCOPE_SYS, SEM_ACQUIRE, p.epoch, p.err);
-      for (int c = threadIdx.x * 8; c < p.N; c += blockDim.x * 8) {
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < w; ++s) {
-          const uint4 v = *(const uint4*)(p.scatter + ((long long)s * p.tpr + tl) * p.N + c);
-          const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+      const int units = ntl * cpr;
+      for (int u0 = threadIdx.x; u0 < units; u0 += 2 * blockDim.x) {
+        float acc[2][8];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            acc[2 * i] += __builtin_bit_cast(float, x[i] << 16);
-            acc[2 * i + 1] += __builtin_bit_cast(float, x[i] & 0xffff0000u);
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
+          const int u = u0 + j * blockDim.x;
+          if (u < units) {
+            for (int s = 0; s < w; ++s)
+              acc_bf16x8(acc[j], *(const uint4*)(p.scatter + ((long long)s * p.tpr + tl0) * p.N + ((long long)u << 3)));
           }
         }
-        uint4 o;
-        o.x = Frag<true>::pack2(acc[0], acc[1]);
-        o.y = Frag<true>::pack2(acc[2], acc[3]);
-        o.z = Frag<true>::pack2(acc[4], acc[5]);
-        o.w = Frag<true>::pack2(acc[6], acc[7]);
-        *(uint4*)(p.out + (long long)tl * p.N + c) = o;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int u = u0 + j * blockDim.x;
+          if (u < units) *(uint4*)(p.out + (long long)tl0 * p.N + ((long long)u << 3)) = pack_bf16x8(acc[j]);
+        }
       }
     }
   }
@@ -287,7 +326,7 @@ TDIST_API int tdist_moe_align(const int* topk_ids, int* sorted_ids, int* expert_
                               int* meta, int n, int E, int w, int topk, int tokens_per_rank, int rank, int cap,
                               void* stream) {
   TDIST_REQUIRE(E > 0 && w > 0 && cap % BM == 0 && cap >= n, "bad align arguments");
-  const size_t lds = (size_t)(2 * E * w + E + 1) * sizeof(int);
+  const size_t lds = (size_t)(2 * E * w + E + 1 + cap / BM) * sizeof(int);
   TDIST_REQUIRE(lds <= 160 * 1024, "too many experts x ranks for one workgroup");
   AlignParams p{topk_ids, sorted_ids, expert_of_block, seg_range, order, meta, n, E, w, topk, tokens_per_rank, rank, cap};
   static bool attr_set = false;
@@ -366,7 +405,8 @@ TDIST_API int tdist_moe_topk_reduce_rs(const SymmCtx* ctx, const void* gemm_out,
   p.tpr = ntokens / w;
   p.epoch = epoch;
   TDIST_HIP_TRY(hipMemsetAsync(counters, 0, (size_t)(TDIST_MAX_RANKS + 4) * sizeof(int), (hipStream_t)stream));
-  hipLaunchKernelGGL(moe_topk_reduce_rs_kernel, dim3(num_ctas > 0 ? num_ctas : 128), dim3(256), 0, (hipStream_t)stream, p);
+  // memory-bound streaming work: four workgroups per CU unless the caller budgets fewer
+  hipLaunchKernelGGL(moe_topk_reduce_rs_kernel, dim3(num_ctas > 0 ? num_ctas : 1024), dim3(256), 0, (hipStream_t)stream, p);
   TDIST_HIP_TRY(hipGetLastError());
   return 0;
 }

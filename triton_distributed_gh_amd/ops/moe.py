@@ -15,6 +15,7 @@ accepted and converted once per weight tensor (cached).
 from __future__ import annotations
 
 import ctypes
+import os
 import dataclasses
 from typing import Any, Optional
 
@@ -354,6 +355,7 @@ def run_moe_reduce_rs(x: torch.Tensor, weights: torch.Tensor, chosen_experts: to
     _lib.check(
         lib.tdist_moe_topk_reduce_rs(ctypes.byref(cs), _lib.ptr(gemm_out), _lib.ptr(ctx.scatter[parity][rank]),
                                      _lib.ptr(ctx.flags[parity][rank]), _lib.ptr(ctx.scratch), _lib.ptr(ctx.scratch[40:]),
-                                     _lib.ptr(out), ntokens, topk, N, epoch, ctx.num_ctas, _lib.stream_handle()),
+                                     _lib.ptr(out), ntokens, topk, N, epoch,
+                                     int(os.environ.get("TDIST_MOE_RS_CTAS", "0")) or ctx.num_ctas, _lib.stream_handle()),
         "tdist_moe_topk_reduce_rs")
     return out
