@@ -13,6 +13,7 @@
 //   quiet / fence   = system-scope release fence + drain of outstanding stores
 //   barrier_all*    = sense-free slot-matrix barrier (one slot per (dst, src) pair)
 #pragma once
+#include "tdist/cache_policy.hpp"
 #include "tdist/primitives.hpp"
 
 namespace tdist {
@@ -77,6 +78,36 @@ __device__ __forceinline__ void copy_bytes(void* dst, const void* src, size_t by
     for (size_t j = tid; j < bytes; j += nthreads)
       reinterpret_cast<unsigned char*>(dst)[j] = reinterpret_cast<const unsigned char*>(src)[j];
   }
+}
+
+// Same copy with write-through system-scope stores for the 16-byte body (see cache_policy.hpp):
+// the payload leaves the L2 at once, so the publisher needs no release fence (a system-scope
+// release walks the whole L2), only `drain_stores()` in every storing wave + a barrier before the
+// flag.  Returns true when some bytes had to go out as plain stores (unaligned operands or a tail
+// shorter than 16 bytes) - then the caller still owes a release fence before it signals.  The
+// result depends only on the arguments, so it is uniform over the cooperating threads.
+__device__ __forceinline__ bool copy_bytes_wt_sys(void* dst, const void* src, size_t bytes, int tid, int nthreads) {
+  const uintptr_t d = reinterpret_cast<uintptr_t>(dst), s = reinterpret_cast<uintptr_t>(src);
+  if (((d | s) & 15) != 0) {
+    copy_bytes(dst, src, bytes, tid, nthreads);
+    return bytes != 0;
+  }
+  const size_t n16 = bytes >> 4;
+  const uint4* s4 = reinterpret_cast<const uint4*>(src);
+  uint4* d4 = reinterpret_cast<uint4*>(dst);
+  size_t i = tid;
+  for (; i + 3 * (size_t)nthreads < n16; i += 4 * (size_t)nthreads) {
+    const uint4 a = s4[i], b = s4[i + nthreads], c = s4[i + 2 * (size_t)nthreads], e = s4[i + 3 * (size_t)nthreads];
+    st_wt128_sys(d4 + i, a);
+    st_wt128_sys(d4 + i + nthreads, b);
+    st_wt128_sys(d4 + i + 2 * (size_t)nthreads, c);
+    st_wt128_sys(d4 + i + 3 * (size_t)nthreads, e);
+  }
+  for (; i < n16; i += nthreads) st_wt128_sys(d4 + i, s4[i]);
+  const size_t done = n16 << 4;
+  for (size_t j = done + tid; j < bytes; j += nthreads)
+    reinterpret_cast<unsigned char*>(dst)[j] = reinterpret_cast<const unsigned char*>(src)[j];
+  return done != bytes;
 }
 
 // put: dest is a symmetric address (translated to `pe`), source is local.

@@ -15,6 +15,7 @@
 // Role in the reference: kernels/nvidia/allreduce.py one_shot_push :332-383, two_shot_push :446-524;
 // the NVLS multimem / TMA / double-tree variants (:214-329, :386-443, :527-682) have no xGMI
 // counterpart and are served by these two kernels (see ops/allreduce.py for the mapping).
+#include "tdist/cache_policy.hpp"
 #include "tdist/common.hpp"
 #include "tdist/primitives.hpp"
 #include "tdist/shmem_device.hpp"
@@ -104,10 +105,12 @@ struct Elem<_Float16> {
 };
 
 // Raise flag[phase][rank][c] on every peer, then wait for flag[phase][s][c] of every peer s.
-__device__ __forceinline__ void exchange_flags(const ArParams& p, int phase, int c) {
+// The payload went out with write-through stores, so publishing is drain + barrier; only a push
+// that had to fall back to plain stores (`need_release`, workgroup-uniform) pays a release fence.
+__device__ __forceinline__ void exchange_flags(const ArParams& p, int phase, int c, bool need_release) {
   const int w = p.ctx.num_ranks, rank = p.ctx.rank;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (need_release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  drain_stores();
   __syncthreads();
   const int t = threadIdx.x;
   if (t < w && t != rank) {
@@ -159,12 +162,13 @@ __global__ __launch_bounds__(512) void allreduce_one_shot_kernel(ArParams p) {
   const long long e0 = min((long long)c * per, p.n), e1 = min(e0 + per, p.n);
   const T* in = (const T*)p.in;
   T* ws = (T*)p.ws;
+  bool plain = false;
   for (int i = 1; i < w; ++i) {
     const int peer = (rank + i) % w;
     T* dst = symm_at(p.ctx, ws, peer) + (long long)rank * p.cap + e0;
-    shmem::copy_bytes(dst, in + e0, (size_t)(e1 - e0) * sizeof(T), threadIdx.x, blockDim.x);
+    plain |= shmem::copy_bytes_wt_sys(dst, in + e0, (size_t)(e1 - e0) * sizeof(T), threadIdx.x, blockDim.x);
   }
-  exchange_flags(p, 0, c);
+  exchange_flags(p, 0, c, plain);
   sum_slices<T>(p, in, ws, p.cap, (T*)p.out, e0, e1);
 }
 
@@ -179,15 +183,17 @@ __global__ __launch_bounds__(512) void allreduce_two_shot_kernel(ArParams p) {
   T* recv = (T*)p.ws;                         // [w][ce]
   T* gather = recv + (long long)w * ce;       // [w][ce]
   // phase 1: reduce-scatter pushes
+  bool plain = false;
   for (int i = 1; i < w; ++i) {
     const int peer = (rank + i) % w;
     const long long g0 = min(peer * ce + s0, p.n), g1 = min(peer * ce + s1, p.n);
     if (g1 > g0) {
       T* dst = symm_at(p.ctx, recv, peer) + (long long)rank * ce + s0;
-      shmem::copy_bytes(dst, in + g0, (size_t)(g1 - g0) * sizeof(T), threadIdx.x, blockDim.x);
+      plain |= shmem::copy_bytes_wt_sys(dst, in + g0, (size_t)(g1 - g0) * sizeof(T), threadIdx.x, blockDim.x);
     }
   }
-  exchange_flags(p, 0, c);
+  exchange_flags(p, 0, c, plain);
+  plain = false;
   // reduce own chunk's sub-slice into the local gather buffer, then broadcast it
   {
     const long long g0 = min(rank * ce + s0, p.n), g1 = min(rank * ce + s1, p.n);
@@ -198,12 +204,12 @@ __global__ __launch_bounds__(512) void allreduce_two_shot_kernel(ArParams p) {
       for (int i = 1; i < w; ++i) {
         const int peer = (rank + i) % w;
         T* dst = symm_at(p.ctx, gather, peer) + (long long)rank * ce + s0;
-        shmem::copy_bytes(dst, gather + (long long)rank * ce + s0, (size_t)(g1 - g0) * sizeof(T), threadIdx.x,
-                          blockDim.x);
+        plain |= shmem::copy_bytes_wt_sys(dst, gather + (long long)rank * ce + s0, (size_t)(g1 - g0) * sizeof(T),
+                                          threadIdx.x, blockDim.x);
       }
     }
   }
-  exchange_flags(p, 1, c);
+  exchange_flags(p, 1, c, plain);
   // phase 2: every chunk's sub-slice is now in the local gather buffer
   for (int s = 0; s < w; ++s) {
     const long long g0 = min(s * ce + s0, p.n), g1 = min(s * ce + s1, p.n);

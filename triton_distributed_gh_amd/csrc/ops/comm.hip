@@ -11,6 +11,7 @@
 // kernels/nvidia/ep_a2a.py:36-320 (dispatch / combine / splits / bincount),
 // kernels/nvidia/p2p.py:30-85.  NUMA / multi-node / multimem variants have nothing to map to inside
 // one full-mesh xGMI node and are served by the same kernels.
+#include "tdist/cache_policy.hpp"
 #include "tdist/common.hpp"
 #include "tdist/primitives.hpp"
 #include "tdist/shmem_device.hpp"
@@ -40,17 +41,15 @@ __global__ __launch_bounds__(512) void allgather_push_kernel(AgParams p) {
   const long long b0 = min((long long)slice * per, p.bytes_per_rank), b1 = min(b0 + per, p.bytes_per_rank);
   char* src = p.buf + rank * p.bytes_per_rank;
   char* dst = symm_at(p.ctx, p.buf, peer) + rank * p.bytes_per_rank;
-  shmem::copy_bytes(dst + b0, src + b0, (size_t)(b1 - b0), threadIdx.x, blockDim.x);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // write-through stores: publishing is drain + barrier + counter (no release fence unless an
+  // unaligned shard forced plain stores)
+  const bool plain = shmem::copy_bytes_wt_sys(dst + b0, src + b0, (size_t)(b1 - b0), threadIdx.x, blockDim.x);
+  if (plain) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  drain_stores();
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int prev = atom_add_acqrel_agent(p.local_cnt + peer, 1);
-    if (prev == p.slices - 1) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      store_relaxed_system(symm_at(p.ctx, p.flags, peer) + rank, p.epoch);
-    }
+    const int prev = atom_add_relaxed_agent(p.local_cnt + peer, 1);
+    if (prev == p.slices - 1) store_relaxed_system(symm_at(p.ctx, p.flags, peer) + rank, p.epoch);
   }
   __syncthreads();
   // every workgroup waits for the shard of "its" peer, so kernel completion = all shards present
@@ -154,10 +153,12 @@ struct A2AParams {
   unsigned long long call_count;
 };
 
-__device__ __forceinline__ void a2a_copy_slice(char* dst, const char* src, long long total, int slice, int slices) {
+// Returns true when part of the slice went out as plain (not write-through) stores.
+__device__ __forceinline__ bool a2a_copy_slice(char* dst, const char* src, long long total, int slice, int slices) {
   const long long per = ((total + slices - 1) / slices + 15) & ~15ll;
   const long long b0 = min((long long)slice * per, total), b1 = min(b0 + per, total);
-  if (b1 > b0) shmem::copy_bytes(dst + b0, src + b0, (size_t)(b1 - b0), threadIdx.x, blockDim.x);
+  if (b1 <= b0) return false;
+  return shmem::copy_bytes_wt_sys(dst + b0, src + b0, (size_t)(b1 - b0), threadIdx.x, blockDim.x);
 }
 
 __global__ __launch_bounds__(1024) void all_to_all_kernel(A2AParams p) {
@@ -171,28 +172,32 @@ __global__ __launch_bounds__(1024) void all_to_all_kernel(A2AParams p) {
   if ((m_st != c_st || rows != c_ed - c_st) && threadIdx.x == 0) atomicOr(p.err, 2);
   const long long slot_row = (long long)half * w * p.max_m + (long long)rank * p.max_m;
   char* dst = symm_at(p.ctx, p.recv_buf, pid) + slot_row * p.row_bytes;
-  a2a_copy_slice(dst, p.send_buf + (long long)m_st * p.row_bytes, (long long)rows * p.row_bytes, slice, p.slices);
+  // Payload, scales and splits all leave as write-through system-scope stores, so publishing is
+  // drain + barrier + counter; a release fence (a walk over the whole L2) is only paid when an
+  // unaligned operand forced plain stores.
+  bool plain = a2a_copy_slice(dst, p.send_buf + (long long)m_st * p.row_bytes, (long long)rows * p.row_bytes, slice,
+                              p.slices);
   if (p.send_scale) {
     float* sd = symm_at(p.ctx, p.recv_scale, pid) + slot_row * p.scale_elems;
-    a2a_copy_slice((char*)sd, (const char*)(p.send_scale + (long long)m_st * p.scale_elems),
-                   (long long)rows * p.scale_elems * (long long)sizeof(float), slice, p.slices);
+    plain |= a2a_copy_slice((char*)sd, (const char*)(p.send_scale + (long long)m_st * p.scale_elems),
+                            (long long)rows * p.scale_elems * (long long)sizeof(float), slice, p.slices);
   }
   if (slice == 0) {
     int* sp = symm_at(p.ctx, p.split_buf, pid) + half * w * p.epr + rank * p.epr;
     for (int e = threadIdx.x; e < p.epr; e += blockDim.x)
-      sp[e] = p.cumsum[pid * p.epr + e + 1] - p.cumsum[pid * p.epr + e];
+      store_relaxed_system(sp + e, p.cumsum[pid * p.epr + e + 1] - p.cumsum[pid * p.epr + e]);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (plain) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  drain_stores();
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int prev = atom_add_acqrel_agent(p.done + pid, 1);
+    // relaxed: every slice's stores were drained before its add, and the add that completes the
+    // destination is ordered after all earlier adds on the word
+    const int prev = atom_add_relaxed_agent(p.done + pid, 1);
     if (prev == p.slices - 1) {
       // last slice of this destination: re-arm the counter for the next call (nobody else touches
       // it any more in this launch), then publish
       store_relaxed_agent(p.done + pid, 0);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       store_relaxed_system(symm_at(p.ctx, p.signal, pid) + half * w + rank, p.call_count);
     }
     if (slice == 0) {
