@@ -300,25 +300,28 @@ __global__ __launch_bounds__(512) void ag_push_kernel(AgPushParams p) {
   const long long dst_off = ((long long)rank * p.M_per_rank + (long long)chunk * p.rows_per_chunk) * p.row_bytes + b0;
   // Rotate the peer order per workgroup so that at any moment the workgroups of this kernel are
   // spread over all w-1 xGMI links instead of all writing to the same peer.
+  // write-through stores (payload leaves the L2 at once): publishing is drain + barrier + counter;
+  // a release fence is only needed if an unaligned shard forced plain stores
+  bool plain = false;
   if (p.include_self) {
     char* dst = (char*)p.ws + dst_off;
-    shmem::copy_bytes(dst, src, (size_t)(b1 - b0), threadIdx.x, blockDim.x);
+    plain |= shmem::copy_bytes_wt_sys(dst, src, (size_t)(b1 - b0), threadIdx.x, blockDim.x);
   }
   for (int i = 0; i < w - 1; ++i) {
     const int peer = (rank + 1 + (i + blockIdx.x) % (w - 1)) % w;
     char* dst = (char*)symm_at(p.ctx, p.ws, peer) + dst_off;
-    shmem::copy_bytes(dst, src, (size_t)(b1 - b0), threadIdx.x, blockDim.x);
+    plain |= shmem::copy_bytes_wt_sys(dst, src, (size_t)(b1 - b0), threadIdx.x, blockDim.x);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (plain) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  drain_stores();
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int prev = atom_add_acqrel_agent(p.done_count + chunk, 1);
+    const int prev = atom_add_relaxed_agent(p.done_count + chunk, 1);
     if (prev == p.slices - 1) {
       const int cpr = p.M_per_rank / p.rows_per_chunk;
       for (int i = p.include_self ? 0 : 1; i < w; ++i) {
         const int peer = (rank + i) % w;
-        store_release_system(symm_at(p.ctx, p.flags, peer) + rank * cpr + chunk, p.epoch);
+        store_relaxed_system(symm_at(p.ctx, p.flags, peer) + rank * cpr + chunk, p.epoch);
       }
     }
   }

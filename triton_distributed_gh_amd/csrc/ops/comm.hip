@@ -254,6 +254,7 @@ __global__ __launch_bounds__(512) void ep_dispatch_kernel(EpDispatchParams p) {
   const int waves_per_block = blockDim.x / 64;
   const int lane = threadIdx.x & 63;
   const long long total = (long long)p.T * p.topk;
+  bool plain = false;
   for (long long item = (long long)blockIdx.x * waves_per_block + (threadIdx.x >> 6); item < total;
        item += (long long)gridDim.x * waves_per_block) {
     const int t = (int)(item / p.topk);
@@ -263,17 +264,16 @@ __global__ __launch_bounds__(512) void ep_dispatch_kernel(EpDispatchParams p) {
     if (lane == 0) slot = p.dst_base[e] + atomicAdd(p.cursor + e, 1);
     slot = __shfl(slot, 0);
     char* dst = symm_at(p.ctx, p.recv_buf, d) + (long long)slot * p.row_bytes;
-    shmem::copy_bytes(dst, p.tokens + (long long)t * p.row_bytes, (size_t)p.row_bytes, lane, 64);
+    plain |= shmem::copy_bytes_wt_sys(dst, p.tokens + (long long)t * p.row_bytes, (size_t)p.row_bytes, lane, 64);
     if (lane == 0) p.scatter_idx[item] = slot;
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // token rows went out write-through; a release fence only if unaligned rows forced plain stores
+  if (plain) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  drain_stores();
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int prev = atom_add_acqrel_agent(p.done, 1);
+    const int prev = atom_add_relaxed_agent(p.done, 1);
     if (prev == (int)gridDim.x - 1) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       for (int r = 0; r < w; ++r) store_relaxed_system(symm_at(p.ctx, p.flags, r) + p.ctx.rank, p.epoch);
     }
   }

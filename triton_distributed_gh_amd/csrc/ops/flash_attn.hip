@@ -16,6 +16,7 @@
 // or zig-zag (rank r owns half-blocks r and 2w-1-r), and the kernel can wait on per-source-rank
 // arrival flags right before it first touches a rank's slab of the gathered KV, so attention
 // over early slabs overlaps the rest of the gather (the reference joins the streams instead).
+#include "tdist/cache_policy.hpp"
 #include "tdist/common.hpp"
 #include "tdist/atomics.hpp"
 #include "tdist/gemm_gfx950.hpp"
@@ -323,18 +324,19 @@ __global__ __launch_bounds__(256) void sp_kv_push_kernel(KvPushArgs p) {
       }
       const long long dst = ((long long)p.cu_full[b] + g) * p.row_bytes + ch * 16;
       const long long src = (long long)row * p.row_bytes + ch * 16;
-      *(uint4*)(kd + dst) = *(const uint4*)((const char*)p.k_shard + src);
-      *(uint4*)(vd + dst) = *(const uint4*)((const char*)p.v_shard + src);
+      const uint4 kq = *(const uint4*)((const char*)p.k_shard + src);
+      const uint4 vq = *(const uint4*)((const char*)p.v_shard + src);
+      st_wt128_sys(kd + dst, kq);      // write-through: no release fence before the flags
+      st_wt128_sys(vd + dst, vq);
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  drain_stores();
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int prev = atom_add_acqrel_agent(p.done, 1);
+    const int prev = atom_add_relaxed_agent(p.done, 1);
     if (prev == (int)gridDim.x - 1) {
-      *p.done = 0;
-      for (int i = 0; i < w; ++i) store_release_system(symm_at(p.ctx, p.flags, (rank + i) % w) + rank, p.epoch);
+      store_relaxed_agent(p.done, 0);
+      for (int i = 0; i < w; ++i) store_relaxed_system(symm_at(p.ctx, p.flags, (rank + i) % w) + rank, p.epoch);
     }
   }
 }
