@@ -36,6 +36,22 @@ run $N/test_compile_aot.py
 run $N/test_pp.py --virtual-ranks 2 --heap-mb 256 --check
 run $N/test_tp_attn.py --model tdist/tiny-dense --bsz 8 --seq_len 32 $V --check
 run $N/test_tp_moe.py --M 256 --model tdist/tiny-moe $V --check
+run $N/test_ag_small_msg.py $V --check
+run $N/test_ag_small_msg.py $V --iters 5
+run $N/test_notify.py $V
+run $N/test_ring_put.py $V
+run $N/test_multimem_ld_reduce.py $V
+run $N/test_nvshmem_api.py
+run $N/test_team_split.py
+run $N/test_simt.py
+run $N/test_utils.py
+run $N/test_language_extra.py
+run $N/test_distributed_wait.py --case lower
+run $N/test_distributed_wait.py --case correctness
+run $N/test_distributed_wait.py --case perf
+run $N/test_perf_ring_reduce_tma.py
+run $N/test_ep_moe_inference.py -M 64 -N 256 -I 128 -G 2 --topk 2 $V --check
+run $N/test_sp_ag_attention_inter_node.py $V --check --seqlens 512 1024
 run $A/test_wait_and_notify.py $V
 run $A/test_libdevice.py
 run $A/test_rocshmem_api.py $V

@@ -17,12 +17,20 @@ CASES = [
     ["triton_dist/test/amd/test_ag_gemm_intra_node.py", "256", "128", "64", "--virtual-ranks", "2", "--check"],
     ["triton_dist/test/amd/test_gemm_rs_intra_node.py", "256", "128", "64", "--virtual-ranks", "2", "--check"],
     ["triton_dist/test/amd/test_barrier_all.py", "--virtual-ranks", "3", "--rounds", "3"],
+    ["triton_dist/test/nvidia/test_ag_small_msg.py", "--virtual-ranks", "3", "--check", "--max-nbytes", "4096"],
+    ["triton_dist/test/nvidia/test_notify.py", "--virtual-ranks", "3", "--rounds", "2"],
+    ["triton_dist/test/nvidia/test_ring_put.py", "--virtual-ranks", "4", "-n", "256"],
+    ["triton_dist/test/nvidia/test_multimem_ld_reduce.py", "--virtual-ranks", "3", "-n", "1000"],
+    ["triton_dist/test/nvidia/test_nvshmem_api.py", "-n", "64"],
+    ["triton_dist/test/nvidia/test_team_split.py"],
+    ["triton_dist/test/nvidia/test_simt.py"],
+    ["triton_dist/test/nvidia/test_utils.py"],
 ]
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0].split("/")[-1] for c in CASES])
 def test_script_runs(case):
-    env = {"CUDA_VISIBLE_DEVICES": "", "HIP_VISIBLE_DEVICES": "", "PATH": "/usr/bin:/bin:/usr/local/bin",
+    env = {"CUDA_VISIBLE_DEVICES": "", "HIP_VISIBLE_DEVICES": "", "PATH": "/usr/bin:/bin:/usr/local/bin:/opt/rocm/bin",
            "RANDOM_PARAMS": "1", "TDIST_NO_HF_CONFIG": "1", "HOME": "/tmp"}
     res = subprocess.run([sys.executable, *case], cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
     assert res.returncode == 0 and "✅" in res.stdout, (res.stdout + res.stderr)[-2000:]
