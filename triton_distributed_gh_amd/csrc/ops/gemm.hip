@@ -6,6 +6,8 @@
 //
 // Role in the reference: `tl.dot` matmul kernels of python/triton_dist/test/amd/test_matmul_amd.py
 // and my_lab/benchmark/layer.py:20-64 (y = x W^T).
+#include <stdlib.h>
+
 #include "tdist/common.hpp"
 #include "tdist/gemm_gfx950.hpp"
 
@@ -46,6 +48,113 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_256_kernel(const uint16_t*
   });
 }
 
+// Decode-shaped GEMM (M <= 16): the weights are streamed exactly once with non-temporal 16-byte
+// loads and feed 16x16x32 MFMAs whose M dimension is the zero-padded batch.  A workgroup of four
+// waves covers BN = 16 * WN output columns (WN = 1 / 2 / 4); wave k owns the k-th quarter of K for
+// ALL of the workgroup's columns, so one activation fragment feeds WN MFMAs and the activations
+// (at most 16 x K, L2 resident) are read once per workgroup instead of once per column group.  Each
+// lane keeps sixteen 16-byte weight loads in flight.  The four K-quarters are summed through LDS, one
+// column group per wave.
+template <bool IS_BF16, int WN>
+__global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(const uint16_t* __restrict__ X,
+                                                             const uint16_t* __restrict__ W,
+                                                             uint16_t* __restrict__ C, int M, int N, int K,
+                                                             long long ldx, long long ldw, long long ldc) {
+  using F = Frag<IS_BF16>;
+  using VT = typename F::T;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  constexpr int BN_ = 16 * WN;
+  constexpr int U = 16 / WN;                             // K-steps per batch of loads (16 weight loads in flight)
+  __shared__ float red[4 * WN * 64 * 4];                 // [K quarter][column group][lane][4]
+  const int wk = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int li = lane & 15, lg = lane >> 4;
+  const int n0 = blockIdx.x * BN_;
+  const int ksteps = K / 32;
+  const int per = (ksteps + 3) / 4;
+  const int ks0 = min(wk * per, ksteps), ks1 = min(ks0 + per, ksteps);
+  const uint16_t* xr = X + (long long)min(li, M - 1) * ldx + lg * 8;
+  const uint16_t* wr[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j)                            // clamped: out-of-range columns are not stored
+    wr[j] = W + (long long)min(n0 + j * 16 + li, N - 1) * ldw + lg * 8;
+  const bool xvalid = li < M;
+  f32x4 acc[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int ks = ks0;
+  for (; ks + U <= ks1; ks += U) {
+    u32x4 wv[U][WN], xv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) wv[u][j] = __builtin_nontemporal_load((const u32x4*)(wr[j] + (ks + u) * 32));
+#pragma unroll
+    for (int u = 0; u < U; ++u) xv[u] = xvalid ? *(const u32x4*)(xr + (ks + u) * 32) : u32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+        acc[j] = F::mfma(__builtin_bit_cast(VT, xv[u]), __builtin_bit_cast(VT, wv[u][j]), acc[j]);
+  }
+  for (; ks < ks1; ++ks) {
+    const u32x4 xv = xvalid ? *(const u32x4*)(xr + ks * 32) : u32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const u32x4 wv = __builtin_nontemporal_load((const u32x4*)(wr[j] + ks * 32));
+      acc[j] = F::mfma(__builtin_bit_cast(VT, xv), __builtin_bit_cast(VT, wv), acc[j]);
+    }
+  }
+  // accumulator: row (token) = 4*lg + r, column = li of group j.  Wave g sums column group g.
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    float* slot = red + ((wk * WN + j) * 64 + lane) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) slot[r] = acc[j][r];
+  }
+  __syncthreads();
+  if (wk >= WN) return;
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float* o = red + ((q * WN + wk) * 64 + lane) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sum[r] += o[r];
+  }
+  // lanes li and li^1 hold neighbouring columns: the even lane stores both (N, ldc are even)
+  const int col = n0 + wk * 16 + li;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * lg + r;
+    const float mine = sum[r];
+    const float other = __shfl_xor(mine, 1);
+    if (row < M && col < N && (li & 1) == 0) *(uint32_t*)(C + (long long)row * ldc + col) = F::pack2(mine, other);
+  }
+}
+
+template <bool IS_BF16>
+static void launch_skinny(const void* A, const void* B, void* C, int M, int N, int K, long long lda, long long ldb,
+                          long long ldc, hipStream_t s) {
+  // Column-block size (measured on MI355X, K 2048..12288): with 1-4 tokens the activation loads
+  // are negligible and small blocks (more workgroups) win; with more tokens sharing one activation
+  // fragment between 2-4 column groups pays as soon as the grid still has a few hundred workgroups.
+  int bn;
+  if (M <= 4)
+    bn = N >= 16384 ? 32 : 16;
+  else
+    bn = N >= 32768 ? 64 : (N >= 6144 ? 32 : 16);
+  static const int forced = getenv("TDIST_SKINNY_BN") ? atoi(getenv("TDIST_SKINNY_BN")) : 0;   // tuning knob
+  if (forced == 16 || forced == 32 || forced == 64) bn = forced;
+  const dim3 grid((N + bn - 1) / bn);
+  const uint16_t *a = (const uint16_t*)A, *b = (const uint16_t*)B;
+  uint16_t* c = (uint16_t*)C;
+  if (bn == 64)
+    hipLaunchKernelGGL((gemm_nt_skinny_kernel<IS_BF16, 4>), grid, dim3(256), 0, s, a, b, c, M, N, K, lda, ldb, ldc);
+  else if (bn == 32)
+    hipLaunchKernelGGL((gemm_nt_skinny_kernel<IS_BF16, 2>), grid, dim3(256), 0, s, a, b, c, M, N, K, lda, ldb, ldc);
+  else
+    hipLaunchKernelGGL((gemm_nt_skinny_kernel<IS_BF16, 1>), grid, dim3(256), 0, s, a, b, c, M, N, K, lda, ldb, ldc);
+}
+
 // dtype: 0 = bf16, 1 = fp16.  Requires K % 64 == 0, K >= 128, N % 8 == 0, 16-byte aligned rows.
 TDIST_API int tdist_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, long long lda,
                             long long ldb, long long ldc, int dtype, int group_m, void* stream, int variant) {
@@ -53,6 +162,14 @@ TDIST_API int tdist_gemm_nt(const void* A, const void* B, void* C, int M, int N,
   TDIST_REQUIRE(K >= 128 && K % 64 == 0, "K must be a multiple of 64 and >= 128");
   TDIST_REQUIRE(N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0, "N/lda/ldb/ldc must be multiples of 8");
   TDIST_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0, "operands must be 16-byte aligned");
+  if (M <= 16 && !((variant >> 8) & 2)) {   // (debug bit 1 of the variant's second byte forces the tile kernel)
+    if (dtype == 0)
+      launch_skinny<true>(A, B, C, M, N, K, lda, ldb, ldc, (hipStream_t)stream);
+    else
+      launch_skinny<false>(A, B, C, M, N, K, lda, ldb, ldc, (hipStream_t)stream);
+    TDIST_HIP_TRY(hipGetLastError());
+    return 0;
+  }
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   if (group_m <= 0) group_m = 8;
   typedef void (*kern_t)(const uint16_t*, const uint16_t*, uint16_t*, int, int, int, long long, long long, long long, int, int);

@@ -1,7 +1,9 @@
 """Single-GPU 16-bit GEMM on the gfx950 MFMA tile engine:  C = A @ B^T.
 
 ``gemm_nt(a, b)`` takes ``a [M, K]`` and ``b [N, K]`` (both K-contiguous - the layout every fused
-op in this package uses for weights) and returns ``[M, N]``.  Shapes the hand-written kernel does
+op in this package uses for weights) and returns ``[M, N]``.  M <= 16 runs the decode kernel
+(weights streamed once through 16x16x32 MFMAs, K split inside the workgroup), everything else the
+256x256 tile kernel.  Shapes the hand-written kernel does
 not cover (K % 64 != 0, K < 128, N % 8 != 0, other dtypes) and CPU tensors go to ``torch.matmul``.
 
 Role in the reference: Triton matmul of python/triton_dist/test/amd/test_matmul_amd.py and the
@@ -48,6 +50,12 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     if not gemm_supported(a, b) or out.stride(1) != 1 or out.stride(0) % 8 or out.data_ptr() % 16:
         if force_native:
             raise ValueError("shape/dtype not supported by the gfx950 GEMM kernel")
+        torch.matmul(a, b.t(), out=out)
+        return out
+    # Between the decode kernel (M <= 16, weights streamed once) and shapes that fill the chip with
+    # 256x256 tiles lies a band (17..255 rows x few column tiles) where the big tile leaves most
+    # CUs idle; a plain library GEMM is the right tool there.
+    if not force_native and M > 16 and -(-M // 256) * -(-N // 256) < 128:
         torch.matmul(a, b.t(), out=out)
         return out
     lib = _lib.hip()

@@ -36,6 +36,7 @@ class Runner:
     def __init__(self, args):
         self.args = args
         self.vc = None
+        self._harness_ms = None
         if args.virtual_ranks and args.virtual_ranks > 0 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
             # Every virtual rank's two streams need hardware queues of their own: kernels that
             # share a queue start in order with limited overlap, so a rank spinning on a peer
@@ -101,9 +102,13 @@ class Runner:
 
         cuda = self.device.type == "cuda"
         if self.virtual and cuda:
-            # gate-released, one call per rank in flight; median over the iterations (host clock)
+            # gate-released, one call per rank in flight; median over the iterations (host clock),
+            # net of what the same harness measures for an empty call (event wake-up + device sync)
+            if self._harness_ms is None:
+                base = sorted(self.vc.timed_run(lambda r, env: None) for _ in range(15))
+                self._harness_ms = base[len(base) // 2]
             per_iter = sorted(self.vc.timed_run(fn) for _ in range(iters))
-            return per_iter[len(per_iter) // 2]
+            return max(per_iter[len(per_iter) // 2] - self._harness_ms, 1e-4)
         if self.virtual:
             t0 = _t.perf_counter()
             for _ in range(iters):
