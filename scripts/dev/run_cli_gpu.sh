@@ -59,5 +59,12 @@ run $A/test_matmul_amd.py --check
 run $A/test_matmul_amd.py -M 4096 -N 8192 -K 8192 --iters 20
 run $A/test_extern_functions.py
 run $A/test_hip_lds.py
+G=triton_dist/mega_triton_kernel/test
+run $G/ops/test_add.py
+run $G/ops/test_rms_norm.py
+run $G/ops/test_mlp_layer.py
+run $G/ops/test_page_attn.py
+run $G/ops/test_allreduce.py 4
+run $G/models/test_qwen3.py 1
 grep -E "^== |^-- rc|✅" "$out" | paste - - - 2>/dev/null | grep -v "rc=0" | head -40
 echo "passed: $(grep -c '^-- rc=0' "$out") of $(grep -c '^== ' "$out")"
