@@ -50,13 +50,14 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_256_kernel(const uint16_t*
 
 // Decode-shaped GEMM (M <= 16): the weights are streamed exactly once with non-temporal 16-byte
 // loads and feed 16x16x32 MFMAs whose M dimension is the zero-padded batch.  A workgroup of four
-// waves covers BN = 16 * WN output columns (WN = 1 / 2 / 4); wave k owns the k-th quarter of K for
-// ALL of the workgroup's columns, so one activation fragment feeds WN MFMAs and the activations
+// (or eight, NW) waves covers BN = 16 * WN output columns (WN = 1 / 2 / 4); wave k owns the k-th slice
+// of K for ALL of the workgroup's columns, so one activation fragment feeds WN MFMAs and the activations
 // (at most 16 x K, L2 resident) are read once per workgroup instead of once per column group.  Each
-// lane keeps sixteen 16-byte weight loads in flight.  The four K-quarters are summed through LDS, one
-// column group per wave.
-template <bool IS_BF16, int WN>
-__global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(const uint16_t* __restrict__ X,
+// lane keeps sixteen 16-byte weight loads in flight.  The K slices are summed through LDS, one
+// column group per wave.  Eight waves are used when the grid alone cannot fill the chip (short N)
+// and K is long enough to give every wave a few batches of loads.
+template <bool IS_BF16, int WN, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const uint16_t* __restrict__ X,
                                                              const uint16_t* __restrict__ W,
                                                              uint16_t* __restrict__ C, int M, int N, int K,
                                                              long long ldx, long long ldw, long long ldc) {
@@ -65,12 +66,12 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(const uint16_t* __r
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
   constexpr int BN_ = 16 * WN;
   constexpr int U = 16 / WN;                             // K-steps per batch of loads (16 weight loads in flight)
-  __shared__ float red[4 * WN * 64 * 4];                 // [K quarter][column group][lane][4]
+  __shared__ float red[NW * WN * 64 * 4];                // [K slice][column group][lane][4]
   const int wk = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int li = lane & 15, lg = lane >> 4;
   const int n0 = blockIdx.x * BN_;
   const int ksteps = K / 32;
-  const int per = (ksteps + 3) / 4;
+  const int per = (ksteps + NW - 1) / NW;
   const int ks0 = min(wk * per, ksteps), ks1 = min(ks0 + per, ksteps);
   const uint16_t* xr = X + (long long)min(li, M - 1) * ldx + lg * 8;
   const uint16_t* wr[WN];
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(const uint16_t* __r
   if (wk >= WN) return;
   f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < NW; ++q) {
     const float* o = red + ((q * WN + wk) * 64 + lane) * 4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) sum[r] += o[r];
@@ -145,14 +146,17 @@ static void launch_skinny(const void* A, const void* B, void* C, int M, int N, i
   static const int forced = getenv("TDIST_SKINNY_BN") ? atoi(getenv("TDIST_SKINNY_BN")) : 0;   // tuning knob
   if (forced == 16 || forced == 32 || forced == 64) bn = forced;
   const dim3 grid((N + bn - 1) / bn);
+  const bool wide = bn == 16 && grid.x < 1024 && K >= 4096;      // 8 waves: twice the loads in flight per workgroup
   const uint16_t *a = (const uint16_t*)A, *b = (const uint16_t*)B;
   uint16_t* c = (uint16_t*)C;
   if (bn == 64)
-    hipLaunchKernelGGL((gemm_nt_skinny_kernel<IS_BF16, 4>), grid, dim3(256), 0, s, a, b, c, M, N, K, lda, ldb, ldc);
+    hipLaunchKernelGGL((gemm_nt_skinny_kernel<IS_BF16, 4, 4>), grid, dim3(256), 0, s, a, b, c, M, N, K, lda, ldb, ldc);
   else if (bn == 32)
-    hipLaunchKernelGGL((gemm_nt_skinny_kernel<IS_BF16, 2>), grid, dim3(256), 0, s, a, b, c, M, N, K, lda, ldb, ldc);
+    hipLaunchKernelGGL((gemm_nt_skinny_kernel<IS_BF16, 2, 4>), grid, dim3(256), 0, s, a, b, c, M, N, K, lda, ldb, ldc);
+  else if (wide)
+    hipLaunchKernelGGL((gemm_nt_skinny_kernel<IS_BF16, 1, 8>), grid, dim3(512), 0, s, a, b, c, M, N, K, lda, ldb, ldc);
   else
-    hipLaunchKernelGGL((gemm_nt_skinny_kernel<IS_BF16, 1>), grid, dim3(256), 0, s, a, b, c, M, N, K, lda, ldb, ldc);
+    hipLaunchKernelGGL((gemm_nt_skinny_kernel<IS_BF16, 1, 4>), grid, dim3(256), 0, s, a, b, c, M, N, K, lda, ldb, ldc);
 }
 
 // dtype: 0 = bf16, 1 = fp16.  Requires K % 64 == 0, K >= 128, N % 8 == 0, 16-byte aligned rows.
