@@ -1,4 +1,4 @@
-"""Single-step decode latency: torch eager / torch + HIP graph / mega kernel.
+"""Single-step decode latency: torch eager / torch + HIP graph / native layers + HIP graph / mega kernel.
 
 Scenario of the reference's mega_triton_kernel/test/models/bench_qwen3.py:113-153 (bs=1, ctx=512;
 published numbers in docs/mega_triton_kernel.md:32-39 are for TP=8 on H800 / H20).  Random weights.
@@ -64,6 +64,20 @@ def main():
             eager()
         _, t_graph = perf_func(g.replay, args.iters, 5)
         res["torch_graph_ms"] = round(t_graph, 4)
+        # same layer stack with every projection on this package's GEMM kernels (decode kernel for
+        # M <= 16), one HIP graph per step: the reference's "triton_dist_AR + cudagraph" column
+        model.set_fwd("triton_dist_AR")
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                eager()
+        torch.cuda.current_stream().wait_stream(s)
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            eager()
+        _, t_native = perf_func(g2.replay, args.iters, 5)
+        res["native_layers_graph_ms"] = round(t_native, 4)
+        model.set_fwd("torch")
     mega = Qwen3Model(model, B, L, page_size=64, num_queues=args.queues, scheduler=args.scheduler, env=env)
     mega.kv_cache.rand_fill_kv_cache(args.ctx)
 
