@@ -1,0 +1,62 @@
+"""Persistent GEMM (variant 3, register-direct epilogue) vs the one-tile-per-workgroup kernel (variant 2)
+and torch.matmul: correctness on full and ragged shapes, then an interleaved timing at the headline shape."""
+import sys
+import torch
+sys.path.insert(0, "/root/repo")
+from triton_distributed_gh_amd.ops.gemm import gemm_nt
+
+
+def timeit(fn, iters):
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3
+
+
+ok = True
+for (M, N, K) in [(256, 256, 128), (512, 768, 256), (300, 520, 192), (4096, 8192, 1024), (1000, 8200, 512), (4096, 1024, 8192)]:
+    for dt in (torch.bfloat16, torch.float16):
+        a = (torch.rand(M, K, device="cuda") * 2 - 1).to(dt)
+        b = (torch.rand(N, K, device="cuda") * 2 - 1).to(dt)
+        out = torch.full((M, N), 7.0, device="cuda", dtype=dt)
+        gemm_nt(a, b, out=out, force_native=True, variant=3)
+        ref = a.float() @ b.float().t()
+        err = ((out.float() - ref).abs().max() / ref.abs().max()).item()
+        good = err < 1e-2
+        ok &= good
+        print(f"{M}x{N}x{K} {dt}: rel err {err:.2e} {'ok' if good else 'FAIL'}", flush=True)
+if not ok:
+    sys.exit(1)
+
+M, N, K = 4096, 8192, 8192
+a = (torch.rand(M, K, device="cuda") * 2 - 1).bfloat16()
+b = (torch.rand(N, K, device="cuda") * 2 - 1).bfloat16()
+out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+ref = a.float() @ b.float().t()
+fns = {"v2": lambda: gemm_nt(a, b, out=out, force_native=True, variant=2)}
+for opt in range(8):
+    v = 3 | (opt << 16)
+    out.zero_()
+    gemm_nt(a, b, out=out, force_native=True, variant=v)
+    err = ((out.float() - ref).abs().max() / ref.abs().max()).item()
+    print(f"opt {opt}: rel err {err:.2e}", flush=True)
+    if err > 1e-2:
+        sys.exit(1)
+    fns[f"v3o{opt}"] = (lambda vv: (lambda: gemm_nt(a, b, out=out, force_native=True, variant=vv)))(v)
+fns["torch"] = lambda: torch.matmul(a, b.t(), out=out)
+del ref
+for _ in range(40):
+    for f in fns.values():
+        f()
+res = {k: [] for k in fns}
+for rnd in range(6):
+    for k, f in fns.items():
+        res[k].append(timeit(f, 50))
+fl = 2.0 * M * N * K
+for k, v in res.items():
+    v = sorted(v)
+    med = v[len(v) // 2]
+    print(f"{k:6s} median {med:.1f} us ({fl / med / 1e6:.0f} TF) min {v[0]:.1f} max {v[-1]:.1f}", flush=True)

@@ -22,6 +22,32 @@ def test_gemm_nt_matches_fp32_reference(M, N, K, dtype):
     assert rel < 1e-2
 
 
+@pytest.mark.parametrize("M,N,K", SHAPES + [(4096, 4096, 512), (1000, 8200, 256)])
+@pytest.mark.parametrize("knobs", [0, 3])
+def test_persistent_gemm_matches_fp32_reference(M, N, K, knobs):
+    """Variant 3: persistent workgroups, permuted accumulator columns, stores straight from registers
+    (more than one tile per workgroup at the larger shapes, ragged edges, untouched padding)."""
+    torch.manual_seed(M + N * 5 + K)
+    for dtype in (torch.bfloat16, torch.float16):
+        a = (torch.rand(M, K, device="cuda") * 2 - 1).to(dtype)
+        b = (torch.rand(N, K, device="cuda") * 2 - 1).to(dtype)
+        out = torch.full((M, N + 8), 7.0, device="cuda", dtype=dtype)
+        gemm_nt(a, b, out=out[:, :N], force_native=True, variant=3 | (knobs << 16))
+        ref = a.float() @ b.float().t()
+        rel = (out[:, :N].float() - ref).abs().max().item() / ref.abs().max().item()
+        assert rel < 1e-2
+        assert torch.all(out[:, N:] == 7.0), "wrote past the last column"
+
+
+def test_persistent_gemm_column_permutation_is_undone():
+    # A = I: the output must be exactly B^T, so any column left in the permuted order shows up.
+    K = 256
+    a = torch.eye(K, device="cuda", dtype=torch.bfloat16)
+    b = torch.arange(512 * K, device="cuda", dtype=torch.float32).reshape(512, K).remainder(251).bfloat16()
+    c = gemm_nt(a, b, force_native=True, variant=3)
+    assert torch.equal(c, b.t().contiguous())
+
+
 def test_gemm_nt_asymmetric_identity():
     # A = I with an asymmetric B catches a transposed output or operand mapping.
     K = 256

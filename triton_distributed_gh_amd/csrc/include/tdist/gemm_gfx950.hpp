@@ -264,7 +264,20 @@ __device__ __forceinline__ void mainloop_256(const TileArgs& t, char* smem, Acc<
 // reads A1 and computes the lower 64 rows.  Staging: phase 0 of step t issues A0, A1 of step t+1,
 // phase 1 issues B0, B1 of step t+2 (their slots were read in phase 0 and retired by the counted
 // lgkmcnt before that phase's barrier; A1's reads are retired before phase 1's barrier).
-template <bool IS_BF16>
+//
+// PERM_B permutes which B row (output column) each accumulator register stands for, so that the
+// epilogue can store straight from registers: register r of accumulator tile n in lane group
+// g = lane >> 4 then holds column 32*(n>>1) + 8*g + 4*(n&1) + r of the wave's 64 columns, i.e. tiles
+// (0,1) and (2,3) each give a lane 8 neighbouring columns = one 16-byte store (epilogue_256_direct).
+// The permutation is applied to the per-lane DMA source row and costs nothing.
+//
+// OPT (schedule knobs, bit mask): 1 = in phase 0 the A fragments are waited for one 16-row block at
+// a time inside the MFMA segment (they are consumed in the order they were read) instead of all at
+// once after the barrier, 2 = no s_setprio around the MFMA segment.  Measured at 4096x8192x8192 bf16
+// (MI355X, interleaved with the default): OPT 3 is 0.5-0.8 % faster, each bit alone is neutral.
+// Issuing the LDS-DMA loads between the MFMAs of the compute segment instead of in the read segment
+// was measured 10 % slower and is not kept.
+template <bool IS_BF16, bool PERM_B = false, int OPT = 0>
 __device__ __forceinline__ void mainloop_256_2ph(const TileArgs& t, char* smem, Acc<IS_BF16>& acc) {
   using F = Frag<IS_BF16>;
   using V = typename F::T;
@@ -277,7 +290,9 @@ __device__ __forceinline__ void mainloop_256_2ph(const TileArgs& t, char* smem, 
   const int kchunk = (l & 3) ^ (((l >> 5) & 1) << 1);
   int arow0 = (hr >> 6) * 128 + (hr & 63);
   int arow1 = arow0 + 64;
-  int brow0 = (hr >> 5) * 64 + (hr & 31);
+  // half-tile row hr = 32*wave column + 16*(accumulator tile & 1) + i, i = 4*g + r
+  int brow0 = PERM_B ? (hr >> 5) * 64 + ((hr & 15) >> 2) * 8 + ((hr >> 4) & 1) * 4 + (hr & 3)
+                     : (hr >> 5) * 64 + (hr & 31);
   int brow1 = brow0 + 32;
   arow0 = arow0 < t.a_rows ? arow0 : t.a_rows - 1;
   arow1 = arow1 < t.a_rows ? arow1 : t.a_rows - 1;
@@ -323,6 +338,17 @@ __device__ __forceinline__ void mainloop_256_2ph(const TileArgs& t, char* smem, 
   if (late_group) __builtin_amdgcn_s_barrier();
 
   V a[4][2], b0[2][2], b1[2][2];
+  constexpr bool PROG = (OPT & 1) != 0, NOPRIO = (OPT & 2) != 0;
+  // MFMAs of one 16-row block m of the current 64-row half (both k halves, all four column tiles)
+  auto mfma_row = [&](int m, int mo) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int n = 0; n < 2; ++n) acc.v[mo + m][n] = F::mfma(b0[n][ks], a[m][ks], acc.v[mo + m][n]);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) acc.v[mo + m][2 + n] = F::mfma(b1[n][ks], a[m][ks], acc.v[mo + m][2 + n]);
+    }
+  };
   for (int kt = 0; kt < nt; ++kt) {
     const int boff = (kt & 1) * BUF_BYTES;
     // ---------------- phase 0: rows 0..63 of the wave tile ----------------
@@ -344,19 +370,34 @@ __device__ __forceinline__ void mainloop_256_2ph(const TileArgs& t, char* smem, 
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (!PROG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
+    if constexpr (!NOPRIO) __builtin_amdgcn_s_setprio(1);
+    if constexpr (PROG) {
+      // reads were issued B0 x4, B1 x4, then A0 block by block: two more retire per 16-row block
+      asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+      mfma_row(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+      mfma_row(1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+      mfma_row(2, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      mfma_row(3, 0);
+    } else {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < 4; ++m) {
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc.v[m][n] = F::mfma(b0[n][ks], a[m][ks], acc.v[m][n]);
+          for (int n = 0; n < 2; ++n) acc.v[m][n] = F::mfma(b0[n][ks], a[m][ks], acc.v[m][n]);
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc.v[m][2 + n] = F::mfma(b1[n][ks], a[m][ks], acc.v[m][2 + n]);
-      }
-    __builtin_amdgcn_s_setprio(0);
+          for (int n = 0; n < 2; ++n) acc.v[m][2 + n] = F::mfma(b1[n][ks], a[m][ks], acc.v[m][2 + n]);
+        }
+    }
+    if constexpr (!NOPRIO) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     // ---------------- phase 1: rows 64..127 of the wave tile ----------------
@@ -371,20 +412,23 @@ __device__ __forceinline__ void mainloop_256_2ph(const TileArgs& t, char* smem, 
     } else if (kt + 1 < nt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    // (always complete here: the other wave group restages this buffer's A1 slot one barrier later)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_s_setprio(1);
+    if constexpr (!NOPRIO) __builtin_amdgcn_s_setprio(1);
+    {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < 4; ++m) {
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc.v[4 + m][n] = F::mfma(b0[n][ks], a[m][ks], acc.v[4 + m][n]);
+          for (int n = 0; n < 2; ++n) acc.v[4 + m][n] = F::mfma(b0[n][ks], a[m][ks], acc.v[4 + m][n]);
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc.v[4 + m][2 + n] = F::mfma(b1[n][ks], a[m][ks], acc.v[4 + m][2 + n]);
-      }
-    __builtin_amdgcn_s_setprio(0);
+          for (int n = 0; n < 2; ++n) acc.v[4 + m][2 + n] = F::mfma(b1[n][ks], a[m][ks], acc.v[4 + m][2 + n]);
+        }
+    }
+    if constexpr (!NOPRIO) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
   }
@@ -425,6 +469,31 @@ __device__ __forceinline__ void epilogue_256_from(GetFn&& get, char* smem, Store
     store(row, cc * 8, v);
   }
   __syncthreads();
+}
+
+// Epilogue for accumulators produced with PERM_B: no LDS, no barrier.  Every lane converts its
+// values and hands sixteen 16-byte pieces to `store(row_in_tile, col_in_tile, uint4)`; one wave
+// instruction covers 16 rows x 64 contiguous bytes.  Because LDS is not touched, a persistent kernel
+// can issue the next tile's first loads right behind these stores and the write-out drains under
+// the next main loop.
+template <bool IS_BF16, class StoreFn>
+__device__ __forceinline__ void epilogue_256_direct(const Acc<IS_BF16>& acc, StoreFn&& store) {
+  using F = Frag<IS_BF16>;
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, l = tid & 63;
+  const int row = (w >> 2) * 128 + (l & 15);
+  const int col = (w & 3) * 64 + (l >> 4) * 8;
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      uint4 v;
+      v.x = F::pack2(acc.v[m][2 * p][0], acc.v[m][2 * p][1]);
+      v.y = F::pack2(acc.v[m][2 * p][2], acc.v[m][2 * p][3]);
+      v.z = F::pack2(acc.v[m][2 * p + 1][0], acc.v[m][2 * p + 1][1]);
+      v.w = F::pack2(acc.v[m][2 * p + 1][2], acc.v[m][2 * p + 1][3]);
+      store(row + m * 16, col + 32 * p, v);
+    }
 }
 
 template <bool IS_BF16, class StoreFn>

@@ -48,6 +48,45 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_256_kernel(const uint16_t*
   });
 }
 
+// Persistent form: one workgroup per CU walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... (the
+// grid is a multiple of 8, so a workgroup stays on its XCD and keeps the same compact patch mapping).
+// The epilogue stores straight from registers (permuted accumulator columns), so the first loads of
+// the next tile are issued right behind the stores of the previous one: with two tiles per CU at the
+// headline shape, the 32 MiB that every CU of the chip writes at the same moment drains under the
+// next main loop instead of idling the matrix cores.
+template <bool IS_BF16, int OPT>
+__global__ __launch_bounds__(THREADS, 2) void gemm_nt_256_persistent_kernel(const uint16_t* __restrict__ A,
+                                                                            const uint16_t* __restrict__ B,
+                                                                            uint16_t* __restrict__ C, int M, int N,
+                                                                            int K, long long lda, long long ldb,
+                                                                            long long ldc, int group_m) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int num_pid_m = (M + BM - 1) / BM;
+  const int num_pid_n = (N + BN - 1) / BN;
+  const int nwg = num_pid_m * num_pid_n;
+  for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
+    const int id = xcd_remap(vb, nwg);
+    int pid_m, pid_n;
+    tile_coords(id, num_pid_m, num_pid_n, group_m, pid_m, pid_n);
+    const int row0 = pid_m * BM, col0 = pid_n * BN;
+    TileArgs t;
+    t.A = A + (long long)row0 * lda;
+    t.B = B + (long long)col0 * ldb;
+    t.lda = lda;
+    t.ldb = ldb;
+    t.a_rows = M - row0;
+    t.b_rows = N - col0;
+    t.K = K;
+    Acc<IS_BF16> acc;
+    mainloop_256_2ph<IS_BF16, true, OPT>(t, smem, acc);
+    const int mrem = M - row0, nrem = N - col0;
+    uint16_t* cbase = C + (long long)row0 * ldc + col0;
+    epilogue_256_direct<IS_BF16>(acc, [&](int r, int c, const uint4& v) {
+      if (r < mrem && c < nrem) *(uint4*)(cbase + (long long)r * ldc + c) = v;
+    });
+  }
+}
+
 // Decode-shaped GEMM (M <= 16): the weights are streamed exactly once with non-temporal 16-byte
 // loads and feed 16x16x32 MFMAs whose M dimension is the zero-padded batch.  A workgroup of four
 // (or eight, NW) waves covers BN = 16 * WN output columns (WN = 1 / 2 / 4); wave k owns the k-th slice
@@ -185,6 +224,32 @@ TDIST_API int tdist_gemm_nt(const void* A, const void* B, void* C, int M, int N,
       for (int j = 0; j < 2; ++j)
         TDIST_HIP_TRY(hipFuncSetAttribute((const void*)table[i][j], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set = true;
+  }
+  if ((variant & 255) == 3) {
+    typedef void (*pkern_t)(const uint16_t*, const uint16_t*, uint16_t*, int, int, int, long long, long long, long long, int);
+    // bits 16..17 of `variant` pick the schedule knobs of mainloop_256_2ph (fp16: defaults only)
+    static const pkern_t ptable[5] = {
+        gemm_nt_256_persistent_kernel<true, 0>, gemm_nt_256_persistent_kernel<true, 1>,
+        gemm_nt_256_persistent_kernel<true, 2>, gemm_nt_256_persistent_kernel<true, 3>,
+        gemm_nt_256_persistent_kernel<false, 3>};
+    static int num_cus = 0;
+    static bool pattr_set = false;
+    if (!pattr_set) {
+      int dev = 0;
+      TDIST_HIP_TRY(hipGetDevice(&dev));
+      TDIST_HIP_TRY(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+      for (int i = 0; i < 5; ++i)
+        TDIST_HIP_TRY(hipFuncSetAttribute((const void*)ptable[i], hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES));
+      pattr_set = true;
+    }
+    int grid = num_cus & ~7;                      // multiple of 8: a workgroup's tiles stay on its XCD
+    if (grid < 8) grid = 8;
+    if (tiles < grid) grid = tiles;               // (fewer tiles than CUs: one tile each, no remap constraint)
+    const pkern_t pk = dtype == 0 ? ptable[(variant >> 16) & 3] : ptable[4];
+    hipLaunchKernelGGL(pk, dim3(grid), dim3(THREADS), 2 * BUF_BYTES, (hipStream_t)stream, (const uint16_t*)A,
+                       (const uint16_t*)B, (uint16_t*)C, M, N, K, lda, ldb, ldc, group_m);
+    TDIST_HIP_TRY(hipGetLastError());
+    return 0;
   }
   kern_t k = table[dtype == 0 ? 0 : 1][(variant & 255) == 2 ? 1 : 0];
   hipLaunchKernelGGL(k, dim3(tiles), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, (const uint16_t*)A,
