@@ -38,6 +38,59 @@ def test_all_reduce(w, method, dtype, n):
         vc.close()
 
 
+@pytest.mark.parametrize("w", [2, 4])
+@pytest.mark.parametrize("method", [AllReduceMethod.OneShot, AllReduceMethod.TwoShot])
+def test_all_reduce_graph_replay(w, method):
+    """The call number lives on the device, so a captured all-reduce picks a fresh epoch and buffer
+    parity on every replay: replays, eager calls in between and two launches per graph all agree."""
+    vc = VirtualCluster(w, heap_bytes=1 << 27)
+    try:
+        ctxs = vc.collective(lambda r, env: create_allreduce_ctx(8 << 20, r, w, env=env))
+        n = 8192 * 3 + 8
+        xs = [torch.zeros(n, device="cuda", dtype=torch.bfloat16) for _ in range(w)]
+        mid = [torch.empty_like(x) for x in xs]
+        outs = [torch.empty_like(x) for x in xs]
+
+        def fill():
+            for x in xs:
+                x.copy_((torch.rand(n, device="cuda") - 0.5).bfloat16())
+            torch.cuda.synchronize()
+            first = sum(x.float() for x in xs).bfloat16()
+            return first, (first.float() * w).bfloat16()
+
+        def check(first, second):
+            for r in range(w):
+                ctxs[r].check_error()
+                assert torch.allclose(mid[r].float(), first.float(), atol=2e-2 * w, rtol=2e-2)
+                assert torch.allclose(outs[r].float(), second.float(), atol=4e-2 * w * w, rtol=4e-2)
+                assert torch.equal(outs[r], outs[0])
+
+        def eager(r, env):
+            all_reduce(xs[r], method, ctxs[r], output=mid[r])
+            all_reduce(mid[r], method, ctxs[r], output=outs[r])
+
+        fill()
+        vc.run(lambda r, env: all_reduce(xs[r], method, ctxs[r], output=mid[r]))   # odd number of calls before capture
+        graphs = []
+        for r in range(w):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=vc.streams[r]):
+                eager(r, vc.envs[r])
+            graphs.append(g)
+        for it in range(6):
+            first, second = fill()
+            for t in mid + outs:
+                t.zero_()
+            torch.cuda.synchronize()
+            if it == 3:
+                vc.run(eager)                  # an eager call between replays keeps the sequence
+            else:
+                vc.run(lambda r, env: graphs[r].replay())
+            check(first, second)
+    finally:
+        vc.close()
+
+
 @pytest.mark.parametrize("w,M,N,K", [(2, 512, 1024, 512), (4, 128, 2048, 1024), (8, 300, 1280, 2048)])
 def test_gemm_allreduce(w, M, N, K):
     vc = VirtualCluster(w, heap_bytes=1 << 27)

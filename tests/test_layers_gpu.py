@@ -303,6 +303,62 @@ def test_model_modes_match_single_rank(name, mode, w):
         vc.close()
 
 
+def test_all_reduce_backend_decode_replays_from_graph():
+    """triton_dist_AR at world size 2: each rank captures ONE decode step and replays it; the
+    all-reduce kernels advance their call number on the device, so every replay matches the
+    single-rank model."""
+    name, w, bsz, prompt, L, steps = "tdist/tiny-dense", 2, 4, 16, 128, 4
+    torch.manual_seed(7)
+    ids = torch.randint(0, 1000, (bsz, prompt), device="cuda")
+    pos = torch.arange(prompt, device="cuda")[None].repeat(bsz, 1)
+    g = AutoLLM.from_pretrained(ModelConfig(model_name=name, max_length=L, dtype=BF, rank=0, world_size=1))
+    gkv = KV_Cache(g.num_layers, bsz, L, g.num_key_value_heads, g.head_dim, BF, 1)
+    tok = g.inference(ids, pos, gkv)[:, -1].argmax(-1, keepdim=True)
+    gkv.kv_offset.fill_(prompt)
+    toks, gold = [tok], []
+    for _ in range(steps):
+        gold.append(g.inference(toks[-1], gkv.get_kv_len()[:, None].long(), gkv))
+        gkv.inc_offset()
+        toks.append(gold[-1][:, -1].argmax(-1, keepdim=True))
+    vc = VirtualCluster(w, heap_bytes=1 << 28)
+    try:
+        models = [AutoLLM.from_pretrained(ModelConfig(model_name=name, max_length=L, dtype=BF, rank=r, world_size=w),
+                                          env=vc.envs[r]) for r in range(w)]
+        kvs = [KV_Cache(g.num_layers, bsz, L, g.num_key_value_heads, g.head_dim, BF, w) for _ in range(w)]
+        for m in models:
+            m.set_fwd("triton_dist_AR")
+        vc.collective(lambda r, env: models[r].init_triton_dist_AR_ctx(max_M=bsz * prompt))
+        torch.cuda.synchronize()
+        vc.run(lambda r, env: models[r].inference(ids, pos, kvs[r]))            # eager prefill
+        for kv in kvs:
+            kv.kv_offset.fill_(prompt)
+        s_tok = [torch.zeros_like(tok) for _ in range(w)]
+        s_pos = [torch.zeros((bsz, 1), dtype=torch.long, device="cuda") for _ in range(w)]
+        graphs, logits = [], [None] * w
+        # warm-up step outside capture (lazy tables), undone by not advancing the KV offset
+        for r in range(w):
+            s_tok[r].copy_(toks[0])
+            s_pos[r].copy_(kvs[r].get_kv_len()[:, None].long())
+        torch.cuda.synchronize()
+        vc.run(lambda r, env: models[r].inference(s_tok[r], s_pos[r], kvs[r]))
+        for r in range(w):
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=vc.streams[r]):
+                logits[r] = models[r].inference(s_tok[r], s_pos[r], kvs[r])
+            graphs.append(gr)
+        for step in range(steps):
+            for r in range(w):
+                s_tok[r].copy_(toks[step])
+                s_pos[r].copy_(kvs[r].get_kv_len()[:, None].long())
+            torch.cuda.synchronize()
+            vc.run(lambda r, env: graphs[r].replay())
+            for r in range(w):
+                assert _rel(logits[r], gold[step]) < 5e-2
+                kvs[r].inc_offset()
+    finally:
+        vc.close()
+
+
 def test_engine_graph_decode_matches_eager():
     cfg = ModelConfig(model_name="tdist/tiny-dense", max_length=128, dtype=BF, rank=0, world_size=1)
     eng = Engine(cfg)

@@ -5,6 +5,12 @@
 // is no grid barrier and no cross-rank barrier.  Flags carry the call's epoch and the workspaces /
 // flags are double-buffered by call parity, so nothing is reset between calls.
 //
+// The call number lives ON THE DEVICE (`state[0]`, one word per context and rank): every workgroup
+// reads it on entry and derives buffer parity and flag value from it; the workgroup that finishes
+// last advances it.  A launch therefore carries no per-call argument, and a HIP graph that captured
+// it picks a fresh epoch on every replay - all ranks issue the same sequence of launches, so their
+// counters stay equal.
+//
 //   one-shot : push own slice into every peer's slot [rank]; flag; wait w-1 flags; sum the w
 //              contributions in rank order (bitwise identical result on every rank).
 //   two-shot : rank r owns chunk r.  Phase 1: push sub-slice of chunk p to peer p (reduce-scatter);
@@ -26,8 +32,11 @@ struct ArParams {
   SymmCtx ctx;
   const void* in;
   void* out;
-  void* ws;        // symmetric, this parity
-  int* flags;      // symmetric (signal arena), this parity: [2][w][G]
+  void* ws;        // symmetric, this call's parity (resolved on the device, see resolve_call)
+  int* flags;      // symmetric (signal arena), this call's parity: [2][w][G]
+  void* ws_par[2];     // both parities, as given by the host
+  int* flags_par[2];
+  int* state;      // [0] call number in [0, 2 * EPOCH_MOD), [1] finished-workgroup count
   int* err;
   long long n;     // elements
   long long cap;   // one-shot: slot stride in elements; two-shot: chunk stride (ce) in elements
@@ -104,6 +113,34 @@ struct Elem<_Float16> {
   static __device__ __forceinline__ _Float16 from_f(float x) { return (_Float16)x; }
 };
 
+constexpr int EPOCH_MOD = 4093;   // flag values are 1 .. EPOCH_MOD (0 = never written)
+
+// Entry of every workgroup: read the call number, select parity buffers and the flag value.
+__device__ __forceinline__ int resolve_call(ArParams& p) {
+  __shared__ int s_call;
+  if (threadIdx.x == 0) s_call = load_relaxed_agent(p.state);
+  __syncthreads();
+  const int call = s_call;
+  p.ws = p.ws_par[call & 1];
+  p.flags = p.flags_par[call & 1];
+  p.epoch = call % EPOCH_MOD + 1;
+  return call;
+}
+
+// Exit of every workgroup: the last one to arrive re-arms the count and advances the call number.
+// (Every workgroup read the call number before it could finish, so nobody sees the new value early;
+// the next launch on the stream starts after this kernel's end-of-kernel release.)
+__device__ __forceinline__ void finish_call(const ArParams& p, int call) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int prev = atom_add_relaxed_agent(p.state + 1, 1);
+    if (prev == (int)gridDim.x - 1) {
+      store_relaxed_agent(p.state + 1, 0);
+      store_relaxed_agent(p.state, (call + 1) % (2 * EPOCH_MOD));
+    }
+  }
+}
+
 // Raise flag[phase][rank][c] on every peer, then wait for flag[phase][s][c] of every peer s.
 // The payload went out with write-through stores, so publishing is drain + barrier; only a push
 // that had to fall back to plain stores (`need_release`, workgroup-uniform) pays a release fence.
@@ -157,6 +194,7 @@ __device__ __forceinline__ void sum_slices(const ArParams& p, const T* own, cons
 template <typename T>
 __global__ __launch_bounds__(512) void allreduce_one_shot_kernel(ArParams p) {
   constexpr int VEC = Elem<T>::VEC;
+  const int call = resolve_call(p);
   const int w = p.ctx.num_ranks, rank = p.ctx.rank, c = blockIdx.x;
   const long long per = ((p.n + p.G - 1) / p.G + VEC - 1) / VEC * VEC;
   const long long e0 = min((long long)c * per, p.n), e1 = min(e0 + per, p.n);
@@ -170,11 +208,13 @@ __global__ __launch_bounds__(512) void allreduce_one_shot_kernel(ArParams p) {
   }
   exchange_flags(p, 0, c, plain);
   sum_slices<T>(p, in, ws, p.cap, (T*)p.out, e0, e1);
+  finish_call(p, call);
 }
 
 template <typename T>
 __global__ __launch_bounds__(512) void allreduce_two_shot_kernel(ArParams p) {
   constexpr int VEC = Elem<T>::VEC;
+  const int call = resolve_call(p);
   const int w = p.ctx.num_ranks, rank = p.ctx.rank, c = blockIdx.x;
   const long long ce = p.cap;                                   // chunk stride (elements, multiple of VEC)
   const long long sub = ((ce + p.G - 1) / p.G + VEC - 1) / VEC * VEC;
@@ -217,24 +257,35 @@ __global__ __launch_bounds__(512) void allreduce_two_shot_kernel(ArParams p) {
       shmem::copy_bytes((T*)p.out + g0, gather + (long long)s * ce + s0, (size_t)(g1 - g0) * sizeof(T), threadIdx.x,
                         blockDim.x);
   }
+  finish_call(p, call);
 }
 
 // dtype: 0 bf16, 1 fp16, 2 fp32.  method: 1 one-shot, 2 two-shot.
-TDIST_API int tdist_allreduce(const tdist::SymmCtx* ctx, const void* in, void* out, void* ws, int* flags, int* err,
-                              long long n, long long cap, int G, int epoch, int dtype, int method, void* stream) {
+// ws0/ws1, flags0/flags1: the two parity buffers (this rank's symmetric addresses).  state: two
+// int32 in device memory, zeroed once when the context is created, never touched by the host again.
+TDIST_API int tdist_allreduce(const tdist::SymmCtx* ctx, const void* in, void* out, void* ws0, void* ws1, int* flags0,
+                              int* flags1, int* state, int* err, long long n, long long cap, int G, int dtype,
+                              int method, void* stream) {
   TDIST_REQUIRE(n > 0 && G > 0 && G <= 1024, "bad n / G");
-  TDIST_REQUIRE((((uintptr_t)in | (uintptr_t)out | (uintptr_t)ws) & 15) == 0, "buffers must be 16-byte aligned");
+  TDIST_REQUIRE((((uintptr_t)in | (uintptr_t)out | (uintptr_t)ws0 | (uintptr_t)ws1) & 15) == 0,
+                "buffers must be 16-byte aligned");
+  TDIST_REQUIRE(state && flags0 && flags1, "missing call state / flags");
   ArParams p;
   p.ctx = *ctx;
   p.in = in;
   p.out = out;
-  p.ws = ws;
-  p.flags = flags;
+  p.ws = nullptr;
+  p.flags = nullptr;
+  p.ws_par[0] = ws0;
+  p.ws_par[1] = ws1;
+  p.flags_par[0] = flags0;
+  p.flags_par[1] = flags1;
+  p.state = state;
   p.err = err;
   p.n = n;
   p.cap = cap;
   p.G = G;
-  p.epoch = epoch;
+  p.epoch = 0;
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(T)                                                                              \
   do {                                                                                         \

@@ -4,10 +4,12 @@ Reference: python/triton_dist/models/engine.py:36-189.  Back-ends: ``torch`` (RC
 ``triton_dist`` (AG+GEMM / GEMM+RS, batch sharded over ranks), ``triton_dist_AR`` (symmetric-memory
 all-reduce kernels) and ``triton_dist_gemm_ar`` (GEMM fused with the all-reduce).
 
-Graph replay is used where the whole step is replay-safe: the torch back-end and any back-end at
-world size 1.  The multi-rank fused ops number their calls with a host-side epoch (buffer parity +
-flag value), which a replayed graph would freeze, so those back-ends run the same decode loop
-eagerly - the ops refuse capture rather than race (utils/distributed.py: forbid_graph_capture).
+Graph replay is used where the whole step is replay-safe: the torch back-end, any back-end at
+world size 1, and ``triton_dist_AR`` at any world size (its all-reduce kernels keep their call
+number on the device, so a replayed launch picks a fresh epoch and buffer parity by itself).  The
+other fused multi-rank ops number their calls with a host-side epoch, which a replayed graph would
+freeze, so ``triton_dist`` / ``triton_dist_gemm_ar`` run the same decode loop eagerly at world size
+> 1 - those ops refuse capture rather than race (utils/distributed.py: forbid_graph_capture).
 """
 from __future__ import annotations
 
@@ -125,7 +127,8 @@ class Engine:
         self._switch_backend(bsz)
         if self.backend == "triton_dist":
             next_token = next_token.split(bsz // m.world_size, dim=0)[m.rank].contiguous()
-        use_graph = not self.no_graph and m.device.type == "cuda" and (self.backend == "torch" or m.world_size == 1)
+        use_graph = not self.no_graph and m.device.type == "cuda" and (
+            self.backend in ("torch", "triton_dist_AR") or m.world_size == 1)
         if use_graph:
             self.model_launch = self._init_cuda_graph(bsz)
         else:

@@ -93,7 +93,8 @@ class AllReduceContext:
     flags: List[List[torch.Tensor]]          # [parity][rank] int32 [2 * w * MAX_CTAS]
     err: Optional[torch.Tensor]
     env: Any = None
-    call_count: int = 0
+    call_count: int = 0                      # host path: selects parity / epoch; HIP path: statistics only
+    state: Optional[torch.Tensor] = None     # HIP path: [call number, finished workgroups] int32, owned by the kernels
 
     def check_error(self) -> None:
         if self.err is not None and int(self.err[0]) != 0:
@@ -110,11 +111,13 @@ def create_allreduce_ctx(workspace_nbytes: int, rank: int, world_size: int, loca
         ws.append(heap.create_tensor_list([workspace_nbytes], torch.uint8, zero=False))
         fl.append(heap.create_tensor_list([2 * world_size * MAX_CTAS], torch.int32, arena="sig"))
     err = torch.zeros(4, dtype=torch.int32, device=env.device) if env.backend == "hip" else None
+    state = torch.zeros(4, dtype=torch.int32, device=env.device) if env.backend == "hip" else None
     if env.backend == "hip":
         torch.cuda.synchronize()
     if env.cpu_group is not None:
         torch.distributed.barrier(group=env.cpu_group)
-    return AllReduceContext(workspace_nbytes, rank, world_size, local_world_size or world_size, ws, fl, err, env)
+    return AllReduceContext(workspace_nbytes, rank, world_size, local_world_size or world_size, ws, fl, err, env,
+                            state=state)
 
 
 def _run_straggler(straggler_option, rank):
@@ -129,7 +132,10 @@ def _all_reduce_chunk(x, out, method, ctx: AllReduceContext, max_sm: int):
     w, rank = ctx.world_size, ctx.rank
     n = x.numel()
     esize = x.element_size()
-    forbid_graph_capture("all_reduce", w)
+    if env.backend == "host":
+        forbid_graph_capture("all_reduce", w)
+    # HIP path: the call number lives in ctx.state on the device (the kernels select parity and
+    # flag value themselves), so the launch is the same every time and may be captured in a graph.
     parity = ctx.call_count & 1
     epoch = ctx.call_count % EPOCH_MOD + 1
     ctx.call_count += 1
@@ -149,9 +155,11 @@ def _all_reduce_chunk(x, out, method, ctx: AllReduceContext, max_sm: int):
         G = min(G, max_sm)
     cs = env.heap.ctx_struct()
     _lib.check(
-        _lib.hip().tdist_allreduce(ctypes.byref(cs), _lib.ptr(x), _lib.ptr(out), _lib.ptr(ctx.workspaces[parity][rank]),
-                                   _lib.ptr(ctx.flags[parity][rank]), _lib.ptr(ctx.err), ctypes.c_longlong(n),
-                                   ctypes.c_longlong(cap), G, epoch, _DT[x.dtype], kind, _lib.stream_handle()),
+        _lib.hip().tdist_allreduce(ctypes.byref(cs), _lib.ptr(x), _lib.ptr(out), _lib.ptr(ctx.workspaces[0][rank]),
+                                   _lib.ptr(ctx.workspaces[1][rank]), _lib.ptr(ctx.flags[0][rank]),
+                                   _lib.ptr(ctx.flags[1][rank]), _lib.ptr(ctx.state), _lib.ptr(ctx.err),
+                                   ctypes.c_longlong(n), ctypes.c_longlong(cap), G, _DT[x.dtype], kind,
+                                   _lib.stream_handle()),
         "tdist_allreduce")
     return out
 
@@ -202,8 +210,6 @@ def all_reduce(x: torch.Tensor, method: AllReduceMethod = AllReduceMethod.Unknow
     if n <= max_elems:
         _all_reduce_chunk(x.view(-1), output.view(-1), method, ctx, max_sm)
         return output
-    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
-        raise RuntimeError("all_reduce: multi-chunk inputs cannot be captured in a graph; enlarge the workspace")
     xf, of = x.view(-1), output.view(-1)
     for s in range(0, n, max_elems):
         e = min(n, s + max_elems)
