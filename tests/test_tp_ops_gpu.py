@@ -147,3 +147,69 @@ def test_fused_ops_on_a_grown_heap():
                 assert (o2[r].float() - ref2).abs().max().item() / ref2.abs().max().item() < 1e-2
     finally:
         vc.close()
+
+
+@pytest.mark.parametrize("w,M,N,K", [(2, 1024, 1024, 512), (4, 1024, 2048, 1024)])
+def test_ag_gemm_gemm_rs_pair_replays_from_graph(w, M, N, K):
+    """The TP MLP pair captured once per rank and replayed: both kernels number their calls on the
+    device, so every replay (and an eager call in between) uses a fresh epoch and buffer parity."""
+    vc = VirtualCluster(w, heap_bytes=1 << 27)
+    try:
+        ag = vc.collective(lambda r, env: create_ag_gemm_intra_node_context(
+            M, N // w, K, torch.bfloat16, torch.bfloat16, r, w, num_ctas=_ctas(w), env=env,
+            ag_streams=[vc.side_streams[r]]))
+        rs = vc.collective(lambda r, env: create_gemm_rs_intra_node_context(M, K, torch.bfloat16, r, w,
+                                                                            num_ctas=_ctas(w), env=env))
+        x = [torch.zeros(M // w, K, device="cuda", dtype=torch.bfloat16) for _ in range(w)]
+        w1 = [((torch.rand(N // w, K, device="cuda") * 2 - 1) * 0.05).bfloat16() for _ in range(w)]
+        w2 = [((torch.rand(K, N // w, device="cuda") * 2 - 1) * 0.05).bfloat16() for _ in range(w)]
+        outs = [None] * w
+
+        def pair(r, env):
+            h = ag_gemm_intra_node(x[r], w1[r], False, ag[r])          # [M, N/w]
+            outs[r] = gemm_rs_intra_node(h, w2[r], rs[r])              # [M/w, K]
+            return outs[r]
+
+        def reference():
+            xf = torch.cat(x).float()
+            acc = 0
+            for r in range(w):
+                h = (xf @ w1[r].float().t()).bfloat16().float()
+                acc = acc + (h @ w2[r].float().t()).bfloat16().float()
+            return acc
+
+        def fill():
+            for t in x:
+                t.copy_((torch.rand(M // w, K, device="cuda") * 2 - 1).bfloat16())
+            torch.cuda.synchronize()
+
+        def check(res):
+            ref = reference()
+            for r in range(w):
+                ag[r].check_error()
+                rs[r].check_error()
+                got = res[r].float()
+                want = ref[r * (M // w):(r + 1) * (M // w)]
+                assert (got - want).abs().max().item() / want.abs().max().item() < 2e-2
+
+        fill()
+        check(vc.run(pair))                      # one eager call: an odd number of calls before capture
+        graphs = []
+        for r in range(w):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=vc.streams[r]):
+                pair(r, vc.envs[r])
+            graphs.append(g)
+        static_outs = list(outs)
+        for it in range(5):
+            fill()
+            for t in static_outs:
+                t.zero_()
+            torch.cuda.synchronize()
+            if it == 2:
+                check(vc.run(pair))
+            else:
+                vc.run(lambda r, env: graphs[r].replay())
+                check(static_outs)
+    finally:
+        vc.close()

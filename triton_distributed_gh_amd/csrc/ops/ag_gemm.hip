@@ -26,6 +26,7 @@
 //     tiles whose data already arrived;
 //   * every spin is bounded and reports through an error word instead of hanging the GPU.
 #include "tdist/cache_policy.hpp"
+#include "tdist/call_state.hpp"
 #include "tdist/common.hpp"
 #include "tdist/gemm_gfx950.hpp"
 #include "tdist/primitives.hpp"
@@ -54,9 +55,15 @@ struct AgGemmParams {
   int straddle;              // 1: tiles walk the whole [M, K] workspace (own rows copied in too)
   int push_wgs;              // first push_wgs tickets push the local shard to every peer
   int split_k;               // K is cut into split_k ranges, one work item each
+  // Device-side call numbering (tdist/call_state.hpp).  When `state` is set, ws / flags / epoch above
+  // are ignored by the host and resolved on the device from the call number: the launch is then the
+  // same every time and can be replayed from a HIP graph.
+  int* state;
+  uint16_t* ws_par[2];
+  int* flags_par[2];
 };
 
-constexpr int TICKET_SLOT = LDS_BYTES;  // 16 bytes after the tile staging area: [0] ticket, [1] split-K arrival
+constexpr int TICKET_SLOT = LDS_BYTES;  // 16 bytes after the tile staging area: [0] ticket, [1] split-K arrival, [2] call number
 
 // Producer work item `pw` of `p.push_wgs`: for every chunk in order, copy slice pw of the chunk
 // to every peer's workspace.  Each thread keeps eight 16-byte pieces in flight; every piece is
@@ -138,6 +145,13 @@ __global__ __launch_bounds__(THREADS, 2) void ag_gemm_consumer_kernel(AgGemmPara
   const int S = p.split_k;
   const int total = p.push_wgs + total_mb * num_pid_n * S;
   const int ksteps = p.K / BK;
+  int call = 0;
+  if (p.state) {
+    call = call_begin(p.state, s_ticket + 2);
+    p.ws = p.ws_par[call_parity(call)];
+    p.flags = p.flags_par[call_parity(call)];
+    p.epoch = call_epoch(call);
+  }
 
   while (true) {
     int item = fetch_ticket_block(p.ticket, s_ticket);
@@ -272,6 +286,7 @@ __global__ __launch_bounds__(THREADS, 2) void ag_gemm_consumer_kernel(AgGemmPara
         },
         smem, store_c);
   }
+  if (p.state) call_end(p.state, call);
 }
 
 // In-kernel producer (alternative to the copy engines): workgroup b pushes slice (b % slices) of
@@ -336,12 +351,16 @@ static int check_common(const void* B, const void* C, int N_local, int K, long l
 
 // scratch layout (int32): [0] error word (sticky, never cleared here), [4] ticket,
 // [8, 8 + cpr) push counters, [8 + cpr, 8 + cpr + tiles) split-K arrival counters.
+// `state` != nullptr: device-side call numbering; ws / flags are then parity 0 and ws1 / flags1 parity 1,
+// and `epoch` is ignored.
 TDIST_API int tdist_ag_gemm_consumer(const tdist::SymmCtx* ctx, const void* a_local, void* ws, const void* B, void* C,
                                      int* flags, int* scratch, long long scratch_ints, void* partial,
                                      long long partial_bytes, long long lda_local, long long ld_ws, long long ldb,
                                      long long ldc, int M_per_rank, int N_local, int K, int rows_per_chunk, int epoch,
-                                     int straddle, int push_wgs, int split_k, int num_ctas, int dtype, void* stream) {
+                                     int straddle, int push_wgs, int split_k, int num_ctas, int dtype, void* stream,
+                                     int* state, void* ws1, int* flags1) {
   if (check_common(B, C, N_local, K, ldb, ldc)) return -1;
+  TDIST_REQUIRE(!state || (ws1 && flags1 && (((uintptr_t)ws1) & 15) == 0), "device-side call numbering needs both parities");
   const int world = ctx->num_ranks, rank = ctx->rank;
   TDIST_REQUIRE(world >= 1 && world <= TDIST_MAX_RANKS && rank >= 0 && rank < world, "bad rank/world");
   TDIST_REQUIRE(M_per_rank > 0 && rows_per_chunk > 0 && M_per_rank % rows_per_chunk == 0,
@@ -385,6 +404,11 @@ TDIST_API int tdist_ag_gemm_consumer(const tdist::SymmCtx* ctx, const void* a_lo
   p.straddle = straddle;
   p.push_wgs = world > 1 ? push_wgs : 0;
   p.split_k = split_k;
+  p.state = state;
+  p.ws_par[0] = (uint16_t*)ws;
+  p.ws_par[1] = (uint16_t*)ws1;
+  p.flags_par[0] = flags;
+  p.flags_par[1] = flags1;
   const int total = p.push_wgs + tiles * split_k;
   int grid = num_ctas > 0 ? num_ctas : 256;
   if (grid > total) grid = total;

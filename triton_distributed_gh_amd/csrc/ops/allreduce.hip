@@ -22,6 +22,7 @@
 // the NVLS multimem / TMA / double-tree variants (:214-329, :386-443, :527-682) have no xGMI
 // counterpart and are served by these two kernels (see ops/allreduce.py for the mapping).
 #include "tdist/cache_policy.hpp"
+#include "tdist/call_state.hpp"
 #include "tdist/common.hpp"
 #include "tdist/primitives.hpp"
 #include "tdist/shmem_device.hpp"
@@ -113,33 +114,18 @@ struct Elem<_Float16> {
   static __device__ __forceinline__ _Float16 from_f(float x) { return (_Float16)x; }
 };
 
-constexpr int EPOCH_MOD = 4093;   // flag values are 1 .. EPOCH_MOD (0 = never written)
-
-// Entry of every workgroup: read the call number, select parity buffers and the flag value.
+// Entry of every workgroup: read the call number (tdist/call_state.hpp), select the parity buffers
+// and the flag value.
 __device__ __forceinline__ int resolve_call(ArParams& p) {
   __shared__ int s_call;
-  if (threadIdx.x == 0) s_call = load_relaxed_agent(p.state);
-  __syncthreads();
-  const int call = s_call;
-  p.ws = p.ws_par[call & 1];
-  p.flags = p.flags_par[call & 1];
-  p.epoch = call % EPOCH_MOD + 1;
+  const int call = call_begin(p.state, &s_call);
+  p.ws = p.ws_par[call_parity(call)];
+  p.flags = p.flags_par[call_parity(call)];
+  p.epoch = call_epoch(call);
   return call;
 }
 
-// Exit of every workgroup: the last one to arrive re-arms the count and advances the call number.
-// (Every workgroup read the call number before it could finish, so nobody sees the new value early;
-// the next launch on the stream starts after this kernel's end-of-kernel release.)
-__device__ __forceinline__ void finish_call(const ArParams& p, int call) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int prev = atom_add_relaxed_agent(p.state + 1, 1);
-    if (prev == (int)gridDim.x - 1) {
-      store_relaxed_agent(p.state + 1, 0);
-      store_relaxed_agent(p.state, (call + 1) % (2 * EPOCH_MOD));
-    }
-  }
-}
+__device__ __forceinline__ void finish_call(const ArParams& p, int call) { call_end(p.state, call); }
 
 // Raise flag[phase][rank][c] on every peer, then wait for flag[phase][s][c] of every peer s.
 // The payload went out with write-through stores, so publishing is drain + barrier; only a push

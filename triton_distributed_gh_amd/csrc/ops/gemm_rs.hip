@@ -19,6 +19,7 @@
 // buffers and flags are double-buffered by call parity and flags carry the call's epoch, so no
 // cross-rank barrier is needed at all.
 #include "tdist/cache_policy.hpp"
+#include "tdist/call_state.hpp"
 #include "tdist/common.hpp"
 #include "tdist/gemm_gfx950.hpp"
 #include "tdist/primitives.hpp"
@@ -40,6 +41,11 @@ struct GemmRsParams {
   int rows_per_chunk;
   int epoch;
   int* dbg;               // optional progress trace: [grid][4] ints (last item, stage, items done, spare)
+  // Device-side call numbering (tdist/call_state.hpp): when `state` is set, scatter / flags / epoch are
+  // resolved on the device from the call number and the launch can be replayed from a HIP graph.
+  int* state;
+  uint16_t* scatter_par[2];
+  int* flags_par[2];
 };
 
 constexpr int RS_TICKET_SLOT = LDS_BYTES;
@@ -118,6 +124,13 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_rs_kernel(GemmRsParams p) {
   const int S = Gc + Rc;
   const int total = cpr * S;
   int* ticket = p.counters + w * cpr;
+  int call = 0;
+  if (p.state) {
+    call = call_begin(p.state, s_ticket + 2);
+    p.scatter = p.scatter_par[call_parity(call)];
+    p.flags = p.flags_par[call_parity(call)];
+    p.epoch = call_epoch(call);
+  }
 
   while (true) {
     const int item = fetch_ticket_block(ticket, s_ticket);
@@ -199,12 +212,13 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_rs_kernel(GemmRsParams p) {
       }
     }
   }
+  if (p.state) call_end(p.state, call);
 }
 
 TDIST_API int tdist_gemm_rs(const tdist::SymmCtx* ctx, const void* A, const void* B, void* scatter, int* flags,
                             int* counters, int* err, void* out, long long lda, long long ldb, long long ldo,
                             int M_per_rank, int N, int K, int rows_per_chunk, int epoch, int num_ctas, int dtype,
-                            void* stream, int* dbg) {
+                            void* stream, int* dbg, int* state, void* scatter1, int* flags1) {
   TDIST_REQUIRE(K >= 128 && K % 64 == 0, "K must be a multiple of 64 and >= 128");
   TDIST_REQUIRE(N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldo % 8 == 0, "N/lda/ldb/ldo must be multiples of 8");
   TDIST_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)out | (uintptr_t)scatter) & 15) == 0,
@@ -231,6 +245,13 @@ TDIST_API int tdist_gemm_rs(const tdist::SymmCtx* ctx, const void* A, const void
   p.rows_per_chunk = rows_per_chunk;
   p.epoch = epoch;
   p.dbg = dbg;
+  TDIST_REQUIRE(!state || (scatter1 && flags1 && (((uintptr_t)scatter1) & 15) == 0),
+                "device-side call numbering needs both parities");
+  p.state = state;
+  p.scatter_par[0] = (uint16_t*)scatter;
+  p.scatter_par[1] = (uint16_t*)scatter1;
+  p.flags_par[0] = flags;
+  p.flags_par[1] = flags1;
   const int cpr = M_per_rank / rows_per_chunk;
   const size_t counter_bytes = (((size_t)(w * cpr + 4) * sizeof(int)) + 15) & ~(size_t)15;
   static bool attr_set = false;

@@ -5,11 +5,13 @@ Reference: python/triton_dist/models/engine.py:36-189.  Back-ends: ``torch`` (RC
 all-reduce kernels) and ``triton_dist_gemm_ar`` (GEMM fused with the all-reduce).
 
 Graph replay is used where the whole step is replay-safe: the torch back-end, any back-end at
-world size 1, and ``triton_dist_AR`` at any world size (its all-reduce kernels keep their call
-number on the device, so a replayed launch picks a fresh epoch and buffer parity by itself).  The
-other fused multi-rank ops number their calls with a host-side epoch, which a replayed graph would
-freeze, so ``triton_dist`` / ``triton_dist_gemm_ar`` run the same decode loop eagerly at world size
-> 1 - those ops refuse capture rather than race (utils/distributed.py: forbid_graph_capture).
+world size 1, and ``triton_dist_AR`` at any world size (the all-reduce kernels keep their call number
+on the device, so a replayed launch picks a fresh epoch and buffer parity by itself;
+csrc/include/tdist/call_state.hpp).  AG+GEMM and GEMM+RS do the same, but only accept capture when
+every rank's rows are whole 256-row tiles (prefill-sized M), and GEMM+AR / the MoE ops number their
+calls on the host; so ``triton_dist`` and ``triton_dist_gemm_ar`` run the decode loop eagerly at
+world size > 1 - the ops refuse capture rather than race (utils/distributed.py:
+forbid_graph_capture).
 """
 from __future__ import annotations
 

@@ -64,6 +64,9 @@ class AllGatherGEMMTensorParallelContext:
     call_count: int = 0
     backend: str = "hip"
     partial: Optional[torch.Tensor] = None      # split-K fp32 partial tiles (allocated on first use)
+    # in-kernel producer only: [call number, finished workgroups] int32, owned by the kernels (the
+    # call number selects parity and epoch on the device, so the launch can be replayed from a graph)
+    state: Optional[torch.Tensor] = None
 
     # names the reference exposes on its context
     @property
@@ -96,10 +99,11 @@ def create_ag_gemm_intra_node_context(max_M, N, K, input_dtype, output_dtype, ra
     # "kernel": push kernel (device-side stores + system-scope flag), no driver-dependent ordering.
     # "copy_engine": SDMA copies; flags by 4-byte copies (as the reference) or stream write-value.
     producer = producer or os.environ.get("TDIST_AG_PRODUCER", "kernel")
-    epoch_table = scratch = None
+    epoch_table = scratch = state = None
     if env.backend == "hip":
         epoch_table = torch.arange(EPOCH_MOD + 2, dtype=torch.int32, device=env.device)
         scratch = torch.zeros(8 + max_chunks, dtype=torch.int32, device=env.device)
+        state = torch.zeros(4, dtype=torch.int32, device=env.device)
         if ag_streams is None and num_ranks > 1 and getattr(env, "side_stream", None) is not None:
             ag_streams = [env.side_stream]
         if ag_streams is None and num_ranks > 1:
@@ -115,7 +119,7 @@ def create_ag_gemm_intra_node_context(max_M, N, K, input_dtype, output_dtype, ra
         M_PER_CHUNK=M_PER_CHUNK, BLOCK_M=BLOCK_M, BLOCK_N=BLOCK_N, BLOCK_K=BLOCK_K, stages=stages, autotune=autotune,
         producer=producer,
         flag_mode=os.environ.get("TDIST_AG_FLAG_MODE", "write_value" if env.shared_gpu else "memcpy"),
-        num_ctas=num_ctas, backend=env.backend)
+        num_ctas=num_ctas, backend=env.backend, state=state)
 
 
 def _rows_per_chunk(M_per_rank: int, want: int) -> int:
@@ -174,7 +178,13 @@ def ag_gemm_intra_node_op(a, b, c, ctx: AllGatherGEMMTensorParallelContext):
         gemm_nt(a, b, out=c)
         return c
     a = a.contiguous()
-    forbid_graph_capture("ag_gemm", w)
+    # The in-kernel producer numbers its calls on the device (ctx.state); every other producer takes
+    # parity and epoch from the host and must not be captured in a graph.
+    device_calls = ctx.backend == "hip" and ctx.producer == "kernel" and ctx.state is not None
+    # Capture is accepted for the configuration covered by the replay tests: whole 256-row tiles per
+    # rank.  (Shapes whose tiles straddle ranks run the same kernels eagerly.)
+    if not device_calls or M_per_rank % _BM != 0:
+        forbid_graph_capture("ag_gemm", w)
     parity = ctx.call_count & 1
     epoch = ctx.call_count % EPOCH_MOD + 1
     ctx.call_count += 1
@@ -207,30 +217,37 @@ def ag_gemm_intra_node_op(a, b, c, ctx: AllGatherGEMMTensorParallelContext):
             if env.cpu_group is not None:
                 torch.distributed.barrier(group=env.cpu_group)
 
-    ws = ctx.workspaces[parity][rank]
+    ws = ctx.workspaces[0 if device_calls else parity][rank]
+    fl = ctx.flags[0 if device_calls else parity][rank]
     straddle = straddle and w > 1
     tiles = _num_tiles(M_per_rank, w, N_local, straddle)
     split_k = _pick_split_k(tiles, K, ctx.num_ctas or 256)
     cpr = M_per_rank // rpc
     need = (8 + cpr + (tiles if split_k > 1 else 0) + 3) & ~3
     if ctx.scratch.numel() < need:
+        assert not torch.cuda.is_current_stream_capturing(), "ag_gemm: run this shape once before capturing it"
         ctx.scratch = torch.zeros(need, dtype=torch.int32, device=env.device)
     partial, partial_bytes = None, 0
     if split_k > 1:
         partial_bytes = tiles * split_k * _BM * _BM * 4
         if ctx.partial is None or ctx.partial.numel() < partial_bytes:
+            assert not torch.cuda.is_current_stream_capturing(), "ag_gemm: run this shape once before capturing it"
             ctx.partial = torch.empty(partial_bytes, dtype=torch.uint8, device=env.device)
         partial = ctx.partial
     _lib.check(
         lib.tdist_ag_gemm_consumer(ctypes.byref(env.heap.ctx_struct()), _lib.ptr(a), _lib.ptr(ws), _lib.ptr(b),
-                                   _lib.ptr(c), _lib.ptr(ctx.flags[parity][rank]), _lib.ptr(ctx.scratch),
+                                   _lib.ptr(c), _lib.ptr(fl), _lib.ptr(ctx.scratch),
                                    ctypes.c_longlong(ctx.scratch.numel()),
                                    _lib.ptr(partial) if partial is not None else ctypes.c_void_p(0),
                                    ctypes.c_longlong(partial_bytes), ctypes.c_longlong(a.stride(0)),
                                    ctypes.c_longlong(ws.stride(0)), ctypes.c_longlong(b.stride(0)),
                                    ctypes.c_longlong(c.stride(0)), M_per_rank, N_local, K, rpc, epoch,
                                    1 if straddle else 0, push_wgs, split_k, ctx.num_ctas, _DT[a.dtype],
-                                   _lib.stream_handle(cur)), "tdist_ag_gemm_consumer")
+                                   _lib.stream_handle(cur),
+                                   _lib.ptr(ctx.state) if device_calls else ctypes.c_void_p(0),
+                                   _lib.ptr(ctx.workspaces[1][rank]) if device_calls else ctypes.c_void_p(0),
+                                   _lib.ptr(ctx.flags[1][rank]) if device_calls else ctypes.c_void_p(0)),
+               "tdist_ag_gemm_consumer")
     # `a` is read by the copy-engine streams; joining them keeps the caller free to reuse it in stream order
     for s in used:
         cur.wait_stream(s)

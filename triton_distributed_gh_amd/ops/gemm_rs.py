@@ -45,6 +45,7 @@ class GEMMReduceScatterTensorParallelContext:
     num_ctas: int = 0
     call_count: int = 0
     backend: str = "hip"
+    state: Optional[torch.Tensor] = None       # HIP path: device-side [call number, finished workgroups]
 
     @property
     def scatter_bufs(self):
@@ -75,9 +76,12 @@ def create_gemm_rs_intra_node_context(max_M, N, output_dtype, rank, num_ranks, t
     for _ in range(2):
         scatter.append(heap.create_tensor_list([max_M, N], output_dtype, zero=False))
         flags.append(heap.create_tensor_list([max_chunks], torch.int32, arena="sig"))
-    scratch = None
+    scratch = state = None
     if env.backend == "hip":
         scratch = torch.zeros(max_chunks + 16, dtype=torch.int32, device=env.device)
+        # [call number, finished workgroups]: owned by the kernels, which pick buffer parity and flag
+        # value from it (csrc/include/tdist/call_state.hpp) - launches are replay-safe
+        state = torch.zeros(4, dtype=torch.int32, device=env.device)
         torch.cuda.synchronize()
     if env.cpu_group is not None:
         torch.distributed.barrier(group=env.cpu_group)
@@ -85,7 +89,7 @@ def create_gemm_rs_intra_node_context(max_M, N, output_dtype, rank, num_ranks, t
                                                   output_dtype=output_dtype, scatter=scatter, flags=flags,
                                                   scratch=scratch, env=env, fuse_scatter=fuse_scatter,
                                                   transpose_weight=transpose_weight, M_PER_CHUNK=M_PER_CHUNK,
-                                                  num_ctas=num_ctas, backend=env.backend)
+                                                  num_ctas=num_ctas, backend=env.backend, state=state)
 
 
 def _rows_per_chunk(M_per_rank: int, want: int) -> int:
@@ -108,7 +112,10 @@ def gemm_rs_intra_node_op(a, b, ctx: GEMMReduceScatterTensorParallelContext, out
     if w == 1 and os.environ.get("TDIST_FORCE_FUSED", "0") != "1":
         gemm_nt(a, b, out=out)
         return out
-    forbid_graph_capture("gemm_rs", w)
+    # Capture is accepted for the configuration covered by the replay tests (whole 256-row tiles
+    # per rank); the kernels number their calls on the device either way.
+    if ctx.backend != "hip" or M_per_rank % 256 != 0:
+        forbid_graph_capture("gemm_rs", w)
     parity = ctx.call_count & 1
     epoch = ctx.call_count % EPOCH_MOD + 1
     ctx.call_count += 1
@@ -119,11 +126,12 @@ def gemm_rs_intra_node_op(a, b, ctx: GEMMReduceScatterTensorParallelContext, out
     lib = _lib.hip()
     cstruct = env.heap.ctx_struct()
     _lib.check(
-        lib.tdist_gemm_rs(ctypes.byref(cstruct), _lib.ptr(a), _lib.ptr(b), _lib.ptr(ctx.scatter[parity][rank]),
-                          _lib.ptr(ctx.flags[parity][rank]), _lib.ptr(ctx.scratch), _lib.ptr(ctx.scratch[-4:]),
+        lib.tdist_gemm_rs(ctypes.byref(cstruct), _lib.ptr(a), _lib.ptr(b), _lib.ptr(ctx.scatter[0][rank]),
+                          _lib.ptr(ctx.flags[0][rank]), _lib.ptr(ctx.scratch), _lib.ptr(ctx.scratch[-4:]),
                           _lib.ptr(out), ctypes.c_longlong(a.stride(0)), ctypes.c_longlong(b.stride(0)),
                           ctypes.c_longlong(out.stride(0)), M_per_rank, N, K_local, rpc, epoch, ctx.num_ctas,
-                          _DT[a.dtype], _lib.stream_handle(), _lib.ptr(getattr(ctx, "debug_trace", None))),
+                          _DT[a.dtype], _lib.stream_handle(), _lib.ptr(getattr(ctx, "debug_trace", None)),
+                          _lib.ptr(ctx.state), _lib.ptr(ctx.scatter[1][rank]), _lib.ptr(ctx.flags[1][rank])),
         "tdist_gemm_rs")
     return out
 
