@@ -58,6 +58,13 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     if not force_native and M > 16 and -(-M // 256) * -(-N // 256) < 128:
         torch.matmul(a, b.t(), out=out)
         return out
+    # Decode shapes: the weight-streaming kernel wins on layers up to ~64 MB of weights and on very
+    # wide, shallow heads (151936 x 2048: 111 vs 201 us); on long-K layers of 100+ MB it reaches
+    # 4-5 TB/s against 6.3-6.6 TB/s for the library's 64x16x512 streaming kernel
+    # (profiles/decode_gemm_r1.md), so those go to the library.
+    if not force_native and M <= 16 and K >= 4096 and N * K * a.element_size() >= (96 << 20):
+        torch.matmul(a, b.t(), out=out)
+        return out
     lib = _lib.hip()
     _lib.check(
         lib.tdist_gemm_nt(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), M, N, K, ctypes.c_longlong(a.stride(0)),
