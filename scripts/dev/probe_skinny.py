@@ -12,7 +12,7 @@ def bench(fn, iters=100, warmup=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 
-shapes = [(4096, 4096), (6144, 4096), (4096, 12288), (12800, 8192), (24576, 4096), (32768, 4096), (151936, 2048)]
+shapes = [tuple(int(v) for v in sp.split("x")) for sp in sys.argv[1:]] or [(4096, 4096), (6144, 4096), (4096, 12288), (12800, 8192), (24576, 4096), (32768, 4096), (151936, 2048)]
 for M in (1, 16):
     for N, K in shapes:
         a = (torch.rand(M, K, device="cuda") - 0.5).bfloat16()
