@@ -22,12 +22,14 @@ for (M, N, K) in [(256, 256, 128), (512, 768, 256), (300, 520, 192), (4096, 8192
         a = (torch.rand(M, K, device="cuda") * 2 - 1).to(dt)
         b = (torch.rand(N, K, device="cuda") * 2 - 1).to(dt)
         out = torch.full((M, N), 7.0, device="cuda", dtype=dt)
-        gemm_nt(a, b, out=out, force_native=True, variant=3)
         ref = a.float() @ b.float().t()
-        err = ((out.float() - ref).abs().max() / ref.abs().max()).item()
-        good = err < 1e-2
-        ok &= good
-        print(f"{M}x{N}x{K} {dt}: rel err {err:.2e} {'ok' if good else 'FAIL'}", flush=True)
+        for variant in (3, 4):
+            out.fill_(7.0)
+            gemm_nt(a, b, out=out, force_native=True, variant=variant)
+            err = ((out.float() - ref).abs().max() / ref.abs().max()).item()
+            good = err < 1e-2
+            ok &= good
+            print(f"v{variant} {M}x{N}x{K} {dt}: rel err {err:.2e} {'ok' if good else 'FAIL'}", flush=True)
 if not ok:
     sys.exit(1)
 
@@ -37,7 +39,7 @@ b = (torch.rand(N, K, device="cuda") * 2 - 1).bfloat16()
 out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
 ref = a.float() @ b.float().t()
 fns = {"v2": lambda: gemm_nt(a, b, out=out, force_native=True, variant=2)}
-for opt in range(8):
+for opt in range(4):
     v = 3 | (opt << 16)
     out.zero_()
     gemm_nt(a, b, out=out, force_native=True, variant=v)
@@ -46,6 +48,7 @@ for opt in range(8):
     if err > 1e-2:
         sys.exit(1)
     fns[f"v3o{opt}"] = (lambda vv: (lambda: gemm_nt(a, b, out=out, force_native=True, variant=vv)))(v)
+fns["v4"] = lambda: gemm_nt(a, b, out=out, force_native=True, variant=4)
 fns["torch"] = lambda: torch.matmul(a, b.t(), out=out)
 del ref
 for _ in range(40):

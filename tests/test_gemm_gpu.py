@@ -39,6 +39,22 @@ def test_persistent_gemm_matches_fp32_reference(M, N, K, knobs):
         assert torch.all(out[:, N:] == 7.0), "wrote past the last column"
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 520, 192), (1000, 8200, 256), (4096, 4096, 512)])
+def test_four_wave_gemm_matches_fp32_reference(M, N, K):
+    """Variant 4: four 128x128 waves, accumulators in the accumulation registers, slab ring of four,
+    stores straight from registers (ragged edges, several tiles per workgroup, untouched padding)."""
+    torch.manual_seed(M + N * 3 + K)
+    for dtype in (torch.bfloat16, torch.float16):
+        a = (torch.rand(M, K, device="cuda") * 2 - 1).to(dtype)
+        b = (torch.rand(N, K, device="cuda") * 2 - 1).to(dtype)
+        out = torch.full((M, N + 8), 7.0, device="cuda", dtype=dtype)
+        gemm_nt(a, b, out=out[:, :N], force_native=True, variant=4)
+        ref = a.float() @ b.float().t()
+        rel = (out[:, :N].float() - ref).abs().max().item() / ref.abs().max().item()
+        assert rel < 1e-2
+        assert torch.all(out[:, N:] == 7.0), "wrote past the last column"
+
+
 def test_persistent_gemm_column_permutation_is_undone():
     # A = I: the output must be exactly B^T, so any column left in the permuted order shows up.
     K = 256

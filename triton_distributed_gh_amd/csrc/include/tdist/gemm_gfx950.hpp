@@ -60,6 +60,11 @@ struct Frag<true> {
   static __device__ __forceinline__ f32x4 mfma(T a, T b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   }
+  // accumulator pinned to the accumulation registers (the register allocator otherwise moves
+  // 256-register accumulators back and forth between the two halves of the register file)
+  static __device__ __forceinline__ void mfma_acc(T a, T b, f32x4& c) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  }
   static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
     bf16x2 v = {(__bf16)lo, (__bf16)hi};
@@ -71,6 +76,9 @@ struct Frag<false> {
   using T = f16x8;
   static __device__ __forceinline__ f32x4 mfma(T a, T b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ void mfma_acc(T a, T b, f32x4& c) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
   }
   static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
     typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
@@ -504,6 +512,176 @@ __device__ __forceinline__ void epilogue_256(const Acc<IS_BF16>& acc, char* smem
         for (int n = 0; n < 4; ++n) v[n] = acc.v[m][n];
       },
       smem, store);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Four-wave form of the 256x256 tile: 256 threads, waves 2 (M) x 2 (N), each wave owns 128x128 of C
+// (64 accumulator tiles = 256 registers, which with one wave per SIMD live in the accumulation
+// half of the register file).  Per 32-deep K slab a wave reads 8 A + 8 B fragments for 64 MFMAs -
+// 128 KiB of LDS reads per 64 of K for the workgroup instead of 192 KiB with eight 128x64 waves.
+// There is no partner wave to hide a wave's LDS / DMA segment, so reads and DMA issue are
+// interleaved with the MFMAs of the same wave:
+//   * LDS is a ring of four 32 KiB slabs ([A: 16 sub-tiles of 16 rows x 32 k][B: 16 sub-tiles],
+//     sub-tile image and XOR swizzle as above); wave w stages A and B sub-tiles 4w .. 4w+3 of every slab;
+//   * fragments are double-buffered in registers: during the MFMAs of slab s the wave reads the
+//     fragments of slab s+1 (first four MFMA rows) and issues the DMA of slab s+4 (last four rows)
+//     into the buffer slab s has just left;
+//   * one barrier per slab: before it every wave has retired its reads of slab s (lgkmcnt) and its
+//     own DMA pieces of slab s+1 (counted vmcnt: slabs s+2, s+3 stay in flight), after it slab s+1
+//     may be read and slab s's buffer restaged.
+// Accumulator columns are permuted as with PERM_B (epilogue_256_4w_direct stores from registers).
+constexpr int W4_THREADS = 256;
+constexpr int W4_SLAB = 32768;
+constexpr int W4_NS = 4;
+constexpr int W4_LDS_BYTES = W4_NS * W4_SLAB;
+
+template <bool IS_BF16>
+struct Acc4 {
+  f32x4 v[8][8];
+};
+
+template <bool IS_BF16>
+__device__ __forceinline__ void mainloop_256_4w(const TileArgs& t, char* smem, Acc4<IS_BF16>& acc) {
+  using F = Frag<IS_BF16>;
+  using V = typename F::T;
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63;
+  const int wr = w >> 1, wc = w & 1;
+  const int i = l >> 2;                                     // row inside a staged sub-tile
+  const int kchunk = (l & 3) ^ (((l >> 5) & 1) << 1);
+  const uint16_t* pa[4];
+  const uint16_t* pb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ts = 4 * w + j;                               // sub-tile index inside the slab's A / B half
+    int ar = ts * 16 + i;
+    ar = ar < t.a_rows ? ar : t.a_rows - 1;
+    // B sub-tile ts = 8 * wave column + n; its row i = 4g + r stands for output column
+    // 32*(n>>1) + 8*g + 4*(n&1) + r of that wave column's 128
+    int br = (ts >> 3) * 128 + ((ts & 7) >> 1) * 32 + (i >> 2) * 8 + (ts & 1) * 4 + (i & 3);
+    br = br < t.b_rows ? br : t.b_rows - 1;
+    pa[j] = t.A + (long long)ar * t.lda + kchunk * 8;
+    pb[j] = t.B + (long long)br * t.ldb + kchunk * 8;
+  }
+  const int ns = t.K / 32;                                  // even, >= 4
+  char* stage_dst = smem + w * 4096;
+  auto stage_piece = [&](int s, auto jc) {
+    constexpr int j = decltype(jc)::value;                  // 0..3 A, 4..7 B
+    const uint16_t* src = (j < 4 ? pa[j & 3] : pb[j & 3]) + (long long)s * 32;
+    char* dst = stage_dst + (s & 3) * W4_SLAB + (j < 4 ? 0 : 16384) + (j & 3) * 1024;
+    __builtin_amdgcn_global_load_lds(TDIST_GLB_PTR(src), TDIST_LDS_PTR(dst), 16, 0, 0);
+  };
+  auto stage_slab = [&](int s) {
+    stage_piece(s, std::integral_constant<int, 0>{}); stage_piece(s, std::integral_constant<int, 1>{});
+    stage_piece(s, std::integral_constant<int, 2>{}); stage_piece(s, std::integral_constant<int, 3>{});
+    stage_piece(s, std::integral_constant<int, 4>{}); stage_piece(s, std::integral_constant<int, 5>{});
+    stage_piece(s, std::integral_constant<int, 6>{}); stage_piece(s, std::integral_constant<int, 7>{});
+  };
+  const int lane_off = (((l & 15) * 64) + ((l >> 4) * 16)) ^ ((((l & 15) >> 3) & 1) << 5);
+  const char* a_rd = smem + wr * 8192 + lane_off;           // + slab buffer + m * 1024
+  const char* b_rd = smem + 16384 + wc * 8192 + lane_off;   // + slab buffer + n * 1024
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int n = 0; n < 8; ++n) acc.v[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  V fa[2][8], fb[2][8];
+  stage_slab(0); stage_slab(1); stage_slab(2); stage_slab(3);
+  asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    fa[0][m] = *(const V*)(a_rd + m * 1024);
+    fb[0][m] = *(const V*)(b_rd + m * 1024);
+  }
+
+  // STEADY: slab s+4 exists, so every read and every DMA piece is issued unconditionally - the
+  // instruction stream has no branches and the compiler's own lgkmcnt bookkeeping stays exact
+  // (fragments of slab s: 16 reads issued one slab ago; it waits for them with the new reads in flight).
+  auto slab_body = [&](int s, auto pc, auto steady_c) {
+    constexpr int P = decltype(pc)::value;
+    constexpr bool STEADY = decltype(steady_c)::value;
+    const bool more = STEADY || s + 1 < ns;
+    if constexpr (STEADY) {
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else if (more) {
+      if (s + 3 < ns) {
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      } else if (s + 2 < ns) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+    // all of this wave's reads of slab s (issued during slab s-1) must be retired before the
+    // barrier, because after it another wave may restage that buffer
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    const int nb = ((s + 1) & 3) * W4_SLAB;
+    const bool restage = STEADY || s + 4 < ns;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      // row m of the wave tile first, then this row's share of the memory work: the compiler
+      // (which cannot see the waits above) puts its own full lgkmcnt wait in front of the first
+      // MFMA, so nothing new may be in flight at that point
+#pragma unroll
+      for (int n = 0; n < 8; ++n) F::mfma_acc(fb[P][n], fa[P][m], acc.v[m][n]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (m < 4) {
+        if (more) {
+          fa[P ^ 1][2 * m] = *(const V*)(a_rd + nb + (2 * m) * 1024);
+          fa[P ^ 1][2 * m + 1] = *(const V*)(a_rd + nb + (2 * m + 1) * 1024);
+          fb[P ^ 1][2 * m] = *(const V*)(b_rd + nb + (2 * m) * 1024);
+          fb[P ^ 1][2 * m + 1] = *(const V*)(b_rd + nb + (2 * m + 1) * 1024);
+        }
+      } else if (restage) {
+        if (m == 4) { stage_piece(s + 4, std::integral_constant<int, 0>{}); stage_piece(s + 4, std::integral_constant<int, 1>{}); }
+        if (m == 5) { stage_piece(s + 4, std::integral_constant<int, 2>{}); stage_piece(s + 4, std::integral_constant<int, 3>{}); }
+        if (m == 6) { stage_piece(s + 4, std::integral_constant<int, 4>{}); stage_piece(s + 4, std::integral_constant<int, 5>{}); }
+        if (m == 7) { stage_piece(s + 4, std::integral_constant<int, 6>{}); stage_piece(s + 4, std::integral_constant<int, 7>{}); }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  int s = 0;
+  for (; s + 5 < ns; s += 2) {
+    slab_body(s, P0{}, std::true_type{});
+    slab_body(s + 1, P1{}, std::true_type{});
+  }
+  for (; s < ns; s += 2) {
+    slab_body(s, P0{}, std::false_type{});
+    slab_body(s + 1, P1{}, std::false_type{});
+  }
+  // every wave's last fragment reads were retired before the last slab's barrier: LDS is free.
+  // The MFMAs are inline assembly, so the compiler does not know that the accumulators are still
+  // in the matrix pipeline: cover the read-after-MFMA distance (18 wait states) by hand.
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+}
+
+// Stores of the four-wave accumulators straight from registers: 32 pieces of 16 bytes per lane,
+// `store(row_in_tile, col_in_tile, uint4)`.
+template <bool IS_BF16, class StoreFn>
+__device__ __forceinline__ void epilogue_256_4w_direct(const Acc4<IS_BF16>& acc, StoreFn&& store) {
+  using F = Frag<IS_BF16>;
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, l = tid & 63;
+  const int row = (w >> 1) * 128 + (l & 15);
+  const int col = (w & 1) * 128 + (l >> 4) * 8;
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      uint4 v;
+      v.x = F::pack2(acc.v[m][2 * p][0], acc.v[m][2 * p][1]);
+      v.y = F::pack2(acc.v[m][2 * p][2], acc.v[m][2 * p][3]);
+      v.z = F::pack2(acc.v[m][2 * p + 1][0], acc.v[m][2 * p + 1][1]);
+      v.w = F::pack2(acc.v[m][2 * p + 1][2], acc.v[m][2 * p + 1][3]);
+      store(row + m * 16, col + 32 * p, v);
+    }
 }
 
 // Bijective remap of a linear workgroup id so that each group of ids that shares an XCD

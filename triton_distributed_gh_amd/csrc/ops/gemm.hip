@@ -87,6 +87,42 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_256_persistent_kernel(cons
   }
 }
 
+// Four-wave persistent form (variant 4): see mainloop_256_4w.
+template <bool IS_BF16>
+__global__ __launch_bounds__(W4_THREADS) void gemm_nt_256_4w_kernel(const uint16_t* __restrict__ A,
+                                                                    const uint16_t* __restrict__ B,
+                                                                    uint16_t* __restrict__ C, int M, int N, int K,
+                                                                    long long lda, long long ldb, long long ldc,
+                                                                    int group_m) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int num_pid_m = (M + BM - 1) / BM;
+  const int num_pid_n = (N + BN - 1) / BN;
+  const int nwg = num_pid_m * num_pid_n;
+  for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
+    const int id = xcd_remap(vb, nwg);
+    int pid_m, pid_n;
+    tile_coords(id, num_pid_m, num_pid_n, group_m, pid_m, pid_n);
+    const int row0 = pid_m * BM, col0 = pid_n * BN;
+    TileArgs t;
+    t.A = A + (long long)row0 * lda;
+    t.B = B + (long long)col0 * ldb;
+    t.lda = lda;
+    t.ldb = ldb;
+    t.a_rows = M - row0;
+    t.b_rows = N - col0;
+    t.K = K;
+    Acc4<IS_BF16> acc;
+    mainloop_256_4w<IS_BF16>(t, smem, acc);
+    const int mrem = M - row0, nrem = N - col0;
+    uint16_t* cbase = C + (long long)row0 * ldc + col0;
+    epilogue_256_4w_direct<IS_BF16>(acc, [&](int r, int c, const uint4& v) {
+      if (r < mrem && c < nrem) *(uint4*)(cbase + (long long)r * ldc + c) = v;
+    });
+    // the next tile's prologue restages all four slabs: every wave must be done reading first
+    __syncthreads();
+  }
+}
+
 // Decode-shaped GEMM (M <= 16): the weights are streamed exactly once with non-temporal 16-byte
 // loads and feed 16x16x32 MFMAs whose M dimension is the zero-padded batch.  A workgroup of four
 // (or eight, NW) waves covers BN = 16 * WN output columns (WN = 1 / 2 / 4); wave k owns the k-th slice
@@ -227,6 +263,29 @@ TDIST_API int tdist_gemm_nt(const void* A, const void* B, void* C, int M, int N,
       for (int j = 0; j < 2; ++j)
         TDIST_HIP_TRY(hipFuncSetAttribute((const void*)table[i][j], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set = true;
+  }
+  if ((variant & 255) == 4) {
+    static int num_cus4 = 0;
+    if (!num_cus4) {
+      int dev = 0;
+      TDIST_HIP_TRY(hipGetDevice(&dev));
+      TDIST_HIP_TRY(hipDeviceGetAttribute(&num_cus4, hipDeviceAttributeMultiprocessorCount, dev));
+      TDIST_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_256_4w_kernel<true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES));
+      TDIST_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_256_4w_kernel<false>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES));
+    }
+    int grid = num_cus4 & ~7;
+    if (grid < 8) grid = 8;
+    if (tiles < grid) grid = tiles;
+    if (dtype == 0)
+      hipLaunchKernelGGL(gemm_nt_256_4w_kernel<true>, dim3(grid), dim3(W4_THREADS), W4_LDS_BYTES, (hipStream_t)stream,
+                         (const uint16_t*)A, (const uint16_t*)B, (uint16_t*)C, M, N, K, lda, ldb, ldc, group_m);
+    else
+      hipLaunchKernelGGL(gemm_nt_256_4w_kernel<false>, dim3(grid), dim3(W4_THREADS), W4_LDS_BYTES, (hipStream_t)stream,
+                         (const uint16_t*)A, (const uint16_t*)B, (uint16_t*)C, M, N, K, lda, ldb, ldc, group_m);
+    TDIST_HIP_TRY(hipGetLastError());
+    return 0;
   }
   if ((variant & 255) == 3) {
     typedef void (*pkern_t)(const uint16_t*, const uint16_t*, uint16_t*, int, int, int, long long, long long, long long, int);
