@@ -284,7 +284,11 @@ __device__ __forceinline__ void mainloop_256(const TileArgs& t, char* smem, Acc<
 // once after the barrier, 2 = no s_setprio around the MFMA segment.  Measured at 4096x8192x8192 bf16
 // (MI355X, interleaved with the default): OPT 3 is 0.5-0.8 % faster, each bit alone is neutral.
 // Issuing the LDS-DMA loads between the MFMAs of the compute segment instead of in the read segment
-// was measured 10 % slower and is not kept.
+// was measured 10 % slower and is not kept.  Timing experiments with this loop (results discarded):
+// without any staging in the loop the GEMM takes 306-311 us instead of 353 us; with the staging kept
+// but its vmcnt waits removed, or its sources pinned to K-step 0 (cache hits), it stays within 3 % of
+// the full kernel - the cost is the issue of the eight LDS-DMA pieces per wave and K-step itself,
+// not HBM latency or bandwidth.
 template <bool IS_BF16, bool PERM_B = false, int OPT = 0>
 __device__ __forceinline__ void mainloop_256_2ph(const TileArgs& t, char* smem, Acc<IS_BF16>& acc) {
   using F = Frag<IS_BF16>;
