@@ -73,7 +73,26 @@ def main():
                              ("gemm_rs", lambda r, e: mlps[r].torch_gemm_rs(y))):
                 R.print_all(f"torch {name}: {R.time(fn, args.warmup, args.iters):.4f} ms")
     else:
-        R.print_all(f"dist-triton mlp ({args.mode}): {R.time(lambda r, e: fwd(r), args.warmup, args.iters):.4f} ms")
+        run = lambda r, e: fwd(r)
+        # CUDA_GRAPH=1 (reference: kernels/amd/all_gather_gemm.py:310, amd-ci.yml:48-52): one forward is
+        # captured per process and replayed.  The fused kernels number their calls on the device, so a
+        # replay is a fresh call; AG+GEMM / GEMM+RS accept capture for whole 256-row tiles per rank.
+        capturable = args.mode == "allreduce" or (args.mode == "ag_rs" and Mr % 256 == 0) or w == 1
+        if os.environ.get("CUDA_GRAPH", "0") == "1" and not R.virtual and dev.type == "cuda" and capturable:
+            r0 = R.local_ranks[0]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    fwd(r0)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                fwd(r0)
+            run = lambda r, e: graph.replay()
+            R.print("HIP graph captured")
+        R.print_all(f"dist-triton mlp ({args.mode}): {R.time(run, args.warmup, args.iters):.4f} ms")
         if not R.virtual:
             R.print_all(f"torch mlp: {R.time(lambda r, e: mlps[r].torch_fwd(x), args.warmup, args.iters):.4f} ms")
     R.close()
