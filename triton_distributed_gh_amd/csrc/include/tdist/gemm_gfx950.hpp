@@ -321,6 +321,10 @@ __device__ __forceinline__ void mainloop_256_2ph(const TileArgs& t, char* smem, 
   const uint16_t* pb1 = t.B + (long long)brow1 * t.ldb + kchunk * 8;
   const int nt = t.K / BK;
   const int stage_sub = w * 2048;
+  // (Staging through the buffer form - `buffer_load_dwordx4 ... offen lds` with the tile bases in two
+  // scalar descriptors and the K walk in the scalar offset, no vector address arithmetic per piece -
+  // was measured too: 350.7 vs 354.4 us and 352.0 vs 350.1 us against the global form, i.e. noise.
+  // Its immediate offset also shifts the LDS destination, so it cannot address the second k half.)
   auto stage = [&](int kt, auto kind_c) {
     constexpr int kind = decltype(kind_c)::value;
     if (kt < nt) {
