@@ -164,3 +164,42 @@ def test_sp_ag_attention(w, zigzag, causal):
                 assert err < 3e-2, f"rank {r} iter {it}: {err}"
     finally:
         vc.close()
+
+
+@pytest.mark.parametrize("B,S,Hq,Hkv,D,norm", [(1, 1, 32, 8, 128, True), (3, 1, 8, 8, 64, False), (2, 5, 16, 4, 128, True),
+                                                (1, 7, 4, 2, 256, True)])
+def test_qkv_prep_matches_separate_kernels(B, S, Hq, Hkv, D, norm):
+    """Fused per-head norm + rope + cache append + attended length vs rms_norm / apply_rope_ / kv_append."""
+    from triton_distributed_gh_amd.ops import elementwise
+
+    torch.manual_seed(B * 100 + S * 10 + Hq)
+    dev, bf = "cuda", torch.bfloat16
+    max_len, W = 64, (Hq + 2 * Hkv) * D
+    big = (torch.rand(B, S, W + 64, device=dev) * 2 - 1).to(bf)
+    qkv = big[:, :, :W]                                            # strided rows
+    qw = (torch.rand(D, device=dev) + 0.5).to(bf) if norm else None
+    kw = (torch.rand(D, device=dev) + 0.5).to(bf) if norm else None
+    cos, sin = elementwise.rope_cache(256, D, device=dev)
+    offs = torch.randint(0, max_len - S, (B,), device=dev, dtype=torch.int32)
+    pos = offs.long()[:, None] + torch.arange(S, device=dev)[None]
+    kc = torch.zeros(B, max_len, Hkv, D, device=dev, dtype=bf)
+    vc = torch.zeros_like(kc)
+    total = torch.zeros(B, dtype=torch.int32, device=dev)
+    assert elementwise.qkv_prep_supported(qkv, kc, vc, D)
+    q = elementwise.qkv_prep(qkv, qw, kw, 1e-6, 1e-6, pos, cos, sin, kc, vc, offs, total, Hq, Hkv, D)
+    # reference: the separate ops
+    qr, kr, vr = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+    qr, kr = qr.reshape(-1, D).contiguous(), kr.reshape(-1, D).contiguous()
+    if norm:
+        qr, kr = elementwise.rms_norm(qr, qw, 1e-6), elementwise.rms_norm(kr, kw, 1e-6)
+    qr = elementwise.apply_rope_(qr.view(B * S, Hq, D).clone(), pos.reshape(-1), cos, sin)
+    kr = elementwise.apply_rope_(kr.view(B * S, Hkv, D).clone(), pos.reshape(-1), cos, sin)
+    kc_ref, vc_ref = torch.zeros_like(kc), torch.zeros_like(vc)
+    slots = (torch.arange(B, device=dev)[:, None] * max_len + pos).reshape(-1)
+    elementwise.kv_append(kr, kc_ref, slots)
+    elementwise.kv_append(vr.reshape(B * S, Hkv, D).contiguous(), vc_ref, slots)
+    assert torch.equal(total, offs + S)
+    assert torch.equal(vc, vc_ref)
+    assert (q.view(B * S, Hq, D).float() - qr.float()).abs().max().item() <= 2e-2
+    assert (kc.float() - kc_ref.float()).abs().max().item() <= 2e-2
+    assert torch.equal(kc == 0, kc_ref == 0) or (kc != 0).sum() == (kc_ref != 0).sum()

@@ -111,6 +111,83 @@ __global__ __launch_bounds__(256) void rope_kernel(uint16_t* __restrict__ x, con
   }
 }
 
+// Everything between the QKV projection and the attention kernel in ONE launch (decode runs it once
+// per layer, where each separate launch costs more than the work): per token and head
+//   q heads : [rmsnorm(head) * q_w] -> rope -> q_out [tokens, Hq, D]
+//   k heads : [rmsnorm(head) * k_w] -> rope -> k_cache[b, kv_offset[b] + s, head]
+//   v heads :                                 v_cache[b, kv_offset[b] + s, head]
+// and total_out[b] = kv_offset[b] + S (the length the attention kernel has to cover).  One wave per
+// head, four heads per workgroup; lane i owns elements i and i + D/2 of the head (the neox rotation
+// pair).  The norm result is rounded to 16 bits before the rotation, like the separate kernels do.
+// Role in the reference: layers/amd/tp_attn.py:52-168 (norm + rope) and the mega kernel's
+// qk_norm_rope_update_kvcache task (mega_triton_kernel/kernels/norm.py:31-190).
+__global__ __launch_bounds__(256) void qkv_prep_kernel(const uint16_t* __restrict__ qkv, long long qkv_stride,
+                                                       const uint16_t* __restrict__ q_w, const uint16_t* __restrict__ k_w,
+                                                       float q_eps, float k_eps, const long long* __restrict__ pos,
+                                                       const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                       uint16_t* __restrict__ q_out, uint16_t* __restrict__ k_cache,
+                                                       uint16_t* __restrict__ v_cache, const int* __restrict__ kv_offset,
+                                                       int* __restrict__ total_out, int S, int Hq, int Hkv, int D,
+                                                       long long max_len) {
+  const long long tok = blockIdx.x;
+  const int b = (int)(tok / S), sidx = (int)(tok % S);
+  const int head = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int off = kv_offset[b];
+  if (blockIdx.y == 0 && threadIdx.x == 0 && sidx == 0) total_out[b] = off + S;
+  if (head >= Hq + 2 * Hkv) return;
+  const long long slot = off + sidx;
+  const bool slot_ok = slot >= 0 && slot < max_len;        // a full cache drops the token instead of writing outside
+  const uint16_t* src = qkv + tok * qkv_stride + (long long)head * D;
+  if (head >= Hq + Hkv) {
+    if (!slot_ok) return;
+    uint16_t* dst = v_cache + (((long long)b * max_len + slot) * Hkv + (head - Hq - Hkv)) * D;
+    for (int c = lane * 8; c < D; c += 512) *(uint4*)(dst + c) = *(const uint4*)(src + c);
+    return;
+  }
+  const bool is_q = head < Hq;
+  const int half = D >> 1;
+  const uint16_t* w = is_q ? q_w : k_w;
+  float a[2] = {0.f, 0.f}, c[2] = {0.f, 0.f};
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = lane + 64 * j;
+    if (i < half) {
+      a[j] = __builtin_bit_cast(float, (uint32_t)src[i] << 16);
+      c[j] = __builtin_bit_cast(float, (uint32_t)src[i + half] << 16);
+      ss += a[j] * a[j] + c[j] * c[j];
+    }
+  }
+  if (w) {
+    ss = wave_sum(ss);
+    const float inv = rsqrtf(ss / D + (is_q ? q_eps : k_eps));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = lane + 64 * j;
+      if (i < half) {
+        const float w1 = __builtin_bit_cast(float, (uint32_t)w[i] << 16);
+        const float w2 = __builtin_bit_cast(float, (uint32_t)w[i + half] << 16);
+        a[j] = (float)(__bf16)(a[j] * inv * w1);
+        c[j] = (float)(__bf16)(c[j] * inv * w2);
+      }
+    }
+  }
+  if (!is_q && !slot_ok) return;
+  uint16_t* dst = is_q ? q_out + (tok * Hq + head) * D
+                       : k_cache + (((long long)b * max_len + slot) * Hkv + (head - Hq)) * D;
+  const long long p = pos[tok];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = lane + 64 * j;
+    if (i < half) {
+      const float co = cos_t[p * half + i], si = sin_t[p * half + i];
+      const __bf16 o1 = (__bf16)(a[j] * co - c[j] * si), o2 = (__bf16)(c[j] * co + a[j] * si);
+      dst[i] = __builtin_bit_cast(uint16_t, o1);
+      dst[i + half] = __builtin_bit_cast(uint16_t, o2);
+    }
+  }
+}
+
 // y[row, c] = silu(gu[row, c]) * gu[row, inter + c]   (gate and up halves of one [*, 2*inter] tensor)
 __global__ __launch_bounds__(256) void silu_mul_kernel(const uint16_t* __restrict__ gu, uint16_t* __restrict__ y,
                                                        long long rows, int inter) {
@@ -184,6 +261,23 @@ TDIST_API int tdist_rope(void* x, const long long* pos, const float* cos_t, cons
   if (tokens == 0) return 0;
   hipLaunchKernelGGL(rope_kernel, dim3((unsigned)tokens), dim3(256), 0, (hipStream_t)stream, (uint16_t*)x, pos, cos_t,
                      sin_t, heads, D, token_stride, head_stride);
+  TDIST_HIP_TRY(hipGetLastError());
+  return 0;
+}
+TDIST_API int tdist_qkv_prep(const void* qkv, long long qkv_stride, const void* q_w, const void* k_w, float q_eps,
+                             float k_eps, const long long* pos, const float* cos_t, const float* sin_t, void* q_out,
+                             void* k_cache, void* v_cache, const int* kv_offset, int* total_out, long long tokens, int S,
+                             int Hq, int Hkv, int D, long long max_len, void* stream) {
+  TDIST_REQUIRE(D == 64 || D == 128 || D == 256, "head_dim must be 64, 128 or 256");
+  TDIST_REQUIRE(S > 0 && Hq > 0 && Hkv > 0 && max_len > 0 && qkv_stride % 8 == 0, "bad shape");
+  TDIST_REQUIRE((((uintptr_t)qkv | (uintptr_t)q_out | (uintptr_t)k_cache | (uintptr_t)v_cache) & 15) == 0,
+                "tensors must be 16-byte aligned");
+  if (tokens == 0) return 0;
+  const int heads = Hq + 2 * Hkv;
+  hipLaunchKernelGGL(qkv_prep_kernel, dim3((unsigned)tokens, (unsigned)((heads + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, (const uint16_t*)qkv, qkv_stride, (const uint16_t*)q_w, (const uint16_t*)k_w,
+                     q_eps, k_eps, pos, cos_t, sin_t, (uint16_t*)q_out, (uint16_t*)k_cache, (uint16_t*)v_cache,
+                     kv_offset, total_out, S, Hq, Hkv, D, max_len);
   TDIST_HIP_TRY(hipGetLastError());
   return 0;
 }

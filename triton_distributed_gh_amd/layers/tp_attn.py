@@ -114,6 +114,18 @@ class TP_Attn:
         """qkv [bsz, q_len, (q + 2 kv) / w] -> attention output [bsz, q_len, q / w]."""
         bsz, q_len, _ = qkv.shape
         D = self.head_dim
+        k_cache, v_cache, kv_offset = kv_cache.update_kv_cache(None, None, layer_idx)
+        total = getattr(kv_cache, "total_len", None)
+        if (total is not None and kv_offset.dtype == torch.int32 and k_cache.dim() == 4 and k_cache.shape[0] == bsz
+                and elementwise.qkv_prep_supported(qkv, k_cache, v_cache, D) and cos_sin_cache[0].is_cuda):
+            # one launch: per-head norms, rotation, cache append, attended length (ops/elementwise.py: qkv_prep)
+            q = elementwise.qkv_prep(qkv, getattr(self, "q_norm_w", None), getattr(self, "k_norm_w", None),
+                                     getattr(self, "q_norm_eps", 0.0), getattr(self, "k_norm_eps", 0.0), position_ids,
+                                     cos_sin_cache[0], cos_sin_cache[1], k_cache, v_cache, kv_offset, total,
+                                     self.q_size // D, self.kv_size // D, D)
+            out = flash_attn_with_kvcache(q=q, k_cache=k_cache, v_cache=v_cache, cache_seqlens=total, causal=True,
+                                          seq_table=getattr(kv_cache, "seq_table", None))
+            return out.reshape(bsz, q_len, -1)
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
         v = v.reshape(bsz, q_len, -1, D)
         if hasattr(self, "q_norm_eps"):

@@ -25,6 +25,11 @@ class KV_Cache:
         self.k_cache = torch.zeros(shape, device=self.device, dtype=dtype)
         self.v_cache = torch.zeros(shape, device=self.device, dtype=dtype)
         self.kv_offset = torch.zeros(batch_size, dtype=torch.int32, device=self.device)
+        # scratch of the fused norm + rope + append kernel (lengths including the tokens of this
+        # step) and the one-page-per-sequence table of the decode kernel: created once here so that a
+        # decode step launches no index arithmetic
+        self.total_len = torch.zeros(batch_size, dtype=torch.int32, device=self.device)
+        self.seq_table = torch.arange(batch_size, dtype=torch.int32, device=self.device).view(batch_size, 1)
 
     def update_kv_cache(self, new_k_cache: torch.Tensor, new_v_cache: torch.Tensor, layer_idx: int):
         """Returns the layer's cache views and offsets; the attention op appends k/v itself."""

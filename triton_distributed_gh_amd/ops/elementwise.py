@@ -64,6 +64,36 @@ def apply_rope_(x: torch.Tensor, positions: torch.Tensor, cos: torch.Tensor, sin
     return x
 
 
+def qkv_prep_supported(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, head_dim: int) -> bool:
+    return (_native(qkv, k_cache, v_cache) and head_dim in (64, 128, 256) and qkv.dim() == 3 and qkv.stride(2) == 1
+            and qkv.stride(1) % 8 == 0 and (qkv.shape[1] == 1 or qkv.stride(0) == qkv.shape[1] * qkv.stride(1))
+            and k_cache.is_contiguous() and v_cache.is_contiguous() and qkv.data_ptr() % 16 == 0)
+
+
+def qkv_prep(qkv: torch.Tensor, q_w: Optional[torch.Tensor], k_w: Optional[torch.Tensor], q_eps: float, k_eps: float,
+             position_ids: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, k_cache: torch.Tensor,
+             v_cache: torch.Tensor, kv_offset: torch.Tensor, total_out: torch.Tensor, num_q_heads: int,
+             num_kv_heads: int, head_dim: int) -> torch.Tensor:
+    """One launch for everything between the QKV projection and attention.
+
+    ``qkv [B, S, (Hq + 2 Hkv) * D]`` (row stride free): q/k heads get their optional per-head RMSNorm
+    (``q_w`` / ``k_w`` [D]) and the neox rotation at ``position_ids [B, S]``; k and v rows are appended
+    to ``k_cache / v_cache [B, max_len, Hkv, D]`` at ``kv_offset[b] + s`` (int32 [B]); ``total_out[b]``
+    (int32 [B]) receives ``kv_offset[b] + S``.  Returns q ``[B, S, Hq, D]``.  Call
+    ``qkv_prep_supported`` first."""
+    B, S, _ = qkv.shape
+    q = torch.empty((B, S, num_q_heads, head_dim), dtype=qkv.dtype, device=qkv.device)
+    pos = position_ids.to(torch.int64).contiguous()
+    assert kv_offset.dtype == torch.int32 and total_out.dtype == torch.int32 and cos.dtype == torch.float32
+    _lib.check(
+        _lib.hip().tdist_qkv_prep(_lib.ptr(qkv), ctypes.c_longlong(qkv.stride(1)), _lib.ptr(q_w), _lib.ptr(k_w),
+                                  ctypes.c_float(q_eps), ctypes.c_float(k_eps), _lib.ptr(pos), _lib.ptr(cos),
+                                  _lib.ptr(sin), _lib.ptr(q), _lib.ptr(k_cache), _lib.ptr(v_cache), _lib.ptr(kv_offset),
+                                  _lib.ptr(total_out), ctypes.c_longlong(B * S), S, num_q_heads, num_kv_heads, head_dim,
+                                  ctypes.c_longlong(k_cache.shape[1]), _lib.stream_handle()), "tdist_qkv_prep")
+    return q
+
+
 def silu_mul(gate_up: torch.Tensor) -> torch.Tensor:
     """gate_up [..., 2*I] -> silu(gate) * up  [..., I]."""
     inter = gate_up.shape[-1] // 2

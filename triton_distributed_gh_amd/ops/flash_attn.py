@@ -114,7 +114,8 @@ def _identity_table(device, bsz: int, pages: int) -> torch.Tensor:
     return t
 
 
-def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, cache_seqlens=None, softmax_scale=None, causal=True):
+def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, cache_seqlens=None, softmax_scale=None, causal=True,
+                            seq_table=None):
     """q [B, Sq, Hq, D]; caches [B, max_len, Hkv, D] (contiguous per sequence); ``k``/``v``
     [B, Sq, Hkv, D] are appended at ``cache_seqlens`` first.  Sq == 1 runs split-KV decode, longer
     queries the prefill kernel over the cache prefix."""
@@ -122,17 +123,20 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, cache_seqlens=N
     max_len, Hkv = k_cache.shape[1], k_cache.shape[2]
     if cache_seqlens is None:
         cache_seqlens = torch.zeros(B, dtype=torch.int32, device=q.device)
-    cache_seqlens = cache_seqlens.to(torch.int32)
+    if cache_seqlens.dtype != torch.int32:
+        cache_seqlens = cache_seqlens.to(torch.int32)
     if k is not None:
         pos = cache_seqlens.long().unsqueeze(1) + torch.arange(Sq, device=q.device).unsqueeze(0)   # [B, Sq]
         slots = (torch.arange(B, device=q.device).unsqueeze(1) * max_len + pos).reshape(-1)
         elementwise.kv_append(k.reshape(B * Sq, Hkv, D), k_cache, slots)
         elementwise.kv_append(v.reshape(B * Sq, Hkv, D), v_cache, slots)
-    total = (cache_seqlens + (Sq if k is not None else 0)).to(torch.int32)
+    # with k / v already in the cache, ``cache_seqlens`` is the length to attend over and ``seq_table``
+    # (int32 [B, 1] = arange) may be passed in, so a decode step launches nothing but the attention kernel
+    total = (cache_seqlens + Sq).to(torch.int32) if k is not None else cache_seqlens
     scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(D)
     native = q.is_cuda and q.dtype in (torch.bfloat16, torch.float16) and k_cache.is_contiguous() and v_cache.is_contiguous()
     if Sq == 1 and native and D in (64, 128, 256):
-        table = _identity_table(q.device, B, 1)
+        table = seq_table if seq_table is not None else _identity_table(q.device, B, 1)
         # one "page" per sequence: page size = max_len
         kc = k_cache.view(B, max_len, Hkv, D)
         vc = v_cache.view(B, max_len, Hkv, D)
