@@ -34,11 +34,15 @@ def _tickets(device, n: int) -> torch.Tensor:
 
 
 def auto_kv_splits(batch: int, q_heads: int, kv_heads: int, max_kv_len: int, num_cus: int = 256) -> int:
-    """Enough workgroups for ~2 waves of the chip, but at least 256 tokens of KV per split."""
+    """Enough workgroups for ~2 waves of the chip, but at least 256 tokens of KV per split - or 64
+    when even that many splits leave most CUs idle (small batch, short context: with 8 KV heads and
+    512 tokens two splits are 16 workgroups streaming 128 KiB each, 27 us on MI355X)."""
     group = q_heads // kv_heads
     base = batch * kv_heads * ((group + 15) // 16)
     want = max(1, (2 * num_cus + base - 1) // base)
     cap = max(1, max_kv_len // 256)
+    if base * cap < num_cus:
+        cap = max(1, max_kv_len // 64)
     return int(max(1, min(want, cap, 64)))
 
 
