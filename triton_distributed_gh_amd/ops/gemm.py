@@ -23,6 +23,8 @@ from ..autotuner import tuning
 _DT = {torch.bfloat16: 0, torch.float16: 1}
 # main-loop schedule: 1 = four phases per K-step, 2 = two phases per K-step
 GEMM_VARIANT = int(os.environ.get("TDIST_GEMM_VARIANT", "2"))
+# decode layers (M <= 16, K >= 4096) with at least this many MiB of weights go to the library (0 = never)
+DECODE_LIB_BYTES = int(os.environ.get("TDIST_DECODE_GEMM_LIB_MB", "0")) << 20
 
 
 def gemm_supported(a: torch.Tensor, b: torch.Tensor) -> bool:
@@ -58,11 +60,13 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     if not force_native and M > 16 and -(-M // 256) * -(-N // 256) < 128:
         torch.matmul(a, b.t(), out=out)
         return out
-    # Decode shapes: the weight-streaming kernel wins on layers up to ~64 MB of weights and on very
-    # wide, shallow heads (151936 x 2048: 111 vs 201 us); on long-K layers of 100+ MB it reaches
-    # 4-5 TB/s against 6.3-6.6 TB/s for the library's 64x16x512 streaming kernel
-    # (profiles/decode_gemm_r1.md), so those go to the library.
-    if not force_native and M <= 16 and K >= 4096 and N * K * a.element_size() >= (96 << 20):
+    # Decode shapes stay on the weight-streaming kernel.  Called back to back on ONE 100-270 MB layer the
+    # library's 64x16x512 kernel looks faster (6.3-6.6 vs 4-5 TB/s), but there the weights partly sit in
+    # the 256 MB memory-side cache; in a real decode step (Qwen3-8B, every layer streamed from HBM) the
+    # step takes 4.51 ms with this kernel everywhere against 4.69 ms with those layers on the library
+    # (profiles/decode_gemm_r1.md).  TDIST_DECODE_GEMM_LIB_MB sets a size from which the library is used.
+    if (not force_native and DECODE_LIB_BYTES > 0 and M <= 16 and K >= 4096
+            and N * K * a.element_size() >= DECODE_LIB_BYTES):
         torch.matmul(a, b.t(), out=out)
         return out
     lib = _lib.hip()
