@@ -112,3 +112,22 @@ def test_decode_gemm_matches_fp32_reference(M, N, K, dtype):
     # same numbers as the tile kernel within rounding (debug bit 1 of the variant forces it)
     c2 = gemm_nt(a, b, force_native=True, variant=2 | (2 << 8))
     assert (c2.float() - out[:, :N].float()).abs().max().item() <= 2e-2 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("M", [1, 7, 16])
+@pytest.mark.parametrize("I,K", [(1024, 512), (12288, 4096), (1000, 192)])
+def test_decode_gemm_with_silu_mul_epilogue(M, I, K):
+    """gate_up projection + silu(gate) * up in one launch vs the two separate kernels and fp32."""
+    from triton_distributed_gh_amd.ops.elementwise import silu_mul
+    from triton_distributed_gh_amd.ops.gemm import gemm_nt_silu_mul
+
+    torch.manual_seed(M + I + K)
+    a = (torch.rand(M, K, device="cuda") * 2 - 1).bfloat16()
+    w = ((torch.rand(2 * I, K, device="cuda") * 2 - 1) * 0.1).bfloat16()
+    got = gemm_nt_silu_mul(a, w)
+    two = silu_mul(gemm_nt(a, w, force_native=True))
+    gu = a.float() @ w.float().t()
+    ref = torch.nn.functional.silu(gu[:, :I]) * gu[:, I:]
+    assert got.shape == (M, I)
+    assert (got.float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item() + 1e-3
+    assert (got.float() - two.float()).abs().max().item() <= 1e-2 * ref.abs().max().item() + 1e-3

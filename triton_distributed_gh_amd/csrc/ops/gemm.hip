@@ -131,7 +131,12 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_nt_256_4w_kernel(const uint16
 // lane keeps sixteen 16-byte weight loads in flight.  The K slices are summed through LDS, one
 // column group per wave.  Eight waves are used when the grid alone cannot fill the chip (short N)
 // and K is long enough to give every wave a few batches of loads.
-template <bool IS_BF16, int WN, int NW>
+//
+// SILU (WN == 2): W is a gate_up weight [2 I, K]; the workgroup's two column groups are gate columns
+// n0 .. n0+15 and the matching up columns I + n0 .. I + n0+15, and the epilogue stores
+// silu(gate) * up into C [M, I] - the activation kernel of a gated MLP folded into its first projection
+// (reference: mega_triton_kernel/kernels/mlp_fc1.py + activation.py as two tasks).
+template <bool IS_BF16, int WN, int NW, bool SILU = false>
 __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const uint16_t* __restrict__ X,
                                                              const uint16_t* __restrict__ W,
                                                              uint16_t* __restrict__ C, int M, int N, int K,
@@ -139,8 +144,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const uint16_t*
   using F = Frag<IS_BF16>;
   using VT = typename F::T;
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-  constexpr int BN_ = 16 * WN;
+  static_assert(!SILU || WN == 2, "the fused activation pairs one gate group with one up group");
+  constexpr int BN_ = SILU ? 16 : 16 * WN;               // output columns per workgroup
   constexpr int U = 16 / WN;                             // K-steps per batch of loads (16 weight loads in flight)
+  const int up_off = SILU ? N : 0;                       // (SILU: N is I, the number of OUTPUT columns)
   __shared__ float red[NW * WN * 64 * 4];                // [K slice][column group][lane][4]
   const int wk = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int li = lane & 15, lg = lane >> 4;
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const uint16_t*
   const uint16_t* wr[WN];
 #pragma unroll
   for (int j = 0; j < WN; ++j)                            // clamped: out-of-range columns are not stored
-    wr[j] = W + (long long)min(n0 + j * 16 + li, N - 1) * ldw + lg * 8;
+    wr[j] = W + (long long)(SILU ? j * up_off + min(n0 + li, N - 1) : min(n0 + j * 16 + li, N - 1)) * ldw + lg * 8;
   const bool xvalid = li < M;
   f32x4 acc[WN];
 #pragma unroll
@@ -191,6 +198,29 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const uint16_t*
     for (int r = 0; r < 4; ++r) slot[r] = acc[j][r];
   }
   __syncthreads();
+  if constexpr (SILU) {
+    if (wk != 0) return;
+    f32x4 g = {0.f, 0.f, 0.f, 0.f}, up = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      const float* og = red + ((q * WN + 0) * 64 + lane) * 4;
+      const float* ou = red + ((q * WN + 1) * 64 + lane) * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) g[r] += og[r], up[r] += ou[r];
+    }
+    const int col = n0 + li;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * lg + r;
+      // the separate kernels round gate and up to 16 bits first: do the same, then activate
+      const float gr = IS_BF16 ? (float)(__bf16)g[r] : (float)(_Float16)g[r];
+      const float ur = IS_BF16 ? (float)(__bf16)up[r] : (float)(_Float16)up[r];
+      const float mine = gr / (1.f + __expf(-gr)) * ur;
+      const float other = __shfl_xor(mine, 1);
+      if (row < M && col < N && (li & 1) == 0) *(uint32_t*)(C + (long long)row * ldc + col) = F::pack2(mine, other);
+    }
+    return;
+  }
   if (wk >= WN) return;
   f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -235,6 +265,20 @@ static void launch_skinny(const void* A, const void* B, void* C, int M, int N, i
     hipLaunchKernelGGL((gemm_nt_skinny_kernel<IS_BF16, 1, 8>), grid, dim3(512), 0, s, a, b, c, M, N, K, lda, ldb, ldc);
   else
     hipLaunchKernelGGL((gemm_nt_skinny_kernel<IS_BF16, 1, 4>), grid, dim3(256), 0, s, a, b, c, M, N, K, lda, ldb, ldc);
+}
+
+// C[M, I] = silu(X W[0:I]^T) * (X W[I:2I]^T) for M <= 16 (W = gate_up weight [2 I, K], bf16 only).
+TDIST_API int tdist_gemm_nt_silu_mul(const void* X, const void* W, void* C, int M, int I, int K, long long ldx,
+                                     long long ldw, long long ldc, void* stream) {
+  TDIST_REQUIRE(M > 0 && M <= 16 && I > 0 && I % 2 == 0, "M must be in [1, 16], I even");
+  TDIST_REQUIRE(K >= 128 && K % 32 == 0, "K must be a multiple of 32 and >= 128");
+  TDIST_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && ldc % 2 == 0, "row strides must keep the vector alignment");
+  TDIST_REQUIRE((((uintptr_t)X | (uintptr_t)W) & 15) == 0 && (((uintptr_t)C) & 3) == 0, "operands must be aligned");
+  const dim3 grid((I + 15) / 16);
+  hipLaunchKernelGGL((gemm_nt_skinny_kernel<true, 2, 4, true>), grid, dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)X, (const uint16_t*)W, (uint16_t*)C, M, I, K, ldx, ldw, ldc);
+  TDIST_HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 // dtype: 0 = bf16, 1 = fp16.  Requires K % 64 == 0, K >= 128, N % 8 == 0, 16-byte aligned rows.

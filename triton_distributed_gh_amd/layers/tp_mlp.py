@@ -17,7 +17,7 @@ import torch
 from ..ops import elementwise
 from ..ops.ag_gemm import ag_gemm_intra_node, create_ag_gemm_intra_node_context
 from ..ops.allreduce import AllReduceMethod, all_reduce, create_allreduce_ctx
-from ..ops.gemm import gemm_nt
+from ..ops.gemm import gemm_nt, gemm_nt_silu_mul
 from ..ops.gemm_rs import create_gemm_rs_intra_node_context, gemm_rs_intra_node
 from ..utils.distributed import get_env
 
@@ -108,9 +108,20 @@ class TP_MLP:
         self.ag_ctx = self.rs_ctx = self.ar_ctx = self.gemm_ar_ctx = None
 
     # ---- shared pieces ------------------------------------------------------------------------
+    def _is_silu(self) -> bool:
+        return self.act_fn in (torch.nn.functional.silu, None) or getattr(self.act_fn, "__name__", "") == "silu" \
+            or type(self.act_fn).__name__ in ("SiLU", "SiLUActivation")
+
+    def _gate_up_act(self, x: torch.Tensor) -> torch.Tensor:
+        """act(x @ gate^T) * (x @ up^T); decode-sized inputs take one launch (GEMM with the activation
+        in its epilogue)."""
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.shape[0] <= 16 and x2.is_cuda and self._is_silu():
+            return gemm_nt_silu_mul(x2, self.gate_up_proj).view(*x.shape[:-1], -1)
+        return self._act(_linear(x, self.gate_up_proj))
+
     def _act(self, gate_up: torch.Tensor) -> torch.Tensor:
-        if self.act_fn in (torch.nn.functional.silu, None) or getattr(self.act_fn, "__name__", "") == "silu" \
-                or type(self.act_fn).__name__ in ("SiLU", "SiLUActivation"):
+        if self._is_silu():
             return elementwise.silu_mul(gate_up)
         g, u = torch.chunk(gate_up, 2, dim=-1)
         return self.act_fn(g) * u
@@ -142,7 +153,7 @@ class TP_MLP:
     @torch.inference_mode()
     def dist_triton_AR_fwd(self, x):
         """x replicated [M, H]; GEMMs are local, the sum runs on the symmetric-memory all-reduce."""
-        out = self._act(_linear(x, self.gate_up_proj))
+        out = self._gate_up_act(x)
         out = _linear(out, self.down_proj)
         if self.world_size > 1:
             assert self.ar_ctx is not None, "AllReduce context is not initialized."

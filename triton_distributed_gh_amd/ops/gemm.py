@@ -75,3 +75,23 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
                           ctypes.c_longlong(b.stride(0)), ctypes.c_longlong(out.stride(0)), _DT[a.dtype], group_m,
                           _lib.stream_handle(), variant), "tdist_gemm_nt")
     return out
+
+
+def gemm_nt_silu_mul(a: torch.Tensor, gate_up: torch.Tensor) -> torch.Tensor:
+    """``silu(a @ gate^T) * (a @ up^T)`` for ``gate_up = [gate; up]`` of shape [2 I, K] -> [M, I].
+
+    M <= 16 in bf16 runs ONE launch (the decode GEMM with the activation in its epilogue); everything
+    else is ``gemm_nt`` followed by the activation kernel."""
+    M, K = a.shape
+    I = gate_up.shape[0] // 2
+    if (M <= 16 and a.dtype == torch.bfloat16 and gemm_supported(a, gate_up) and gate_up.shape[0] == 2 * I
+            and I % 2 == 0 and K % 32 == 0):
+        out = torch.empty((M, I), dtype=a.dtype, device=a.device)
+        _lib.check(
+            _lib.hip().tdist_gemm_nt_silu_mul(_lib.ptr(a), _lib.ptr(gate_up), _lib.ptr(out), M, I, K,
+                                              ctypes.c_longlong(a.stride(0)), ctypes.c_longlong(gate_up.stride(0)),
+                                              ctypes.c_longlong(out.stride(0)), _lib.stream_handle()),
+            "tdist_gemm_nt_silu_mul")
+        return out
+    from .elementwise import silu_mul
+    return silu_mul(gemm_nt(a, gate_up))
