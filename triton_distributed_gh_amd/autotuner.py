@@ -27,7 +27,7 @@ _ACTIVE: Dict[str, Any] = {}
 
 # knobs the ops consult; the lists are the default sweep spaces
 KNOWN_KNOBS: Dict[str, Sequence[Any]] = {
-    "gemm.variant": (2, 1),            # 2 = two phases per K-step, 1 = four phases
+    "gemm.variant": (3 | (3 << 16), 2, 1),   # persistent two-phase / two phases per K-step / four phases
     "gemm.group_m": (8, 4, 16),        # tile rows per L2 group
     "ag_gemm.M_PER_CHUNK": (256, 512, 1024),
     "ag_gemm.producer": ("kernel", "copy_engine"),

@@ -21,8 +21,11 @@ from .. import _lib
 from ..autotuner import tuning
 
 _DT = {torch.bfloat16: 0, torch.float16: 1}
-# main-loop schedule: 1 = four phases per K-step, 2 = two phases per K-step
-GEMM_VARIANT = int(os.environ.get("TDIST_GEMM_VARIANT", "2"))
+# tile kernel: 1 = four phases per K-step, 2 = two phases per K-step (one tile per workgroup, LDS-staged
+# epilogue), 3 = two phases, persistent workgroups, register-direct epilogue (bits 16-17: schedule knobs,
+# see mainloop_256_2ph), 4 = four 128x128 waves.  Default: 3 with both knobs - 0.5-0.8 % ahead of 2 in
+# every interleaved run at 4096x8192x8192 (profiles/gemm_persistent_r1.md).
+GEMM_VARIANT = int(os.environ.get("TDIST_GEMM_VARIANT", str(3 | (3 << 16))))
 # decode layers (M <= 16, K >= 4096) with at least this many MiB of weights go to the library (0 = never)
 DECODE_LIB_BYTES = int(os.environ.get("TDIST_DECODE_GEMM_LIB_MB", "0")) << 20
 
