@@ -270,7 +270,10 @@ __device__ __forceinline__ void decode_split_body(const DecodeArgs& a, const int
     float* dst = prow + (long long)(h0 + h) * a.p_stride_h;
     const float val = L > 0.f ? o / L : 0.f;
     const float lse = L > 0.f ? (M + __log2f(L)) * 0.6931471805599453f : -INFINITY;
-    if (a.fused) {
+    if (a.fused == 1 && a.splits == 1) {
+      // a single split is the final result: no partial row, no ticket, no second pass
+      ((uint16_t*)a.out)[b * a.o_stride_b + (long long)(h0 + h) * a.o_stride_h + c] = to16<IS_BF16>(val);
+    } else if (a.fused) {
       // read by another workgroup of this launch: write-through stores (they leave this XCD's L2
       // at once), so the hand-off needs no release fence, only a drain before the ticket
       __hip_atomic_store(dst + c, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void decode_split_kernel(DecodeArgs a) {
   const int valid_h = min(16, group - hblk * 16);
   decode_split_body<IS_BF16, D>(a, b, (int)blockIdx.y, (int)blockIdx.z, smem);
 
-  if (!a.fused) return;
+  if (!a.fused || (a.fused == 1 && a.splits == 1)) return;
   // ---- last workgroup of this (batch, head block) merges the splits.  The partial rows were
   // stored write-through: every wave drains its stores, the workgroup barriers, one lane takes a
   // ticket; the workgroup that draws the last ticket drops its stale L1 lines with ONE acquire

@@ -12,6 +12,7 @@ default split count is sized for 256 CUs rather than fixed at 32.
 from __future__ import annotations
 
 import ctypes
+import os
 import math
 from typing import Optional
 
@@ -114,6 +115,9 @@ def _combine(partial, strides, n, batch, heads, D, lens, out, out_mode, dtype_co
 def _splits(q, k_cache, block_table, kv_split):
     if kv_split is not None and kv_split > 0:
         return int(kv_split)
+    forced = int(os.environ.get("TDIST_DECODE_KV_SPLITS", "0"))        # tuning knob
+    if forced > 0:
+        return forced
     batch, q_heads, _ = q.shape
     return auto_kv_splits(batch, q_heads, k_cache.shape[2], block_table.shape[1] * k_cache.shape[1])
 
