@@ -59,8 +59,17 @@ struct AgGemmParams {
   // are ignored by the host and resolved on the device from the call number: the launch is then the
   // same every time and can be replayed from a HIP graph.
   int* state;
-  uint16_t* ws_par[2];
-  int* flags_par[2];
+  uint16_t *ws0, *ws1;        // (separate fields selected with ?: - indexing an array member with the runtime
+  int *flags0, *flags1;       //  parity would push the whole argument block into scratch memory)
+};
+
+// The per-call view of the double-buffered objects.  It is a separate small value on purpose: writing the
+// selected pointers back into the (large, dynamically indexed) argument block would force a private
+// copy of the whole block into scratch memory.
+struct AgCall {
+  uint16_t* ws;
+  int* flags;
+  int epoch;
 };
 
 constexpr int TICKET_SLOT = LDS_BYTES;  // 16 bytes after the tile staging area: [0] ticket, [1] split-K arrival, [2] call number
@@ -71,7 +80,7 @@ constexpr int TICKET_SLOT = LDS_BYTES;  // 16 bytes after the tile staging area:
 // xGMI links carry traffic at any moment.  The workgroup that completes a chunk raises that
 // chunk's flag on every peer.  Chunks go out in order so the consumers of every peer can start on
 // chunk 0 while chunk 1 is still on the wire.
-__device__ __forceinline__ void push_item(const AgGemmParams& p, int pw) {
+__device__ __forceinline__ void push_item(const AgGemmParams& p, const AgCall& cv, int pw) {
   constexpr int U = 8;
   const int w = p.world, rank = p.rank;
   const int cpr = p.M_per_rank / p.rows_per_chunk;
@@ -101,7 +110,7 @@ __device__ __forceinline__ void push_item(const AgGemmParams& p, int pw) {
       }
       for (int j = first_peer; j < w; ++j) {
         const int peer = j == 0 ? rank : (rank + 1 + (j - 1 + pw) % (w - 1)) % w;
-        char* dst = (char*)(peer == rank ? p.ws : symm_at(p.ctx, p.ws, peer)) + dst_off;
+        char* dst = (char*)(peer == rank ? cv.ws : symm_at(p.ctx, cv.ws, peer)) + dst_off;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int i = base + u * THREADS + (int)threadIdx.x;
@@ -118,8 +127,8 @@ __device__ __forceinline__ void push_item(const AgGemmParams& p, int pw) {
       if (prev == p.push_wgs - 1) {
         for (int j = first_peer; j < w; ++j) {
           const int peer = (rank + j) % w;
-          int* f = (peer == rank ? p.flags : symm_at(p.ctx, p.flags, peer)) + rank * cpr + chunk;
-          store_relaxed_system(f, p.epoch);
+          int* f = (peer == rank ? cv.flags : symm_at(p.ctx, cv.flags, peer)) + rank * cpr + chunk;
+          store_relaxed_system(f, cv.epoch);
         }
       }
     }
@@ -146,18 +155,19 @@ __global__ __launch_bounds__(THREADS, 2) void ag_gemm_consumer_kernel(AgGemmPara
   const int total = p.push_wgs + total_mb * num_pid_n * S;
   const int ksteps = p.K / BK;
   int call = 0;
+  AgCall cv{p.ws, p.flags, p.epoch};
   if (p.state) {
     call = call_begin(p.state, s_ticket + 2);
-    p.ws = p.ws_par[call_parity(call)];
-    p.flags = p.flags_par[call_parity(call)];
-    p.epoch = call_epoch(call);
+    cv.ws = call_parity(call) ? p.ws1 : p.ws0;
+    cv.flags = call_parity(call) ? p.flags1 : p.flags0;
+    cv.epoch = call_epoch(call);
   }
 
   while (true) {
     int item = fetch_ticket_block(p.ticket, s_ticket);
     if (item >= total) break;
     if (item < p.push_wgs) {
-      push_item(p, item);
+      push_item(p, cv, item);
       continue;
     }
     item -= p.push_wgs;
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(THREADS, 2) void ag_gemm_consumer_kernel(AgGemmPara
       const int mb = (first + o) % total_mb;
       g0 = mb * BM;
       rows = min(BM, M - g0);
-      a_ptr = p.ws + (long long)g0 * p.ld_ws;
+      a_ptr = cv.ws + (long long)g0 * p.ld_ws;
       lda = p.ld_ws;
       need_wait = true;
     } else {
@@ -198,7 +208,7 @@ __global__ __launch_bounds__(THREADS, 2) void ag_gemm_consumer_kernel(AgGemmPara
         lda = p.lda_local;
         need_wait = false;
       } else {
-        a_ptr = p.ws + (long long)g0 * p.ld_ws;
+        a_ptr = cv.ws + (long long)g0 * p.ld_ws;
         lda = p.ld_ws;
         need_wait = true;
       }
@@ -207,7 +217,7 @@ __global__ __launch_bounds__(THREADS, 2) void ag_gemm_consumer_kernel(AgGemmPara
       const int g1 = g0 + rows - 1;
       const int f0 = (g0 / p.M_per_rank) * cpr + (g0 % p.M_per_rank) / p.rows_per_chunk;
       const int f1 = (g1 / p.M_per_rank) * cpr + (g1 % p.M_per_rank) / p.rows_per_chunk;
-      const int token = wait((const int*)p.flags + f0, f1 - f0 + 1, SCOPE_SYS, SEM_ACQUIRE, p.epoch, p.err);
+      const int token = wait((const int*)cv.flags + f0, f1 - f0 + 1, SCOPE_SYS, SEM_ACQUIRE, cv.epoch, p.err);
       a_ptr = consume_token(a_ptr, token);
     }
 
@@ -405,10 +415,10 @@ TDIST_API int tdist_ag_gemm_consumer(const tdist::SymmCtx* ctx, const void* a_lo
   p.push_wgs = world > 1 ? push_wgs : 0;
   p.split_k = split_k;
   p.state = state;
-  p.ws_par[0] = (uint16_t*)ws;
-  p.ws_par[1] = (uint16_t*)ws1;
-  p.flags_par[0] = flags;
-  p.flags_par[1] = flags1;
+  p.ws0 = (uint16_t*)ws;
+  p.ws1 = (uint16_t*)ws1;
+  p.flags0 = flags;
+  p.flags1 = flags1;
   const int total = p.push_wgs + tiles * split_k;
   int grid = num_ctas > 0 ? num_ctas : 256;
   if (grid > total) grid = total;

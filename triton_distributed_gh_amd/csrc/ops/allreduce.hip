@@ -35,8 +35,8 @@ struct ArParams {
   void* out;
   void* ws;        // symmetric, this call's parity (resolved on the device, see resolve_call)
   int* flags;      // symmetric (signal arena), this call's parity: [2][w][G]
-  void* ws_par[2];     // both parities, as given by the host
-  int* flags_par[2];
+  void *ws0, *ws1;     // both parities, as given by the host (separate fields selected with ?: - indexing an
+  int *flags0, *flags1;   // array member with the runtime parity would push the argument block into scratch)
   int* state;      // [0] call number in [0, 2 * EPOCH_MOD), [1] finished-workgroup count
   int* err;
   long long n;     // elements
@@ -114,15 +114,21 @@ struct Elem<_Float16> {
   static __device__ __forceinline__ _Float16 from_f(float x) { return (_Float16)x; }
 };
 
-// Entry of every workgroup: read the call number (tdist/call_state.hpp), select the parity buffers
-// and the flag value.
-__device__ __forceinline__ int resolve_call(ArParams& p) {
+// Per-call view of the double-buffered objects, resolved on entry of every workgroup from the call
+// number (tdist/call_state.hpp).  It is a separate small value on purpose: writing the selected
+// pointers back into the large, dynamically indexed argument block would force a private copy of the
+// whole block into scratch memory.
+struct ArCall {
+  void* ws;
+  int* flags;
+  int epoch;
+  int call;
+};
+
+__device__ __forceinline__ ArCall resolve_call(const ArParams& p) {
   __shared__ int s_call;
   const int call = call_begin(p.state, &s_call);
-  p.ws = p.ws_par[call_parity(call)];
-  p.flags = p.flags_par[call_parity(call)];
-  p.epoch = call_epoch(call);
-  return call;
+  return ArCall{call_parity(call) ? p.ws1 : p.ws0, call_parity(call) ? p.flags1 : p.flags0, call_epoch(call), call};
 }
 
 __device__ __forceinline__ void finish_call(const ArParams& p, int call) { call_end(p.state, call); }
@@ -130,17 +136,17 @@ __device__ __forceinline__ void finish_call(const ArParams& p, int call) { call_
 // Raise flag[phase][rank][c] on every peer, then wait for flag[phase][s][c] of every peer s.
 // The payload went out with write-through stores, so publishing is drain + barrier; only a push
 // that had to fall back to plain stores (`need_release`, workgroup-uniform) pays a release fence.
-__device__ __forceinline__ void exchange_flags(const ArParams& p, int phase, int c, bool need_release) {
+__device__ __forceinline__ void exchange_flags(const ArParams& p, const ArCall& cv, int phase, int c, bool need_release) {
   const int w = p.ctx.num_ranks, rank = p.ctx.rank;
   if (need_release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   drain_stores();
   __syncthreads();
   const int t = threadIdx.x;
   if (t < w && t != rank) {
-    int* remote = symm_at(p.ctx, p.flags, t) + (phase * w + rank) * p.G + c;
-    store_relaxed_system(remote, p.epoch);
+    int* remote = symm_at(p.ctx, cv.flags, t) + (phase * w + rank) * p.G + c;
+    store_relaxed_system(remote, cv.epoch);
     const bool dead = load_relaxed_agent(p.err) != 0;
-    if (dead || !spin_until_eq(p.flags + (phase * w + t) * p.G + c, p.epoch, SCOPE_SYS)) {
+    if (dead || !spin_until_eq(cv.flags + (phase * w + t) * p.G + c, cv.epoch, SCOPE_SYS)) {
       if (!dead) atomicOr(p.err, 1);
     }
   }
@@ -180,19 +186,20 @@ __device__ __forceinline__ void sum_slices(const ArParams& p, const T* own, cons
 template <typename T>
 __global__ __launch_bounds__(512) void allreduce_one_shot_kernel(ArParams p) {
   constexpr int VEC = Elem<T>::VEC;
-  const int call = resolve_call(p);
+  const ArCall cv = resolve_call(p);
+  const int call = cv.call;
   const int w = p.ctx.num_ranks, rank = p.ctx.rank, c = blockIdx.x;
   const long long per = ((p.n + p.G - 1) / p.G + VEC - 1) / VEC * VEC;
   const long long e0 = min((long long)c * per, p.n), e1 = min(e0 + per, p.n);
   const T* in = (const T*)p.in;
-  T* ws = (T*)p.ws;
+  T* ws = (T*)cv.ws;
   bool plain = false;
   for (int i = 1; i < w; ++i) {
     const int peer = (rank + i) % w;
     T* dst = symm_at(p.ctx, ws, peer) + (long long)rank * p.cap + e0;
     plain |= shmem::copy_bytes_wt_sys(dst, in + e0, (size_t)(e1 - e0) * sizeof(T), threadIdx.x, blockDim.x);
   }
-  exchange_flags(p, 0, c, plain);
+  exchange_flags(p, cv, 0, c, plain);
   sum_slices<T>(p, in, ws, p.cap, (T*)p.out, e0, e1);
   finish_call(p, call);
 }
@@ -200,13 +207,14 @@ __global__ __launch_bounds__(512) void allreduce_one_shot_kernel(ArParams p) {
 template <typename T>
 __global__ __launch_bounds__(512) void allreduce_two_shot_kernel(ArParams p) {
   constexpr int VEC = Elem<T>::VEC;
-  const int call = resolve_call(p);
+  const ArCall cv = resolve_call(p);
+  const int call = cv.call;
   const int w = p.ctx.num_ranks, rank = p.ctx.rank, c = blockIdx.x;
   const long long ce = p.cap;                                   // chunk stride (elements, multiple of VEC)
   const long long sub = ((ce + p.G - 1) / p.G + VEC - 1) / VEC * VEC;
   const long long s0 = min((long long)c * sub, ce), s1 = min(s0 + sub, ce);
   const T* in = (const T*)p.in;
-  T* recv = (T*)p.ws;                         // [w][ce]
+  T* recv = (T*)cv.ws;                         // [w][ce]
   T* gather = recv + (long long)w * ce;       // [w][ce]
   // phase 1: reduce-scatter pushes
   bool plain = false;
@@ -218,7 +226,7 @@ __global__ __launch_bounds__(512) void allreduce_two_shot_kernel(ArParams p) {
       plain |= shmem::copy_bytes_wt_sys(dst, in + g0, (size_t)(g1 - g0) * sizeof(T), threadIdx.x, blockDim.x);
     }
   }
-  exchange_flags(p, 0, c, plain);
+  exchange_flags(p, cv, 0, c, plain);
   plain = false;
   // reduce own chunk's sub-slice into the local gather buffer, then broadcast it
   {
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(512) void allreduce_two_shot_kernel(ArParams p) {
       }
     }
   }
-  exchange_flags(p, 1, c, plain);
+  exchange_flags(p, cv, 1, c, plain);
   // phase 2: every chunk's sub-slice is now in the local gather buffer
   for (int s = 0; s < w; ++s) {
     const long long g0 = min(s * ce + s0, p.n), g1 = min(s * ce + s1, p.n);
@@ -262,10 +270,10 @@ TDIST_API int tdist_allreduce(const tdist::SymmCtx* ctx, const void* in, void* o
   p.out = out;
   p.ws = nullptr;
   p.flags = nullptr;
-  p.ws_par[0] = ws0;
-  p.ws_par[1] = ws1;
-  p.flags_par[0] = flags0;
-  p.flags_par[1] = flags1;
+  p.ws0 = ws0;
+  p.ws1 = ws1;
+  p.flags0 = flags0;
+  p.flags1 = flags1;
   p.state = state;
   p.err = err;
   p.n = n;

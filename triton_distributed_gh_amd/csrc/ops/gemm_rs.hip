@@ -44,8 +44,16 @@ struct GemmRsParams {
   // Device-side call numbering (tdist/call_state.hpp): when `state` is set, scatter / flags / epoch are
   // resolved on the device from the call number and the launch can be replayed from a HIP graph.
   int* state;
-  uint16_t* scatter_par[2];
-  int* flags_par[2];
+  uint16_t *scatter0, *scatter1;   // (separate fields, selected with ?: - indexing an array member with the
+  int *flags0, *flags1;            //  runtime parity would push the whole argument block into scratch memory)
+};
+
+// Per-call view of the double-buffered objects (kept out of the argument block: writing into that large,
+// dynamically indexed block would force a private copy of all of it into scratch memory).
+struct RsCall {
+  uint16_t* scatter;
+  int* flags;
+  int epoch;
 };
 
 constexpr int RS_TICKET_SLOT = LDS_BYTES;
@@ -53,14 +61,14 @@ constexpr int RED_ROWS = 4;
 constexpr int RED_COLS = THREADS * 8;  // 4096 columns per item
 
 template <bool IS_BF16>
-__device__ __forceinline__ void reduce_item(const GemmRsParams& p, int c, int i, int cpr, int ncb) {
+__device__ __forceinline__ void reduce_item(const GemmRsParams& p, const RsCall& cv, int c, int i, int cpr, int ncb) {
   const int w = p.ctx.num_ranks;
   // wait for every source's partial of chunk c
   {
     int failed = 0;
     const bool dead = load_relaxed_agent(p.err) != 0;
     if ((int)threadIdx.x < w) {
-      if (dead || !spin_until_eq(p.flags + threadIdx.x * cpr + c, p.epoch, SCOPE_SYS)) failed = 1;
+      if (dead || !spin_until_eq(cv.flags + threadIdx.x * cpr + c, cv.epoch, SCOPE_SYS)) failed = 1;
     }
     if (failed && !dead) atomicOr(p.err, 1);
     if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
@@ -74,7 +82,7 @@ __device__ __forceinline__ void reduce_item(const GemmRsParams& p, int c, int i,
   if (col < p.N) {
     const long long seg_stride = (long long)p.M_per_rank * p.N;
     for (int row = row0; row < row_end; ++row) {
-      const uint16_t* src = p.scatter + (long long)row * p.N + col;
+      const uint16_t* src = cv.scatter + (long long)row * p.N + col;
       float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       for (int s0 = 0; s0 < w; s0 += 4) {
         uint4 v[4];
@@ -125,11 +133,12 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_rs_kernel(GemmRsParams p) {
   const int total = cpr * S;
   int* ticket = p.counters + w * cpr;
   int call = 0;
+  RsCall cv{p.scatter, p.flags, p.epoch};
   if (p.state) {
     call = call_begin(p.state, s_ticket + 2);
-    p.scatter = p.scatter_par[call_parity(call)];
-    p.flags = p.flags_par[call_parity(call)];
-    p.epoch = call_epoch(call);
+    cv.scatter = call_parity(call) ? p.scatter1 : p.scatter0;
+    cv.flags = call_parity(call) ? p.flags1 : p.flags0;
+    cv.epoch = call_epoch(call);
   }
 
   while (true) {
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_rs_kernel(GemmRsParams p) {
     }
 
     if (!is_gemm) {
-      reduce_item<IS_BF16>(p, c, i, cpr, ncb);
+      reduce_item<IS_BF16>(p, cv, c, i, cpr, ncb);
       if (p.dbg && threadIdx.x == 0) { p.dbg[blockIdx.x * 4 + 1] = 5; p.dbg[blockIdx.x * 4 + 2] += 1; }
       continue;
     }
@@ -189,7 +198,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_rs_kernel(GemmRsParams p) {
     mainloop_256_2ph<IS_BF16>(t, smem, acc);
     if (p.dbg && threadIdx.x == 0) p.dbg[blockIdx.x * 4 + 1] = 2;
 
-    uint16_t* dst_buf = (d == rank) ? p.scatter : symm_at(p.ctx, p.scatter, d);
+    uint16_t* dst_buf = (d == rank) ? cv.scatter : symm_at(p.ctx, cv.scatter, d);
     uint16_t* cbase = dst_buf + ((long long)rank * p.M_per_rank + r_in) * p.N + pid_n * BN;
     const int nrem = p.N - pid_n * BN;
     const long long ldn = p.N;
@@ -207,8 +216,8 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_rs_kernel(GemmRsParams p) {
       // ordered after all earlier adds on the same word, so the flag follows all of the chunk's data.
       const int prev = atom_add_relaxed_agent(p.counters + d * cpr + c, 1);
       if (prev == tiles_per_dc - 1) {
-        int* flag = ((d == rank) ? p.flags : symm_at(p.ctx, p.flags, d)) + rank * cpr + c;
-        store_relaxed_system(flag, p.epoch);
+        int* flag = ((d == rank) ? cv.flags : symm_at(p.ctx, cv.flags, d)) + rank * cpr + c;
+        store_relaxed_system(flag, cv.epoch);
       }
     }
   }
@@ -248,10 +257,10 @@ TDIST_API int tdist_gemm_rs(const tdist::SymmCtx* ctx, const void* A, const void
   TDIST_REQUIRE(!state || (scatter1 && flags1 && (((uintptr_t)scatter1) & 15) == 0),
                 "device-side call numbering needs both parities");
   p.state = state;
-  p.scatter_par[0] = (uint16_t*)scatter;
-  p.scatter_par[1] = (uint16_t*)scatter1;
-  p.flags_par[0] = flags;
-  p.flags_par[1] = flags1;
+  p.scatter0 = (uint16_t*)scatter;
+  p.scatter1 = (uint16_t*)scatter1;
+  p.flags0 = flags;
+  p.flags1 = flags1;
   const int cpr = M_per_rank / rows_per_chunk;
   const size_t counter_bytes = (((size_t)(w * cpr + 4) * sizeof(int)) + 15) & ~(size_t)15;
   static bool attr_set = false;
