@@ -65,7 +65,7 @@ __device__ __forceinline__ int kv_source_rank(const AttnArgs& a, int n, int Lk) 
 }
 
 template <bool IS_BF16, int D>
-__global__ __launch_bounds__(256) void flash_attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
   using F = Frag<IS_BF16>;
   using VT = typename F::T;
   constexpr int KS = D / 32;
@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(AttnArgs a) {
   const int b = blockIdx.z, h = blockIdx.y;
   const int q0 = a.cu_q[b], Lq = a.cu_q[b + 1] - q0;
   const int k0 = a.cu_k[b], Lk = a.cu_k[b + 1] - k0;
-  const int m0 = blockIdx.x * 128;
+  // causal: the last query blocks see the longest KV range - hand them out first so the short ones fill the tail
+  const int m0 = (a.causal ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * 128;
   if (m0 >= Lq) return;
   const int kvh = h / (a.q_heads / a.kv_heads);
 
@@ -228,6 +229,16 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(AttnArgs a) {
         l_run[rb] = l_run[rb] * alpha[rb] + psum;
         pfrag[rb] = __builtin_bit_cast(VT, uint4{pw[0], pw[1], pw[2], pw[3]});
       }
+      // once the running maxima have settled every alpha is exactly 1: skip the 16 * NDV multiplies
+      // of the accumulator rescale for the whole wave then (wave-uniform branch)
+      if (__builtin_amdgcn_ballot_w64(alpha[0] != 1.f || alpha[1] != 1.f) != 0) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int j = 0; j < NDV; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[rb][j][i] *= alpha[rb];
+      }
 #pragma unroll
       for (int j = 0; j < NDV; ++j) {
         const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
@@ -236,12 +247,7 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(AttnArgs a) {
         for (int p = 0; p < 4; ++p) vw[p] = __builtin_amdgcn_perm(vreg[2 * p + 1][j >> 1], vreg[2 * p][j >> 1], sel);
         const VT vfrag = __builtin_bit_cast(VT, uint4{vw[0], vw[1], vw[2], vw[3]});
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-          f32x4 c = acc[rb][j];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) c[i] *= alpha[rb];
-          acc[rb][j] = F::mfma(vfrag, pfrag[rb], c);
-        }
+        for (int rb = 0; rb < 2; ++rb) acc[rb][j] = F::mfma(vfrag, pfrag[rb], acc[rb][j]);
       }
     }
     if (blk + 1 < nblk) {
