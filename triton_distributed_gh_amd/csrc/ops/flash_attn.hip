@@ -79,11 +79,22 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
 
   extern __shared__ char smem[];             // [2 stages][K tile, V tile]
 
-  const int b = blockIdx.z, h = blockIdx.y;
+  // Workgroups go round-robin over the 8 XCDs in launch order (x fastest).  With the plain mapping an
+  // XCD would always get the same query blocks of every head (causal: 52 to 80 KV-block units of
+  // work against a mean of 66) and all KV heads.  Remapped: XCD k serves the contiguous head group
+  // k (its KV heads stay in that XCD's L2) and every group hands out its query blocks in the same order.
+  int qb = blockIdx.x, h = blockIdx.y;
+  if ((a.q_heads & 7) == 0) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y, hp = a.q_heads >> 3;
+    const int j = lin >> 3;
+    h = (lin & 7) * hp + j % hp;
+    qb = j / hp;
+  }
+  const int b = blockIdx.z;
   const int q0 = a.cu_q[b], Lq = a.cu_q[b + 1] - q0;
   const int k0 = a.cu_k[b], Lk = a.cu_k[b + 1] - k0;
   // causal: the last query blocks see the longest KV range - hand them out first so the short ones fill the tail
-  const int m0 = (a.causal ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * 128;
+  const int m0 = (a.causal ? (int)gridDim.x - 1 - qb : qb) * 128;
   if (m0 >= Lq) return;
   const int kvh = h / (a.q_heads / a.kv_heads);
 
