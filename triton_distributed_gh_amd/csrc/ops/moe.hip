@@ -150,11 +150,25 @@ __global__ __launch_bounds__(THREADS, 2) void moe_group_gemm_kernel(GroupGemmPar
   float* s_scale = (float*)(s_orow + BM);
   const int num_pid_n = (p.N + BN - 1) / BN;
   const int nblocks = p.meta[0];
-  const int total = nblocks * num_pid_n;
+  // Eight ticket queues, one per XCD (workgroups are dealt to the XCDs round-robin by index): queue q
+  // holds the row blocks bi with bi % 8 == q, all column tiles of a block on consecutive tickets.  The
+  // workgroups of one XCD therefore share a handful of A row blocks and one or two experts' B panels
+  // in their L2 instead of a random 1/8 of everything; a workgroup whose queue has run dry moves on
+  // to the next XCD's queue, so the tail is still balanced dynamically.
+  const int xcd = blockIdx.x & 7;
+  int hop = 0;
   while (true) {
-    const int item = fetch_ticket_block(p.ticket, s_ticket);
-    if (item >= total) break;
-    const int bi = item / num_pid_n, pid_n = item - bi * num_pid_n;
+    int q = 0, local = 0;
+    for (; hop < 8; ++hop) {
+      q = (xcd + hop) & 7;
+      const int qsize = q < nblocks ? ((nblocks - q + 7) >> 3) * num_pid_n : 0;
+      if (qsize == 0) continue;
+      local = fetch_ticket_block(p.ticket + q, s_ticket);
+      if (local < qsize) break;
+    }
+    if (hop == 8) break;
+    const int bl = local / num_pid_n, pid_n = local - bl * num_pid_n;
+    const int bi = bl * 8 + q;
     const int b = p.order ? p.order[bi] : bi;
     const int e = p.expert_of_block[b];
     if (threadIdx.x < BM) {
@@ -376,7 +390,7 @@ TDIST_API int tdist_moe_group_gemm(const void* A, const void* B, void* out, cons
     TDIST_HIP_TRY(hipFuncSetAttribute((const void*)moe_group_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  TDIST_HIP_TRY(hipMemsetAsync(ticket, 0, 16, (hipStream_t)stream));
+  TDIST_HIP_TRY(hipMemsetAsync(ticket, 0, 32, (hipStream_t)stream));   // eight queue counters
   const int grid = num_ctas > 0 ? num_ctas : 256;
   if (dtype == 0)
     hipLaunchKernelGGL(moe_group_gemm_kernel<true>, dim3(grid), dim3(THREADS), lds, (hipStream_t)stream, p);

@@ -165,6 +165,7 @@ class MoEAllGatherGroupGEMMTensorParallelContext:
     num_ranks: int
     env: Any = None
     num_ctas: int = 0
+    tickets: Optional[torch.Tensor] = None      # int32 [8]: per-XCD work queues of the grouped GEMM
 
     def check_error(self):
         self.ag.check_error()
@@ -177,7 +178,9 @@ def create_ag_group_gemm_context(max_ntokens, N_per_rank, K, num_experts, topk, 
     num_ctas = default_num_ctas(env, num_ranks, num_ctas)
     ag = create_ag_gemm_intra_node_context(max_ntokens, N_per_rank, K, dtype, dtype, rank, num_ranks,
                                            producer="kernel", num_ctas=num_ctas, ag_streams=ag_streams, env=env)
-    return MoEAllGatherGroupGEMMTensorParallelContext(ag, num_experts, topk, N_per_rank, K, rank, num_ranks, env, num_ctas)
+    tickets = torch.zeros(8, dtype=torch.int32, device=env.device) if env.backend == "hip" else None
+    return MoEAllGatherGroupGEMMTensorParallelContext(ag, num_experts, topk, N_per_rank, K, rank, num_ranks, env, num_ctas,
+                                                      tickets)
 
 
 def ag_group_gemm(a: torch.Tensor, b: torch.Tensor, ctx: MoEAllGatherGroupGEMMTensorParallelContext,
@@ -216,7 +219,7 @@ def ag_group_gemm(a: torch.Tensor, b: torch.Tensor, ctx: MoEAllGatherGroupGEMMTe
         _lib.hip().tdist_moe_group_gemm(_lib.ptr(A), _lib.ptr(b), _lib.ptr(out), _lib.ptr(idx.sorted_ids),
                                         _lib.ptr(idx.expert_of_block), _lib.ptr(idx.seg_range) if w > 1 else None,
                                         _lib.ptr(idx.order) if w > 1 else None, _lib.ptr(idx.meta), None,
-                                        _lib.ptr(flags), _lib.ptr(ag.scratch[4:]), _lib.ptr(ag.scratch),
+                                        _lib.ptr(flags), _lib.ptr(ctx.tickets), _lib.ptr(ag.scratch),
                                         ctypes.c_longlong(A.stride(0)), ctypes.c_longlong(b.stride(1)),
                                         ctypes.c_longlong(out.stride(0)), ctypes.c_longlong(b.stride(0)), N, K, topk, 0,
                                         M_per_rank // rpc, epoch, ctx.num_ctas, _DT[a.dtype], _lib.stream_handle(cur)),
