@@ -64,8 +64,12 @@ __device__ __forceinline__ int kv_source_rank(const AttnArgs& a, int n, int Lk) 
   return min(n / per, a.world - 1);
 }
 
-template <bool IS_BF16, int D>
+// RB = 16-row query blocks per wave: a workgroup covers 64 * RB query rows.  RB = 1 halves the work of
+// the heaviest causal workgroup and doubles the number of workgroups - chosen by the launcher when
+// the grid of 128-row blocks would leave wave slots empty (few heads per rank, short sequences).
+template <bool IS_BF16, int D, int RB>
 __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
+  constexpr int QROWS = 64 * RB;
   using F = Frag<IS_BF16>;
   using VT = typename F::T;
   constexpr int KS = D / 32;
@@ -94,19 +98,19 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
   const int q0 = a.cu_q[b], Lq = a.cu_q[b + 1] - q0;
   const int k0 = a.cu_k[b], Lk = a.cu_k[b + 1] - k0;
   // causal: the last query blocks see the longest KV range - hand them out first so the short ones fill the tail
-  const int m0 = (a.causal ? (int)gridDim.x - 1 - qb : qb) * 128;
+  const int m0 = (a.causal ? (int)gridDim.x - 1 - qb : qb) * QROWS;
   if (m0 >= Lq) return;
   const int kvh = h / (a.q_heads / a.kv_heads);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  const int row_base = m0 + wave * 32;
+  const int row_base = m0 + wave * 16 * RB;
 
   // ---- Q operand (column block rb, head-dim step s): lane (row li, k-group lg)
-  VT qreg[2][KS];
-  int qpos[2];
+  VT qreg[RB][KS];
+  int qpos[RB];
 #pragma unroll
-  for (int rb = 0; rb < 2; ++rb) {
+  for (int rb = 0; rb < RB; ++rb) {
     const int r = row_base + 16 * rb + li;
     qpos[rb] = r < Lq ? q_position(a, r, Lq, Lk) : -1;
     const uint16_t* qp = a.q + (long long)(q0 + min(r, Lq - 1)) * a.q_stride_t + (long long)h * a.q_stride_h + lg * 8;
@@ -117,16 +121,18 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
       qreg[rb][s] = __builtin_bit_cast(VT, v);
     }
   }
-  const int last_row = min(m0 + 127, Lq - 1);
+  const int last_row = min(m0 + QROWS - 1, Lq - 1);
   const int kv_hi = a.causal ? min(Lk, q_position(a, last_row, Lq, Lk) + 1) : Lk;
-  const int wave_last = min(row_base + 31, Lq - 1);
+  const int wave_last = min(row_base + 16 * RB - 1, Lq - 1);
   const int wave_hi = row_base >= Lq ? 0 : (a.causal ? min(Lk, q_position(a, wave_last, Lq, Lk) + 1) : Lk);
   const int nblk = (kv_hi + 31) / 32;
 
-  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
-  f32x4 acc[2][NDV];
+  float m_run[RB], l_run[RB];
+  f32x4 acc[RB][NDV];
 #pragma unroll
-  for (int rb = 0; rb < 2; ++rb)
+  for (int rb = 0; rb < RB; ++rb) m_run[rb] = -INFINITY, l_run[rb] = 0.f;
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
     for (int j = 0; j < NDV; ++j) acc[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -202,10 +208,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
           vreg[t][0] = v.x, vreg[t][1] = v.y;
         }
       }
-      VT pfrag[2];
-      float alpha[2];
+      VT pfrag[RB];
+      float alpha[RB];
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
+      for (int rb = 0; rb < RB; ++rb) {
         f32x4 st[2];
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb) {
@@ -242,9 +248,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
       }
       // once the running maxima have settled every alpha is exactly 1: skip the 16 * NDV multiplies
       // of the accumulator rescale for the whole wave then (wave-uniform branch)
-      if (__builtin_amdgcn_ballot_w64(alpha[0] != 1.f || alpha[1] != 1.f) != 0) {
+      if (__builtin_amdgcn_ballot_w64(alpha[0] != 1.f || alpha[RB - 1] != 1.f) != 0) {
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
           for (int j = 0; j < NDV; ++j)
 #pragma unroll
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
         for (int p = 0; p < 4; ++p) vw[p] = __builtin_amdgcn_perm(vreg[2 * p + 1][j >> 1], vreg[2 * p][j >> 1], sel);
         const VT vfrag = __builtin_bit_cast(VT, uint4{vw[0], vw[1], vw[2], vw[3]});
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) acc[rb][j] = F::mfma(vfrag, pfrag[rb], acc[rb][j]);
+        for (int rb = 0; rb < RB; ++rb) acc[rb][j] = F::mfma(vfrag, pfrag[rb], acc[rb][j]);
       }
     }
     if (blk + 1 < nblk) {
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
   __syncthreads();
   char* stg = smem + wave * TILE_B;
 #pragma unroll
-  for (int rb = 0; rb < 2; ++rb) {
+  for (int rb = 0; rb < RB; ++rb) {
     float l = l_run[rb];
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  for (int idx = lane; idx < 32 * CPR; idx += 64) {
+  for (int idx = lane; idx < 16 * RB * CPR; idx += 64) {
     const int row = idx / CPR, ch = idx - row * CPR;
     const int r = row_base + row;
     if (r < Lq)
@@ -358,19 +364,34 @@ __global__ __launch_bounds__(256) void sp_kv_push_kernel(KvPushArgs p) {
   }
 }
 
-template <bool IS_BF16, int D>
-hipError_t launch_attn(const AttnArgs& a, int max_seqlen_q, int batch, hipStream_t st) {
+template <bool IS_BF16, int D, int RB>
+hipError_t launch_attn_rb(const AttnArgs& a, int max_seqlen_q, int batch, hipStream_t st) {
   constexpr int lds = 2 * 2 * 32 * (D * 2 + 16);
   static bool attr_done = false;
   if (!attr_done) {
-    const hipError_t e = hipFuncSetAttribute((const void*)flash_attn_fwd_kernel<IS_BF16, D>,
+    const hipError_t e = hipFuncSetAttribute((const void*)flash_attn_fwd_kernel<IS_BF16, D, RB>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((flash_attn_fwd_kernel<IS_BF16, D>), dim3((max_seqlen_q + 127) / 128, a.q_heads, batch), dim3(256),
-                     lds, st, a);
+  hipLaunchKernelGGL((flash_attn_fwd_kernel<IS_BF16, D, RB>), dim3((max_seqlen_q + 64 * RB - 1) / (64 * RB), a.q_heads, batch),
+                     dim3(256), lds, st, a);
   return hipGetLastError();
+}
+
+// 64-row workgroups only while 128-row ones would not even give every CU one workgroup: the cost of a
+// KV block hardly depends on the number of query rows, so above that the larger tile wins
+// (TDIST_ATTN_QROWS = 64 / 128 forces one form).
+template <bool IS_BF16, int D>
+hipError_t launch_attn(const AttnArgs& a, int max_seqlen_q, int batch, hipStream_t st) {
+  static const int forced = [] {
+    const char* e = getenv("TDIST_ATTN_QROWS");
+    return e ? atoi(e) : 0;
+  }();
+  const long long wgs128 = (long long)((max_seqlen_q + 127) / 128) * a.q_heads * batch;
+  const bool small = forced == 64 || (forced != 128 && wgs128 <= 256);
+  return small ? launch_attn_rb<IS_BF16, D, 1>(a, max_seqlen_q, batch, st)
+               : launch_attn_rb<IS_BF16, D, 2>(a, max_seqlen_q, batch, st);
 }
 
 }  // namespace
