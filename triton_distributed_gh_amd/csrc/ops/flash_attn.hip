@@ -64,6 +64,13 @@ __device__ __forceinline__ int kv_source_rank(const AttnArgs& a, int n, int Lk) 
   return min(n / per, a.world - 1);
 }
 
+// K/V ring depth and LDS footprint (the ring is reused for the 4 x 32 padded output rows at the end)
+constexpr int attn_stages(int d) { return d <= 128 ? 4 : 2; }
+constexpr int attn_lds_bytes(int d) {
+  const int ring = attn_stages(d) * 2 * 32 * d * 2, out = 4 * 32 * (d * 2 + 16);
+  return ring > out ? ring : out;
+}
+
 // RB = 16-row query blocks per wave: a workgroup covers 64 * RB query rows.  RB = 1 halves the work of
 // the heaviest causal workgroup and doubles the number of workgroups - chosen by the launcher when
 // the grid of 128-row blocks would leave wave slots empty (few heads per rank, short sequences).
@@ -75,13 +82,17 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
   constexpr int KS = D / 32;
   constexpr int NDV = D / 16;
   constexpr int VW = NDV / 2;
-  constexpr int ROW_B = D * 2 + 16;          // padded LDS row (bytes): 16 rows hit 16 distinct bank quads
-  constexpr int TILE_B = 32 * ROW_B;
+  constexpr int ROWB = D * 2;                // LDS row of a K/V tile (bytes), unpadded: chunks are XOR-swizzled instead
+  constexpr int TILE_B = 32 * ROWB;
   constexpr int CPR = D / 8;                 // 16-byte chunks per row
-  constexpr int LD_PER_T = (32 * CPR) / 256; // 16-byte loads per thread per tile
+  constexpr int IPW = CPR / 8;               // direct-to-LDS loads (64 lanes x 16 bytes) per wave and tile
+  constexpr int LPS = 2 * IPW;               // ... per wave and stage (K and V)
+  constexpr int NST = attn_stages(D);        // stages of the K/V ring; NST - 1 blocks are in flight
+  constexpr int ROW_B = D * 2 + 16;          // padded row of the epilogue's output staging
+  constexpr int OUT_TILE_B = 32 * ROW_B;
   constexpr float LOG2E = 1.4426950408889634f;
 
-  extern __shared__ char smem[];             // [2 stages][K tile, V tile]
+  extern __shared__ char smem[];             // [NST stages][K tile, V tile]; reused for the output staging
 
   // Workgroups go round-robin over the 8 XCDs in launch order (x fastest).  With the plain mapping an
   // XCD would always get the same query blocks of every head (causal: 52 to 80 KV-block units of
@@ -102,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
   if (m0 >= Lq) return;
   const int kvh = h / (a.q_heads / a.kv_heads);
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, lg = lane >> 4;
   const int row_base = m0 + wave * 16 * RB;
 
@@ -141,7 +152,19 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
   const uint16_t* vg = a.v + (long long)k0 * a.v_stride_t + (long long)kvh * a.v_stride_h;
   unsigned seen = 0;   // bit r: rank r's KV slab is known to have landed
 
-  uint4 kst[LD_PER_T], vst[LD_PER_T];
+  // K/V tiles go from global memory straight into LDS (no registers, no second hop), NST - 1 blocks
+  // ahead.  A load instruction fills 1024 consecutive LDS bytes, lane i the 16 bytes at 16 * i, so the
+  // bank-conflict padding of a register-staged tile is not available; instead the lane picks WHICH
+  // source chunk it fetches: tile row r keeps chunk c at chunk position c ^ swz(r), and the 16 rows a
+  // fragment read touches land on 16 distinct bank quads.
+  auto swz = [](int r) { return D == 64 ? ((r >> 1) & 7) : (r & 15); };
+  int ld_row[IPW], ld_col[IPW];
+#pragma unroll
+  for (int i = 0; i < IPW; ++i) {
+    const int pos = (wave * IPW + i) * 64 + lane;
+    ld_row[i] = pos / CPR;
+    ld_col[i] = (((pos % CPR) ^ swz(ld_row[i])) & (CPR - 1)) * 8;
+  }
   auto issue = [&](int blk) {
     const int n0 = blk * 32;
     if (a.flags) {
@@ -154,37 +177,44 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
         if (r == r_hi) break;
       }
     }
+    char* kt = smem + (blk % NST) * 2 * TILE_B + wave * IPW * 1024;
 #pragma unroll
-    for (int i = 0; i < LD_PER_T; ++i) {
-      const int idx = threadIdx.x + 256 * i;
-      const int row = idx / CPR, ch = idx - row * CPR;
-      const int tok = min(n0 + row, Lk - 1);
-      kst[i] = *(const uint4*)(kg + (long long)tok * a.k_stride_t + ch * 8);
-      vst[i] = *(const uint4*)(vg + (long long)tok * a.v_stride_t + ch * 8);
+    for (int i = 0; i < IPW; ++i) {
+      const int tok = min(n0 + ld_row[i], Lk - 1);
+      __builtin_amdgcn_global_load_lds(TDIST_GLB_PTR(kg + (long long)tok * a.k_stride_t + ld_col[i]),
+                                       TDIST_LDS_PTR(kt + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(TDIST_GLB_PTR(vg + (long long)tok * a.v_stride_t + ld_col[i]),
+                                       TDIST_LDS_PTR(kt + TILE_B + i * 1024), 16, 0, 0);
     }
   };
-  auto commit = [&](int stage) {
-    char* kt = smem + stage * 2 * TILE_B;
-    char* vt = kt + TILE_B;
+  // fragment read offsets of this lane inside a tile
+  int koff[KS], voff[4][VW >= 4 ? VW / 4 : 1];
 #pragma unroll
-    for (int i = 0; i < LD_PER_T; ++i) {
-      const int idx = threadIdx.x + 256 * i;
-      const int row = idx / CPR, ch = idx - row * CPR;
-      *(uint4*)(kt + row * ROW_B + ch * 16) = kst[i];
-      *(uint4*)(vt + row * ROW_B + ch * 16) = vst[i];
+  for (int s2 = 0; s2 < KS; ++s2) koff[s2] = li * ROWB + (((4 * s2 + lg) ^ swz(li)) << 4);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int r = 4 * lg + t;
+#pragma unroll
+    for (int c = 0; c < (VW >= 4 ? VW / 4 : 1); ++c) {
+      const int byte = li * NDV * 2 + 16 * c;
+      voff[t][c] = r * ROWB + ((((byte >> 4) ^ swz(r)) & (CPR - 1)) << 4) + (byte & 15);
     }
-  };
-
-  if (nblk > 0) {
-    issue(0);
-    commit(0);
-    __syncthreads();
-    if (nblk > 1) issue(1);
   }
 
+#pragma unroll
+  for (int s2 = 0; s2 < NST - 1; ++s2)
+    if (s2 < nblk) issue(s2);
+
   for (int blk = 0; blk < nblk; ++blk) {
+    // this wave's part of block blk has landed once at most the loads of the younger blocks are pending;
+    // after the barrier everybody's part has, and nobody reads the stage that the next issue refills
+    const int ahead = min(NST - 2, nblk - 1 - blk);
+    if (NST >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * LPS) : "memory");
+    else if (NST >= 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (blk + NST - 1 < nblk) issue(blk + NST - 1);
     const int n0 = blk * 32;
-    const char* kt = smem + (blk & 1) * 2 * TILE_B;
+    const char* kt = smem + (blk % NST) * 2 * TILE_B;
     const char* vt = kt + TILE_B;
     if (n0 < wave_hi) {
       VT kfr[2][KS];
@@ -192,19 +222,19 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
       for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
         for (int s = 0; s < KS; ++s)
-          kfr[tb][s] = __builtin_bit_cast(VT, *(const uint4*)(kt + (16 * tb + li) * ROW_B + (32 * s + 8 * lg) * 2));
+          kfr[tb][s] = __builtin_bit_cast(VT, *(const uint4*)(kt + 16 * tb * ROWB + koff[s]));
       uint32_t vreg[8][VW];
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        const char* vp = vt + (16 * (t >> 2) + 4 * lg + (t & 3)) * ROW_B + li * NDV * 2;
+        const char* vb = vt + 16 * (t >> 2) * ROWB;
         if constexpr (VW >= 4) {
 #pragma unroll
           for (int c = 0; c < VW / 4; ++c) {
-            const uint4 v = *(const uint4*)(vp + 16 * c);
+            const uint4 v = *(const uint4*)(vb + voff[t & 3][c]);
             vreg[t][4 * c] = v.x, vreg[t][4 * c + 1] = v.y, vreg[t][4 * c + 2] = v.z, vreg[t][4 * c + 3] = v.w;
           }
         } else {
-          const uint2 v = *(const uint2*)vp;
+          const uint2 v = *(const uint2*)(vb + voff[t & 3][0]);
           vreg[t][0] = v.x, vreg[t][1] = v.y;
         }
       }
@@ -267,16 +297,11 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
         for (int rb = 0; rb < RB; ++rb) acc[rb][j] = F::mfma(vfrag, pfrag[rb], acc[rb][j]);
       }
     }
-    if (blk + 1 < nblk) {
-      commit((blk + 1) & 1);
-      __syncthreads();
-      if (blk + 2 < nblk) issue(blk + 2);
-    }
   }
 
   // ---- epilogue: normalise, stage this wave's 32 x D tile in LDS, store full rows
   __syncthreads();
-  char* stg = smem + wave * TILE_B;
+  char* stg = smem + wave * OUT_TILE_B;
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     float l = l_run[rb];
@@ -366,7 +391,7 @@ __global__ __launch_bounds__(256) void sp_kv_push_kernel(KvPushArgs p) {
 
 template <bool IS_BF16, int D, int RB>
 hipError_t launch_attn_rb(const AttnArgs& a, int max_seqlen_q, int batch, hipStream_t st) {
-  constexpr int lds = 2 * 2 * 32 * (D * 2 + 16);
+  constexpr int lds = attn_lds_bytes(D);
   static bool attr_done = false;
   if (!attr_done) {
     const hipError_t e = hipFuncSetAttribute((const void*)flash_attn_fwd_kernel<IS_BF16, D, RB>,
