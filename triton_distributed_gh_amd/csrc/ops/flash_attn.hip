@@ -64,6 +64,16 @@ __device__ __forceinline__ int kv_source_rank(const AttnArgs& a, int n, int Lk) 
   return min(n / per, a.world - 1);
 }
 
+// max(x, x of lane ^ 16) / max(x, x of lane ^ 32) with the gfx950 row-swap instructions (register file only;
+// a cross-lane shuffle would take a round trip through the LDS pipeline on the softmax's critical path)
+template <int XOR>
+__device__ __forceinline__ float xor_max(float x) {
+  const unsigned u = __builtin_bit_cast(unsigned, x);
+  const auto r = XOR == 16 ? __builtin_amdgcn_permlane16_swap(u, u, false, false)
+                           : __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+
 // K/V ring depth and LDS footprint (the ring is reused for the 4 x 32 padded output rows at the end)
 constexpr int attn_stages(int d) { return d <= 128 ? 4 : 2; }
 constexpr int attn_lds_bytes(int d) {
@@ -259,8 +269,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
           sc[t] = s;
           mx = fmaxf(mx, s);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = xor_max<16>(mx);   // the four k-groups of a query row sit 16 lanes apart
+        mx = xor_max<32>(mx);
         const float m_new = fmaxf(m_run[rb], mx);
         const float m_use = m_new == -INFINITY ? 0.f : m_new;
         alpha[rb] = __builtin_amdgcn_exp2f(m_run[rb] - m_use);
@@ -404,9 +414,10 @@ hipError_t launch_attn_rb(const AttnArgs& a, int max_seqlen_q, int batch, hipStr
   return hipGetLastError();
 }
 
-// 64-row workgroups only while 128-row ones would not even give every CU one workgroup: the cost of a
-// KV block hardly depends on the number of query rows, so above that the larger tile wins
-// (TDIST_ATTN_QROWS = 64 / 128 forces one form).
+// 64-row workgroups while 128-row ones would fill the chip's 512 two-per-CU slots at most once (the
+// heaviest causal workgroup then sets the run time, and halving its rows shortens it: S=8192 with 8
+// heads 305 -> 270 us); with two rounds or more the larger tile wins (S=4096, 32 heads: 234 vs 282 us).
+// TDIST_ATTN_QROWS = 64 / 128 forces one form.
 template <bool IS_BF16, int D>
 hipError_t launch_attn(const AttnArgs& a, int max_seqlen_q, int batch, hipStream_t st) {
   static const int forced = [] {
@@ -414,7 +425,7 @@ hipError_t launch_attn(const AttnArgs& a, int max_seqlen_q, int batch, hipStream
     return e ? atoi(e) : 0;
   }();
   const long long wgs128 = (long long)((max_seqlen_q + 127) / 128) * a.q_heads * batch;
-  const bool small = forced == 64 || (forced != 128 && wgs128 <= 256);
+  const bool small = forced == 64 || (forced != 128 && wgs128 <= 512);
   return small ? launch_attn_rb<IS_BF16, D, 1>(a, max_seqlen_q, batch, st)
                : launch_attn_rb<IS_BF16, D, 2>(a, max_seqlen_q, batch, st);
 }
