@@ -161,6 +161,17 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
   const uint16_t* kg = a.k + (long long)k0 * a.k_stride_t + (long long)kvh * a.k_stride_h;
   const uint16_t* vg = a.v + (long long)k0 * a.v_stride_t + (long long)kvh * a.v_stride_h;
   unsigned seen = 0;   // bit r: rank r's KV slab is known to have landed
+  // last KV position each of this lane's query rows may see, and the smallest one in the wave: KV blocks
+  // that end at or below it need no masking at all
+  int lim[RB], lim_min = 0x7fffffff;
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    lim[rb] = a.causal ? min(qpos[rb], Lk - 1) : (qpos[rb] < 0 ? -1 : Lk - 1);
+    lim_min = min(lim_min, lim[rb]);
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) lim_min = min(lim_min, __shfl_xor(lim_min, off));
+  lim_min = __builtin_amdgcn_readfirstlane(lim_min);
 
   // K/V tiles go from global memory straight into LDS (no registers, no second hop), NST - 1 blocks
   // ahead.  A load instruction fills 1024 consecutive LDS bytes, lane i the 16 bytes at 16 * i, so the
@@ -261,17 +272,24 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
         }
         float sc[8];
         float mx = -INFINITY;
-        const int lim = a.causal ? min(qpos[rb], Lk - 1) : (qpos[rb] < 0 ? -1 : Lk - 1);
+        // raw scores: the scale (> 0) is applied to the row maximum and inside the exponent's fused multiply-add
+        if (n0 + 31 <= lim_min) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const int tok = n0 + 16 * (t >> 2) + 4 * lg + (t & 3);
-          const float s = tok <= lim ? st[t >> 2][t & 3] * scale2 : -INFINITY;
-          sc[t] = s;
-          mx = fmaxf(mx, s);
+          for (int t = 0; t < 8; ++t) {
+            sc[t] = st[t >> 2][t & 3];
+            mx = fmaxf(mx, sc[t]);
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            const int tok = n0 + 16 * (t >> 2) + 4 * lg + (t & 3);
+            sc[t] = tok <= lim[rb] ? st[t >> 2][t & 3] : -INFINITY;
+            mx = fmaxf(mx, sc[t]);
+          }
         }
         mx = xor_max<16>(mx);   // the four k-groups of a query row sit 16 lanes apart
         mx = xor_max<32>(mx);
-        const float m_new = fmaxf(m_run[rb], mx);
+        const float m_new = fmaxf(m_run[rb], mx * scale2);
         const float m_use = m_new == -INFINITY ? 0.f : m_new;
         alpha[rb] = __builtin_amdgcn_exp2f(m_run[rb] - m_use);
         m_run[rb] = m_new;
@@ -279,7 +297,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
         uint32_t pw[4];
 #pragma unroll
         for (int t = 0; t < 8; t += 2) {
-          const float p0 = __builtin_amdgcn_exp2f(sc[t] - m_use), p1 = __builtin_amdgcn_exp2f(sc[t + 1] - m_use);
+          const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[t], scale2, -m_use));
+          const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[t + 1], scale2, -m_use));
           psum += p0 + p1;
           pw[t >> 1] = F::pack2(p0, p1);
         }
@@ -441,6 +460,7 @@ TDIST_API int tdist_flash_attn_varlen_fwd(const void* q, const void* k, const vo
                                           long long v_stride_h, long long o_stride_t, long long o_stride_h,
                                           long long lse_stride_h, float sm_scale, int causal, int pos_mode, int rank,
                                           int world, const int* flags, int epoch, int* err, int dtype, void* stream) {
+  TDIST_REQUIRE(sm_scale > 0.f, "softmax scale must be positive");
   TDIST_REQUIRE(batch > 0 && max_seqlen_q > 0 && q_heads > 0 && kv_heads > 0 && q_heads % kv_heads == 0, "bad shape");
   TDIST_REQUIRE(head_dim == 64 || head_dim == 128, "head_dim must be 64 or 128");
   TDIST_REQUIRE((q_stride_t | q_stride_h | k_stride_t | k_stride_h | v_stride_t | v_stride_h | o_stride_t | o_stride_h) % 8 == 0,
