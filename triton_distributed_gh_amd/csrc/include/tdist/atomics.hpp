@@ -103,6 +103,16 @@ __device__ __forceinline__ int thread_idx(int axis) {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (64 - 1); }
 
+// max(x, x of lane ^ 16) / max(x, x of lane ^ 32) with the gfx950 row-swap instructions (register file only;
+// a cross-lane shuffle would take a round trip through the LDS pipeline on the softmax's critical path)
+template <int XOR>
+__device__ __forceinline__ float xor_max(float x) {
+  const unsigned u = __builtin_bit_cast(unsigned, x);
+  const auto r = XOR == 16 ? __builtin_amdgcn_permlane16_swap(u, u, false, false)
+                           : __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+
 // Constant 100 MHz wall clock, independent of the shader clock.
 __device__ __forceinline__ uint64_t wall_ticks() { return __builtin_amdgcn_s_memrealtime(); }
 

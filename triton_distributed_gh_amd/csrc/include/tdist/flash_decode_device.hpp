@@ -3,6 +3,7 @@
 // (csrc/ops/mega_kernel.hip): argument block, paged-slot lookup, the split-KV body and the
 // LSE-weighted row merge.  See flash_decode.hip for the algorithm description.
 #pragma once
+#include "tdist/atomics.hpp"
 #include "tdist/common.hpp"
 #include "tdist/gemm_gfx950.hpp"
 
@@ -209,8 +210,8 @@ __device__ __forceinline__ void decode_split_body(const DecodeArgs& a, const int
       sc[t] = s;
       mx = fmaxf(mx, s);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = xor_max<16>(mx);
+    mx = xor_max<32>(mx);
     const float m_new = fmaxf(m_run, mx);   // finite: the block holds at least one valid token
     const float alpha = fast_exp2(m_run - m_new);
     m_run = m_new;

@@ -64,16 +64,6 @@ __device__ __forceinline__ int kv_source_rank(const AttnArgs& a, int n, int Lk) 
   return min(n / per, a.world - 1);
 }
 
-// max(x, x of lane ^ 16) / max(x, x of lane ^ 32) with the gfx950 row-swap instructions (register file only;
-// a cross-lane shuffle would take a round trip through the LDS pipeline on the softmax's critical path)
-template <int XOR>
-__device__ __forceinline__ float xor_max(float x) {
-  const unsigned u = __builtin_bit_cast(unsigned, x);
-  const auto r = XOR == 16 ? __builtin_amdgcn_permlane16_swap(u, u, false, false)
-                           : __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
-}
-
 // K/V ring depth and LDS footprint (the ring is reused for the 4 x 32 padded output rows at the end)
 constexpr int attn_stages(int d) { return d <= 128 ? 4 : 2; }
 constexpr int attn_lds_bytes(int d) {
