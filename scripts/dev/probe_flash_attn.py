@@ -13,7 +13,7 @@ def bench(fn, iters=20, warmup=5):
     return e0.elapsed_time(e1) / iters * 1e3
 
 for S, Hq, Hkv, D in [(2048, 32, 8, 128), (4096, 32, 8, 128), (8192, 32, 8, 128), (4096, 64, 8, 128), (4096, 32, 8, 64),
-                      (4096, 8, 1, 128), (2048, 8, 2, 128), (8192, 8, 1, 128), (1024, 32, 8, 128)]:
+                      (4096, 8, 1, 128), (2048, 8, 2, 128), (8192, 8, 1, 128), (1024, 32, 8, 128), (4096, 4, 1, 128), (4096, 12, 4, 128), (4096, 20, 4, 128)]:
     q = (torch.randn(S, Hq, D, device="cuda") * 0.5).bfloat16()
     k = (torch.randn(S, Hkv, D, device="cuda") * 0.5).bfloat16()
     v = (torch.randn(S, Hkv, D, device="cuda") * 0.5).bfloat16()

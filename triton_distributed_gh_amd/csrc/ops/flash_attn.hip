@@ -5,9 +5,12 @@
 // (:105-183) and kernel_consumer_flash_attn_forward (:255-425); the same kernel serves the
 // prefill attention of the TP attention layer (layers/amd/tp_attn.py:275-308 uses flash_attn).
 //
-// Attention kernel: one workgroup (4 waves) per 128 query rows of one (sequence, head); each wave
-// owns 32 rows = two 16-row MFMA column blocks.  K/V blocks of 32 tokens are staged once per
-// workgroup in double-buffered LDS (one barrier per block).  As in the decode kernel the scores
+// Attention kernel: one workgroup (4 waves) per 128 (or, for small grids, 64) query rows of one
+// (sequence, head); each wave owns 32 rows = two 16-row MFMA column blocks (or one).  K/V blocks of 32
+// tokens are loaded once per workgroup straight from global memory into a four-stage LDS ring
+// (direct-to-LDS loads, XOR-swizzled 16-byte chunks, three blocks in flight, one raw barrier per
+// block); workgroups are mapped to (head, query block) so that each XCD serves a contiguous group
+// of heads and all XCDs carry the same causal load.  As in the decode kernel the scores
 // are produced transposed (S^T = K.Q^T) so the P operand of O^T = V^T.P^T falls out of the
 // accumulators without cross-lane traffic and the V operand is an in-register transpose of
 // eight 16-byte LDS row reads.
@@ -104,6 +107,12 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
     const int j = lin >> 3;
     h = (lin & 7) * hp + j % hp;
     qb = j / hp;
+  } else {
+    // head counts that do not divide over the XCDs: heads fastest, so the equally heavy workgroups of
+    // one query block are dealt round the XCDs (balance first; KV heads are then shared between L2s)
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    h = lin % a.q_heads;
+    qb = lin / a.q_heads;
   }
   const int b = blockIdx.z;
   const int q0 = a.cu_q[b], Lq = a.cu_q[b + 1] - q0;
