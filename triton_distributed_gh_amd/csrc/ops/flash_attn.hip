@@ -178,12 +178,26 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
   // source chunk it fetches: tile row r keeps chunk c at chunk position c ^ swz(r), and the 16 rows a
   // fragment read touches land on 16 distinct bank quads.
   auto swz = [](int r) { return D == 64 ? ((r >> 1) & 7) : (r & 15); };
-  int ld_row[IPW], ld_col[IPW];
+  // The V tile is read with the transposing LDS load (4 tile rows x 16 columns per 16-lane group, column-
+  // major into the lanes), which hands the MFMA its V^T operand without any in-register shuffling.
+  // Its image: tile row v = 8 lg + 4 tb + i holds the token that the P operand has at k-group lg,
+  // element 4 tb + i (token 16 tb + 4 lg + i of the block); chunk ch of row v sits at byte
+  //   VSUB (v >> 3) + 512 (ch >> 2) + 64 (v & 7) + 16 ((ch & 3) ^ ((v >> 2) & 3)),
+  // so the two 16-lane groups of a half wave read disjoint bank ranges and all column-block offsets
+  // are instruction immediates.
+  constexpr int VSUB = 128 * CPR;
+  int ld_row[IPW], ld_col[IPW], ldv_tok[IPW], ldv_col[IPW];
 #pragma unroll
   for (int i = 0; i < IPW; ++i) {
     const int pos = (wave * IPW + i) * 64 + lane;
     ld_row[i] = pos / CPR;
     ld_col[i] = (((pos % CPR) ^ swz(ld_row[i])) & (CPR - 1)) * 8;
+    const int off = pos * 16;
+    const int vhi = off / VSUB, rem = off % VSUB;
+    const int v = 8 * vhi + (rem % 512) / 64;
+    const int ch = 4 * (rem / 512) + (((rem % 64) / 16) ^ ((v >> 2) & 3));
+    ldv_tok[i] = 16 * ((v >> 2) & 1) + 4 * (v >> 3) + (v & 3);
+    ldv_col[i] = ch * 8;
   }
   auto issue = [&](int blk) {
     const int n0 = blk * 32;
@@ -200,26 +214,24 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
     char* kt = smem + (blk % NST) * 2 * TILE_B + wave * IPW * 1024;
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
-      const int tok = min(n0 + ld_row[i], Lk - 1);
+      const int tok = min(n0 + ld_row[i], Lk - 1), tokv = min(n0 + ldv_tok[i], Lk - 1);
       __builtin_amdgcn_global_load_lds(TDIST_GLB_PTR(kg + (long long)tok * a.k_stride_t + ld_col[i]),
                                        TDIST_LDS_PTR(kt + i * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(TDIST_GLB_PTR(vg + (long long)tok * a.v_stride_t + ld_col[i]),
+      __builtin_amdgcn_global_load_lds(TDIST_GLB_PTR(vg + (long long)tokv * a.v_stride_t + ldv_col[i]),
                                        TDIST_LDS_PTR(kt + TILE_B + i * 1024), 16, 0, 0);
     }
   };
   // fragment read offsets of this lane inside a tile
-  int koff[KS], voff[4][VW >= 4 ? VW / 4 : 1];
+  int koff[KS], vbase_off[2][2];   // V: [token half tb][parity of the 16-column block j]
 #pragma unroll
   for (int s2 = 0; s2 < KS; ++s2) koff[s2] = li * ROWB + (((4 * s2 + lg) ^ swz(li)) << 4);
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int r = 4 * lg + t;
+  for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
-    for (int c = 0; c < (VW >= 4 ? VW / 4 : 1); ++c) {
-      const int byte = li * NDV * 2 + 16 * c;
-      voff[t][c] = r * ROWB + ((((byte >> 4) ^ swz(r)) & (CPR - 1)) << 4) + (byte & 15);
+    for (int jp = 0; jp < 2; ++jp) {
+      const int q = li >> 2, pp = li & 3;   // lane 4 q + p of a group addresses row q, columns 4 p .. 4 p + 3
+      vbase_off[tb][jp] = VSUB * lg + 64 * (4 * tb + q) + 16 * ((2 * jp + (pp >> 1)) ^ ((2 * lg + tb) & 3)) + 8 * (pp & 1);
     }
-  }
 
 #pragma unroll
   for (int s2 = 0; s2 < NST - 1; ++s2)
@@ -243,21 +255,14 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int s = 0; s < KS; ++s)
           kfr[tb][s] = __builtin_bit_cast(VT, *(const uint4*)(kt + 16 * tb * ROWB + koff[s]));
-      uint32_t vreg[8][VW];
+      typedef short tr4 __attribute__((ext_vector_type(4)));
+      uint2 vtr[NDV][2];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const char* vb = vt + 16 * (t >> 2) * ROWB;
-        if constexpr (VW >= 4) {
+      for (int j = 0; j < NDV; ++j)
 #pragma unroll
-          for (int c = 0; c < VW / 4; ++c) {
-            const uint4 v = *(const uint4*)(vb + voff[t & 3][c]);
-            vreg[t][4 * c] = v.x, vreg[t][4 * c + 1] = v.y, vreg[t][4 * c + 2] = v.z, vreg[t][4 * c + 3] = v.w;
-          }
-        } else {
-          const uint2 v = *(const uint2*)(vb + voff[t & 3][0]);
-          vreg[t][0] = v.x, vreg[t][1] = v.y;
-        }
-      }
+        for (int tb = 0; tb < 2; ++tb)
+          vtr[j][tb] = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) tr4*)(vt + vbase_off[tb][j & 1] + 512 * (j >> 1))));
       VT pfrag[RB];
       float alpha[RB];
 #pragma unroll
@@ -316,11 +321,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
       }
 #pragma unroll
       for (int j = 0; j < NDV; ++j) {
-        const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
-        uint32_t vw[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) vw[p] = __builtin_amdgcn_perm(vreg[2 * p + 1][j >> 1], vreg[2 * p][j >> 1], sel);
-        const VT vfrag = __builtin_bit_cast(VT, uint4{vw[0], vw[1], vw[2], vw[3]});
+        const VT vfrag = __builtin_bit_cast(VT, uint4{vtr[j][0].x, vtr[j][0].y, vtr[j][1].x, vtr[j][1].y});
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) acc[rb][j] = F::mfma(vfrag, pfrag[rb], acc[rb][j]);
       }
@@ -340,15 +341,13 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
     if (a.lse && lg == 0 && r < Lq)
       a.lse[(long long)h * a.lse_stride_h + q0 + r] = l > 0.f ? (m_run[rb] + __log2f(l)) * 0.6931471805599453f : -INFINITY;
 #pragma unroll
-    for (int j = 0; j < NDV; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float v = acc[rb][j][i] * inv;
-        uint16_t bits;
-        if constexpr (IS_BF16) bits = __builtin_bit_cast(uint16_t, (__bf16)v);
-        else bits = __builtin_bit_cast(uint16_t, (_Float16)v);
-        *(uint16_t*)(stg + (16 * rb + li) * ROW_B + (NDV * (4 * lg + i) + j) * 2) = bits;
-      }
+    for (int j = 0; j < NDV; ++j) {
+      // accumulator j of lane (li, lg): head-dim columns 16 j + 4 lg .. + 3 of query row li
+      uint2 pk;
+      pk.x = F::pack2(acc[rb][j][0] * inv, acc[rb][j][1] * inv);
+      pk.y = F::pack2(acc[rb][j][2] * inv, acc[rb][j][3] * inv);
+      *(uint2*)(stg + (16 * rb + li) * ROW_B + (16 * j + 4 * lg) * 2) = pk;
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
