@@ -68,9 +68,9 @@ __device__ __forceinline__ int kv_source_rank(const AttnArgs& a, int n, int Lk) 
 }
 
 // K/V ring depth and LDS footprint (the ring is reused for the 4 x 32 padded output rows at the end)
-constexpr int attn_stages(int d) { return d <= 128 ? 4 : 2; }
-constexpr int attn_lds_bytes(int d) {
-  const int ring = attn_stages(d) * 2 * 32 * d * 2, out = 4 * 32 * (d * 2 + 16);
+constexpr int attn_stages(int d, int rb) { return d <= 128 ? (rb == 1 ? 3 : 4) : 2; }
+constexpr int attn_lds_bytes(int d, int rb) {
+  const int ring = attn_stages(d, rb) * 2 * 32 * d * 2, out = 4 * 32 * (d * 2 + 16);
   return ring > out ? ring : out;
 }
 
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_fwd_kernel(AttnArgs a) {
   constexpr int CPR = D / 8;                 // 16-byte chunks per row
   constexpr int IPW = CPR / 8;               // direct-to-LDS loads (64 lanes x 16 bytes) per wave and tile
   constexpr int LPS = 2 * IPW;               // ... per wave and stage (K and V)
-  constexpr int NST = attn_stages(D);        // stages of the K/V ring; NST - 1 blocks are in flight
+  constexpr int NST = attn_stages(D, RB);        // stages of the K/V ring; NST - 1 blocks are in flight
   constexpr int ROW_B = D * 2 + 16;          // padded row of the epilogue's output staging
   constexpr int OUT_TILE_B = 32 * ROW_B;
   constexpr float LOG2E = 1.4426950408889634f;
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void sp_kv_push_kernel(KvPushArgs p) {
 
 template <bool IS_BF16, int D, int RB>
 hipError_t launch_attn_rb(const AttnArgs& a, int max_seqlen_q, int batch, hipStream_t st) {
-  constexpr int lds = attn_lds_bytes(D);
+  constexpr int lds = attn_lds_bytes(D, RB);
   static bool attr_done = false;
   if (!attr_done) {
     const hipError_t e = hipFuncSetAttribute((const void*)flash_attn_fwd_kernel<IS_BF16, D, RB>,
