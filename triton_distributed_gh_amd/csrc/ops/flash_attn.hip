@@ -431,10 +431,10 @@ hipError_t launch_attn_rb(const AttnArgs& a, int max_seqlen_q, int batch, hipStr
   return hipGetLastError();
 }
 
-// 64-row workgroups while 128-row ones would fill the chip's 512 two-per-CU slots at most once (the
-// heaviest causal workgroup then sets the run time, and halving its rows shortens it: S=8192 with 8
-// heads 305 -> 270 us); with two rounds or more the larger tile wins (S=4096, 32 heads: 234 vs 282 us).
-// TDIST_ATTN_QROWS = 64 / 128 forces one form.
+// 64-row workgroups (three per CU: 138 registers, three-stage ring) while 128-row ones (two per CU) would
+// number at most 768: the heaviest causal workgroup then sets the run time, and halving its rows
+// shortens it (S=2048 with 32 heads 74 -> 60 us, S=4096 with 20 heads 152 -> 133 us); from 1024 on the
+// larger tile wins (S=4096, 32 heads: 200 vs 220 us).  TDIST_ATTN_QROWS = 64 / 128 forces one form.
 template <bool IS_BF16, int D>
 hipError_t launch_attn(const AttnArgs& a, int max_seqlen_q, int batch, hipStream_t st) {
   static const int forced = [] {
@@ -442,7 +442,7 @@ hipError_t launch_attn(const AttnArgs& a, int max_seqlen_q, int batch, hipStream
     return e ? atoi(e) : 0;
   }();
   const long long wgs128 = (long long)((max_seqlen_q + 127) / 128) * a.q_heads * batch;
-  const bool small = forced == 64 || (forced != 128 && wgs128 <= 512);
+  const bool small = forced == 64 || (forced != 128 && wgs128 <= 768);
   return small ? launch_attn_rb<IS_BF16, D, 1>(a, max_seqlen_q, batch, st)
                : launch_attn_rb<IS_BF16, D, 2>(a, max_seqlen_q, batch, st);
 }
