@@ -9,6 +9,16 @@ are also timed separately, and the same pair built from torch.matmul + RCCL coll
 the same process as the yardstick the reference uses (reference:
 python/triton_dist/test/amd/test_gemm_rs_intra_node.py:48-64, layers/amd/tp_mlp.py:156-202).
 
+The timed path is ALWAYS this repository's kernels.  Before timing, the fused ops are checked
+element by element against an fp32-accumulated gold on fresh random inputs - 50 times at TP > 1 - and
+once more after the timed loop.  The tolerance of an element is 1e-2 of the magnitude that was rounded
+to bf16 on its way (|gold| for AG-GEMM; the sum of the |per-rank partials| for GEMM-RS, whose partials
+travel in bf16 as in the reference and in RCCL) plus 1e-3 - the reference's rtol = 1e-2 without its
+atol = 1e-2 floor, which would hide a wrong row of small values.  If the symmetric
+heap cannot be set up, a check fails or a device-side wait times out, the script prints the JSON line
+with "value": null (the torch + RCCL times stay in it as extra fields) and exits with status 1: it
+never reports a torch + RCCL time as the result.
+
 Launch:  python bench.py --gpus 1            (single process)
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
                 --master-port P bench.py --gpus N --steps K --warmup W
@@ -29,6 +39,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 M, N, K = 4096, 8192, 8192
+RTOL, ATOL = 1e-2, 1e-3
 
 
 def _sync_all(env):
@@ -55,7 +66,8 @@ def _time_steps(env, fn, steps, warmup):
 
 
 def _plain_env():
-    """torch.distributed only (no symmetric heap): enough for the torch.matmul + RCCL path."""
+    """torch.distributed only (no symmetric heap): enough to time torch.matmul + RCCL for the report
+    of a run whose fused path could not even start."""
     import datetime
     from types import SimpleNamespace
 
@@ -72,7 +84,27 @@ def _plain_env():
         cpu_group = dist.new_group(ranks=list(range(world)), backend="gloo")
         tp_group = dist.group.WORLD
     return SimpleNamespace(rank=rank, world_size=world, device=dev, heap=None, shared_gpu=shared, has_rccl=not shared,
-                           cpu_group=cpu_group, tp_group=tp_group)
+                           cpu_group=cpu_group, tp_group=tp_group, heap_mode="none", selftest=None, selftest_log=())
+
+
+def _all_agree(env, ok: bool) -> bool:
+    if env.world_size > 1:
+        flag = torch.tensor([1 if ok else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=env.cpu_group)
+        ok = bool(flag[0])
+    return ok
+
+
+def _mismatch(got: torch.Tensor, gold: torch.Tensor, mag: torch.Tensor) -> str:
+    """'' when every element satisfies |got - gold| <= ATOL + RTOL * mag, else a description."""
+    g = got.float()
+    bad = (g - gold).abs() > ATOL + RTOL * mag
+    n = int(bad.sum())
+    if n == 0 and bool(torch.isfinite(g).all()):
+        return ""
+    idx = bad.nonzero()[0].tolist() if n else [-1, -1]
+    return (f"{n} of {g.numel()} elements outside {ATOL} + {RTOL} * magnitude (first at {idx}, max abs diff "
+            f"{(g - gold).abs().max().item():.4e})")
 
 
 def main():
@@ -81,41 +113,48 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-baseline", action="store_true", help="skip the torch+RCCL yardstick")
+    ap.add_argument("--producer", choices=("kernel", "copy_engine"), default=None,
+                    help="AG-GEMM producer: in-kernel push work items (default) or the SDMA copy engines")
+    ap.add_argument("--check-iters", type=int, default=-1,
+                    help="fresh-input checks before timing (default: 50 at TP > 1 on real devices, 3 otherwise)")
     args = ap.parse_args()
 
     from triton_distributed_gh_amd.ops.ag_gemm import ag_gemm_intra_node, create_ag_gemm_intra_node_context
     from triton_distributed_gh_amd.ops.gemm_rs import create_gemm_rs_intra_node_context, gemm_rs_intra_node
     from triton_distributed_gh_amd.utils import finalize_distributed, initialize_distributed
 
-    # The symmetric heap (hipIpc mappings of every peer) is what the fused path stands on.  If it
-    # cannot be set up on this machine the benchmark still runs - on torch.matmul + RCCL - and says so.
-    init_note = ""
+    # The symmetric heap (hipIpc mappings of every peer, proven coherent by the start-up self-test) is
+    # what the fused path stands on.  If it cannot be set up there is no result to report.
+    problems = []
     try:
-        if os.environ.get("TDIST_BENCH_FORCE_PLAIN") == "1":      # exercises the fall-back below
+        if os.environ.get("TDIST_BENCH_FORCE_PLAIN") == "1":      # exercises the failure path below
             raise RuntimeError("forced by TDIST_BENCH_FORCE_PLAIN")
         env = initialize_distributed(seed=0)
-    except Exception as exc:  # noqa: BLE001 - reported in the JSON line
-        init_note = f"symmetric heap unavailable ({type(exc).__name__}: {exc}); "
+    except Exception as exc:  # noqa: BLE001 - reported in the JSON line, exit status 1
+        problems.append(f"symmetric heap unavailable ({type(exc).__name__}: {exc})")
         env = _plain_env()
     w, r, dev = env.world_size, env.rank, env.device
     assert w == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={w}"
     dt = torch.bfloat16
+    Mr = M // w
     ctas = max(8, 224 // w) if env.shared_gpu else 0
 
-    a1 = (torch.rand(M // w, K, device=dev) * 2 - 1).to(dt)
-    w1 = (torch.rand(N // w, K, device=dev) * 2 - 1).to(dt) * 0.05
-    a2 = (torch.rand(M, K // w, device=dev) * 2 - 1).to(dt)
-    w2 = (torch.rand(N, K // w, device=dev) * 2 - 1).to(dt) * 0.05
+    def fresh(shape, scale=1.0):
+        return ((torch.rand(*shape, device=dev) * 2 - 1) * scale).to(dt)
+
+    a1, w1 = fresh((Mr, K)), fresh((N // w, K), 0.05)
+    a2, w2 = fresh((M, K // w)), fresh((N, K // w), 0.05)
 
     ag_ctx = rs_ctx = None
     if env.heap is not None:
-        ag_ctx = create_ag_gemm_intra_node_context(M, N // w, K, dt, dt, r, w, env.tp_group, M_PER_CHUNK=256, num_ctas=ctas)
+        ag_ctx = create_ag_gemm_intra_node_context(M, N // w, K, dt, dt, r, w, env.tp_group, M_PER_CHUNK=256,
+                                                   num_ctas=ctas, producer=args.producer)
         rs_ctx = create_gemm_rs_intra_node_context(M, N, dt, r, w, env.tp_group, M_PER_CHUNK=256, num_ctas=ctas)
 
-    # ---- torch + RCCL reference implementation of the same pair --------------------------------
+    # ---- torch + RCCL implementation of the same pair (yardstick; not available on a shared GPU) ----
     a1_full = torch.empty(M, K, device=dev, dtype=dt)
     c2_full = torch.empty(M, N, device=dev, dtype=dt)
-    c2_out = torch.empty(M // w, N, device=dev, dtype=dt)
+    c2_out = torch.empty(Mr, N, device=dev, dtype=dt)
 
     def torch_ag_gemm():
         if w > 1:
@@ -136,97 +175,133 @@ def main():
     def fused_rs():
         return gemm_rs_intra_node(a2, w2, rs_ctx)
 
-    # ---- one checked step: the timed path must produce the reference's numbers ------------------
-    fused_ok = True
-    note = init_note
-    try:
-        if ag_ctx is None:
-            raise RuntimeError("no symmetric heap")
-        c1 = fused_ag()
-        c2 = fused_rs()
+    # ---- fp32-accumulated gold of both ops on the current inputs -------------------------------------
+    sample = torch.arange(0, Mr, max(1, Mr // 128), device=dev)        # shared GPU: rows checked per shard
+
+    def gold_ag():
+        """fp32 [M, N/w] (or the sampled rows of every shard on a shared GPU) and the matching row index."""
+        if w == 1:
+            return a1.float() @ w1.float().t(), None
+        if env.has_rccl:
+            dist.all_gather_into_tensor(a1_full, a1, group=env.tp_group)
+            return a1_full.float() @ w1.float().t(), None
+        mine = a1[sample].contiguous().view(torch.uint8).cpu()          # (bytes: gloo has no 16-bit integer type)
+        parts = [torch.empty_like(mine) for _ in range(w)]
+        dist.all_gather(parts, mine, group=env.cpu_group)
+        rows = torch.cat([p.view(dt) for p in parts]).to(dev)
+        idx = torch.cat([sample + j * Mr for j in range(w)])
+        return rows.float() @ w1.float().t(), idx
+
+    def gold_rs():
+        """(gold, magnitude, rows): fp32 sum over ranks of the bf16-rounded partials of this rank's shard
+        [M/w, N] and the sum of their absolute values (sampled rows on a shared GPU)."""
+        if w == 1:
+            g = a2.float() @ w2.float().t()
+            return g, g.abs(), None
+        if env.has_rccl:
+            part = (a2.float() @ w2.float().t()).to(dt).float()
+            out = torch.empty(Mr, N, device=dev, dtype=torch.float32)
+            mag = torch.empty(Mr, N, device=dev, dtype=torch.float32)
+            dist.reduce_scatter_tensor(out, part, group=env.tp_group)
+            dist.reduce_scatter_tensor(mag, part.abs_(), group=env.tp_group)
+            return out, mag, None
+        idx = torch.cat([sample + j * Mr for j in range(w)])
+        t = (a2[idx].float() @ w2.float().t()).to(dt).float().cpu()    # [w * |sample|, N]
+        m = t.abs()
+        dist.all_reduce(t, group=env.cpu_group)
+        dist.all_reduce(m, group=env.cpu_group)
+        return t.view(w, -1, N)[r].to(dev), m.view(w, -1, N)[r].to(dev), sample
+
+    def check_once(tag: str) -> str:
+        c1, c2 = fused_ag(), fused_rs()
         torch.cuda.synchronize()
         ag_ctx.check_error()
         rs_ctx.check_error()
-        if env.has_rccl or w == 1:
-            r1 = torch_ag_gemm().float()
-            r2 = torch_gemm_rs().float()
-            e1 = ((c1.float() - r1).abs().max() / r1.abs().max()).item()
-            e2 = ((c2.float() - r2).abs().max() / r2.abs().max()).item()
-            if not (e1 < 2e-2 and e2 < 2e-2):
-                fused_ok, note = False, f"fused result mismatch (rel err {e1:.3e}, {e2:.3e})"
-    except Exception as exc:  # noqa: BLE001 - reported in the JSON line, the run continues on RCCL
-        fused_ok, note = False, init_note + f"fused path failed: {exc}"
-    if w > 1:
-        flag = torch.tensor([1 if fused_ok else 0])
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=env.cpu_group)
-        fused_ok = bool(flag[0])
+        g1, i1 = gold_ag()
+        g2, mag2, i2 = gold_rs()
+        m1 = _mismatch(c1 if i1 is None else c1[i1], g1, g1.abs())
+        m2 = _mismatch(c2 if i2 is None else c2[i2], g2, mag2)
+        if m1 or m2:
+            return f"{tag}: " + "; ".join(x for x in (("AG-GEMM " + m1) if m1 else "", ("GEMM-RS " + m2) if m2 else "") if x)
+        return ""
 
-    run_ag, run_rs = (fused_ag, fused_rs) if fused_ok else (torch_ag_gemm, torch_gemm_rs)
+    # ---- checks on fresh inputs: the timed path must produce the gold's numbers ------------------------
+    n_checks = args.check_iters if args.check_iters >= 0 else (1 if w == 1 else (50 if env.has_rccl else 3))
+    checks_run = 0
+    if not problems:
+        for it in range(n_checks):
+            if it:
+                a1.copy_(fresh((Mr, K)))
+                a2.copy_(fresh((M, K // w)))
+            try:
+                msg = check_once(f"check {it}")
+            except Exception as exc:  # noqa: BLE001
+                msg = f"check {it}: fused path failed: {type(exc).__name__}: {exc}"
+            if not _all_agree(env, msg == ""):
+                problems.append(msg or "a peer rank failed its check")
+                break
+            checks_run += 1
+
+    fused_ok = not problems
 
     def step():
-        run_ag()
-        run_rs()
+        fused_ag()
+        fused_rs()
 
-    # Clock settle (setup, untimed): the first back-to-back full-chip GEMMs after an idle period run
-    # through a power-management transient (kernel times swing 360 -> 500 -> 360 us over ~30 ms in
-    # rocprofv3 traces); drive the chip to its steady state before the W warm-up steps so that the
-    # timed steps of every path (fused and torch+RCCL alike) see the same clocks.
-    settle_t0 = time.perf_counter()
-    while time.perf_counter() - settle_t0 < 0.25:
-        for _ in range(10):
-            step()
-        torch.cuda.synchronize()
+    def base_step():
+        torch_ag_gemm()
+        torch_gemm_rs()
 
-    total_us = _time_steps(env, step, args.steps, args.warmup)
-    ag_us = _time_steps(env, run_ag, max(5, args.steps // 2), 3)
-    rs_us = _time_steps(env, run_rs, max(5, args.steps // 2), 3)
-    base_us = None
-    if not args.no_baseline and (env.has_rccl or w == 1):
-        def base_step():
-            torch_ag_gemm()
-            torch_gemm_rs()
-        base_us = _time_steps(env, base_step, max(5, args.steps // 2), 3)
+    total_us = ag_us = rs_us = None
     if fused_ok:
-        # The timed calls reuse the parity buffers many times over: check the LAST results too, so a
-        # number is only reported for a path that was still producing the reference's values at the end.
-        late_ok = True
+        # Clock settle (setup, untimed): the first back-to-back full-chip GEMMs after an idle period run
+        # through a power-management transient (kernel times swing 360 -> 500 -> 360 us over ~30 ms in
+        # rocprofv3 traces); drive the chip to its steady state before the W warm-up steps.
+        settle_t0 = time.perf_counter()
+        while time.perf_counter() - settle_t0 < 0.25:
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+        total_us = _time_steps(env, step, args.steps, args.warmup)
+        ag_us = _time_steps(env, fused_ag, max(5, args.steps // 2), 3)
+        rs_us = _time_steps(env, fused_rs, max(5, args.steps // 2), 3)
+        # The timed calls reuse the parity buffers many times over: check the LAST state too, so a number
+        # is only reported for a path that was still producing the gold's values at the end.
         try:
-            ag_ctx.check_error()
-            rs_ctx.check_error()
-            if env.has_rccl or w == 1:
-                c1 = fused_ag()
-                c2 = fused_rs()
-                torch.cuda.synchronize()
-                r1 = torch_ag_gemm().float()
-                r2 = torch_gemm_rs().float()
-                e1 = ((c1.float() - r1).abs().max() / r1.abs().max()).item()
-                e2 = ((c2.float() - r2).abs().max() / r2.abs().max()).item()
-                if not (e1 < 2e-2 and e2 < 2e-2):
-                    late_ok, note = False, f"fused result mismatch after the timed loop (rel err {e1:.3e}, {e2:.3e})"
+            msg = check_once("check after the timed loop")
         except Exception as exc:  # noqa: BLE001
-            late_ok, note = False, f"fused path failed during / after the timed loop: {exc}"
-        if w > 1:
-            flag = torch.tensor([1 if late_ok else 0])
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=env.cpu_group)
-            late_ok = bool(flag[0])
-        if not late_ok:
-            # report the torch.matmul + RCCL pair instead (timed with the same K / W)
+            msg = f"fused path failed during / after the timed loop: {type(exc).__name__}: {exc}"
+        if not _all_agree(env, msg == ""):
+            problems.append(msg or "a peer rank failed its check after the timed loop")
             fused_ok = False
-            run_ag, run_rs = torch_ag_gemm, torch_gemm_rs
-            total_us = _time_steps(env, step, args.steps, args.warmup)
-            ag_us = _time_steps(env, run_ag, max(5, args.steps // 2), 3)
-            rs_us = _time_steps(env, run_rs, max(5, args.steps // 2), 3)
+
+    base_us = base_ag_us = base_rs_us = None
+    if not args.no_baseline and (env.has_rccl or w == 1):
+        if not fused_ok:
+            for _ in range(50):
+                base_step()
+            torch.cuda.synchronize()
+        base_us = _time_steps(env, base_step, max(5, args.steps // 2), 3)
+        base_ag_us = _time_steps(env, torch_ag_gemm, max(5, args.steps // 2), 3)
+        base_rs_us = _time_steps(env, torch_gemm_rs, max(5, args.steps // 2), 3)
 
     if r == 0:
         flops = 2.0 * (2.0 * M * N * K) / w  # per GPU per step
+        rnd = lambda x: None if x is None else round(x, 2)  # noqa: E731
+        if not fused_ok:
+            timed_path = "none (fused path rejected; exit status 1)"
+        elif w == 1:
+            timed_path = "native gfx950 GEMM kernels (TP=1: no collective, AG-GEMM and GEMM-RS are plain GEMMs)"
+        else:
+            timed_path = "fused HIP kernels (AG-GEMM and GEMM-RS, one persistent launch each)"
         out = {
             "metric": "intranode AG-GEMM + GEMM-RS latency (us), M=4096 N=K=8192 bf16",
-            "value": round(total_us, 2),
+            "value": rnd(total_us) if fused_ok else None,
             "unit": "us",
             "n_gpus": w,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(total_us / 1e3, 5),
+            "ms_per_step": round(total_us / 1e3, 5) if fused_ok else None,
             "higher_is_better": False,
             "scaling": "strong",
             "vs_baseline": None,
@@ -234,19 +309,28 @@ def main():
             "data": "synthetic (uniform random activations, random-init weights)",
             "config": {"model": "TP MLP-style pair (AG-GEMM then GEMM-RS)", "M": M, "N": N, "K": K,
                        "global_batch": M, "seq_len": 1, "parallelism": f"tp{w}"},
-            "ag_gemm_us": round(ag_us, 2),
-            "gemm_rs_us": round(rs_us, 2),
-            "torch_rccl_pair_us": None if base_us is None else round(base_us, 2),
-            "speedup_vs_torch_rccl": None if base_us is None else round(base_us / total_us, 4),
-            "tflops_per_gpu": round(flops / total_us / 1e6, 1),
-            "timed_path": "fused HIP kernels" if fused_ok else "torch.matmul + RCCL (fused path rejected)",
-            "note": note,
+            "ag_gemm_us": rnd(ag_us) if fused_ok else None,
+            "gemm_rs_us": rnd(rs_us) if fused_ok else None,
+            "torch_ag_gemm_us": rnd(base_ag_us),
+            "torch_gemm_rs_us": rnd(base_rs_us),
+            "torch_rccl_pair_us": rnd(base_us),
+            "speedup_vs_torch_rccl": round(base_us / total_us, 4) if (fused_ok and base_us) else None,
+            "tflops_per_gpu": round(flops / total_us / 1e6, 1) if fused_ok else None,
+            "timed_path": timed_path,
+            "producer": (ag_ctx.producer if (ag_ctx is not None and w > 1) else "none"),
+            "heap_mode": env.heap_mode,
+            "heap_selftest": [f"{m}: {d}" for m, d in getattr(env, "selftest_log", ())],
+            "ranks_share_one_gpu": bool(env.shared_gpu),
+            "checks_passed_before_timing": checks_run,
+            "note": "; ".join(problems),
         }
         print(json.dumps(out), flush=True)
     if env.heap is not None:
         finalize_distributed()
     elif dist.is_initialized():
         dist.destroy_process_group()
+    if not fused_ok:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -13,19 +13,50 @@ ROOT = Path(__file__).resolve().parent.parent
 pytestmark = pytest.mark.gpu
 
 
-def _torchrun(nproc, script, *args, port=29571, timeout=240):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TDIST_LOG="0")
+def _torchrun(nproc, script, *args, port=29571, timeout=240, **extra_env):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TDIST_LOG="0", **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), str(script), *args]
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
 
+def _bench_line(res):
+    return json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+
+
 def test_bench_two_processes_run_the_fused_path():
+    """The driver's launch line at N=2: the heap self-test passes in the default (coarse-grained) mode,
+    the fresh-input checks against the gloo-gathered fp32 gold pass, and the JSON carries the per-op
+    times and the heap mode."""
     res = _torchrun(2, ROOT / "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-baseline")
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
-    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["timed_path"] == "fused HIP kernels" and out["note"] == "", out
+    out = _bench_line(res)
+    assert out["n_gpus"] == 2 and out["timed_path"].startswith("fused HIP kernels") and out["note"] == "", out
+    assert out["heap_mode"] == "coarse" and out["heap_selftest"] and out["heap_selftest"][0].startswith("coarse: ok"), out
+    assert "plain_mismatches=0" in out["heap_selftest"][0] and "timeouts=0" in out["heap_selftest"][0], out
+    assert out["checks_passed_before_timing"] == 3 and out["value"] > 0 and out["ag_gemm_us"] > 0, out
+    assert "torch_ag_gemm_us" in out and "torch_gemm_rs_us" in out and out["producer"] == "kernel", out
+
+
+def test_heap_selftest_falls_back_to_the_next_memory_mode():
+    """A failed probe of the coarse-grained arena (injected) moves the heap to fine-grained memory on
+    every rank, and the fused ops still pass their checks there."""
+    res = _torchrun(2, ROOT / "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-baseline",
+                    "--check-iters", "2", port=29573, TDIST_SELFTEST_FAIL_MODES="0", TDIST_SELFTEST_ROUNDS="20")
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    out = _bench_line(res)
+    assert out["heap_mode"] == "fine" and len(out["heap_selftest"]) == 2, out
+    assert out["heap_selftest"][0].startswith("coarse: FAILED") and out["heap_selftest"][1].startswith("fine: ok"), out
+    assert out["checks_passed_before_timing"] == 2 and out["note"] == "", out
+
+
+def test_bench_exits_nonzero_when_the_fused_path_is_rejected():
+    """No silent swap to torch + RCCL: without a symmetric heap there is no result and the exit status says so."""
+    res = _torchrun(2, ROOT / "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-baseline",
+                    port=29574, TDIST_BENCH_FORCE_PLAIN="1")
+    assert res.returncode != 0, res.stdout[-2000:]
+    out = _bench_line(res)
+    assert out["value"] is None and out["timed_path"].startswith("none") and "forced" in out["note"], out
 
 
 def test_cli_script_two_processes_check():

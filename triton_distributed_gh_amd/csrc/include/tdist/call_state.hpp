@@ -10,6 +10,11 @@
 // All ranks issue the same sequence of launches, so their counters stay equal without any exchange.
 // A workgroup can only finish after it has read the call number, hence nobody sees the new value
 // early; the next launch starts after this kernel's end-of-kernel release.
+//
+// The same "last workgroup out" also re-arms the kernel's work counters (ticket, arrival counters): it
+// zeroes them for the next launch, so a launch is ONE kernel node - no memset node in front of it -
+// and costs one dispatch instead of two.  The words are zero when the context is created; a launch
+// that gave up on a timeout leaves them undefined, which is why the error word is sticky.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -30,16 +35,23 @@ __device__ __forceinline__ int call_parity(int call) { return call & 1; }
 __device__ __forceinline__ int call_epoch(int call) { return call % CALL_EPOCH_MOD + 1; }
 
 // Starts with a workgroup barrier (all of the workgroup's work is issued; completion of its stores is
-// the kernel's own business - the counter only orders launches on one stream).
-__device__ __forceinline__ void call_end(int* state, int call) {
+// the kernel's own business - the counter only orders launches on one stream).  `fin` counts finished
+// workgroups; the last one zeroes `counters[0 .. n_counters)` (every other workgroup has drawn its last
+// ticket before it reported, so nobody reads them any more in this launch) and, when `state` is set,
+// advances the call number.
+__device__ __forceinline__ void call_end(int* state, int call, int* fin, int* counters, int n_counters) {
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const int prev = atom_add_relaxed_agent(state + 1, 1);
-    if (prev == (int)gridDim.x - 1) {
-      store_relaxed_agent(state + 1, 0);
-      store_relaxed_agent(state, (call + 1) % (2 * CALL_EPOCH_MOD));
+  const int prev = threadIdx.x == 0 ? atom_add_relaxed_agent(fin, 1) : 0;
+  if (__builtin_amdgcn_readfirstlane(prev) != (int)gridDim.x - 1) return;     // (only wave 0 can pass)
+  if (threadIdx.x < 64) {
+    for (int i = threadIdx.x; i < n_counters; i += 64) store_relaxed_agent(counters + i, 0);
+    if (threadIdx.x == 0) {
+      store_relaxed_agent(fin, 0);
+      if (state) store_relaxed_agent(state, (call + 1) % (2 * CALL_EPOCH_MOD));
     }
   }
 }
+
+__device__ __forceinline__ void call_end(int* state, int call) { call_end(state, call, state + 1, nullptr, 0); }
 
 }  // namespace tdist

@@ -25,6 +25,9 @@
 //   * tiles are handed out dynamically, so a workgroup stalled on a late chunk never holds back
 //     tiles whose data already arrived;
 //   * every spin is bounded and reports through an error word instead of hanging the GPU.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "tdist/cache_policy.hpp"
 #include "tdist/call_state.hpp"
 #include "tdist/common.hpp"
@@ -42,10 +45,12 @@ struct AgGemmParams {
   const uint16_t* B;         // [N_local, K]
   uint16_t* C;               // [M, N_local]
   int* flags;                // [w * chunks_per_rank] of this call's parity (symmetric, signal arena)
-  int* ticket;               // zeroed before launch
+  int* ticket;               // work counters: zero at launch (re-armed by the last workgroup of every launch)
   int* err;                  // sticky error word (bit 0 = wait timeout)
-  int* push_done;            // [chunks_per_rank] zeroed before launch (push_wgs > 0)
-  int* tile_flags;           // [tiles] arrival counters, zeroed before launch (split_k > 1)
+  int* fin;                  // finished-workgroup counter of this launch
+  int n_counters;            // ints from `ticket` on that the last workgroup zeroes
+  int* push_done;            // [chunks_per_rank] (push_wgs > 0)
+  int* tile_flags;           // [tiles] arrival counters (split_k > 1)
   float* partial;            // [tiles * split_k][32][512] f32x4 (split_k > 1)
   long long lda_local, ld_ws, ldb, ldc;
   int M_per_rank, N_local, K;
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(THREADS, 2) void ag_gemm_consumer_kernel(AgGemmPara
         },
         smem, store_c);
   }
-  if (p.state) call_end(p.state, call);
+  call_end(p.state, call, p.fin, p.ticket, p.n_counters);
 }
 
 // In-kernel producer (alternative to the copy engines): workgroup b pushes slice (b % slices) of
@@ -359,8 +364,9 @@ static int check_common(const void* B, const void* C, int N_local, int K, long l
   return 0;
 }
 
-// scratch layout (int32): [0] error word (sticky, never cleared here), [4] ticket,
-// [8, 8 + cpr) push counters, [8 + cpr, 8 + cpr + tiles) split-K arrival counters.
+// scratch layout (int32): [0] error word (sticky, never cleared here), [1] finished-workgroup counter,
+// [4] ticket, [8, 8 + cpr) push counters, [8 + cpr, 8 + cpr + tiles) split-K arrival counters.  Everything
+// from [1] on must be zero at the first launch; every launch leaves it zero again (call_state.hpp).
 // `state` != nullptr: device-side call numbering; ws / flags are then parity 0 and ws1 / flags1 parity 1,
 // and `epoch` is ignored.
 TDIST_API int tdist_ag_gemm_consumer(const tdist::SymmCtx* ctx, const void* a_local, void* ws, const void* B, void* C,
@@ -396,6 +402,8 @@ TDIST_API int tdist_ag_gemm_consumer(const tdist::SymmCtx* ctx, const void* a_lo
   p.C = (uint16_t*)C;
   p.flags = flags;
   p.err = scratch;
+  p.fin = scratch + 1;
+  p.n_counters = (int)((need_ints - 4 + 3) & ~3ll);
   p.ticket = scratch + 4;
   p.push_done = scratch + 8;
   p.tile_flags = scratch + 8 + cpr;
@@ -422,6 +430,14 @@ TDIST_API int tdist_ag_gemm_consumer(const tdist::SymmCtx* ctx, const void* a_lo
   const int total = p.push_wgs + tiles * split_k;
   int grid = num_ctas > 0 ? num_ctas : 256;
   if (grid > total) grid = total;
+  static const bool trace = getenv("TDIST_TRACE_LAUNCH") != nullptr;
+  if (trace)
+    fprintf(stderr,
+            "[tdist] ag_gemm rank %d/%d a=%p ws0=%p ws1=%p B=%p C=%p flags0=%p flags1=%p scratch=%p(%lld ints) "
+            "partial=%p(%lld B) state=%p Mr=%d N=%d K=%d rpc=%d straddle=%d push=%d splitk=%d grid=%d total=%d\n",
+            rank, world, a_local, ws, ws1, B, C, (void*)flags, (void*)flags1, (void*)scratch, scratch_ints, partial,
+            partial_bytes, (void*)state, M_per_rank, N_local, K, rows_per_chunk, straddle, p.push_wgs, split_k, grid,
+            total);
   static bool attr_set = false;
   if (!attr_set) {
     TDIST_HIP_TRY(hipFuncSetAttribute((const void*)ag_gemm_consumer_kernel<true>,
@@ -430,8 +446,6 @@ TDIST_API int tdist_ag_gemm_consumer(const tdist::SymmCtx* ctx, const void* a_lo
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 16));
     attr_set = true;
   }
-  // one memset, 16-byte granular, covers the ticket and every counter (the error word is sticky)
-  TDIST_HIP_TRY(hipMemsetAsync(scratch + 4, 0, (size_t)((need_ints - 4 + 3) & ~3ll) * sizeof(int), (hipStream_t)stream));
   if (dtype == 0)
     hipLaunchKernelGGL(ag_gemm_consumer_kernel<true>, dim3(grid), dim3(THREADS), LDS_BYTES + 16, (hipStream_t)stream, p);
   else

@@ -18,6 +18,9 @@
 // (kernels/nvidia/gemm_reduce_scatter.py:121-250, reduce_scatter.py:600-697).  Here scatter
 // buffers and flags are double-buffered by call parity and flags carry the call's epoch, so no
 // cross-rank barrier is needed at all.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "tdist/cache_policy.hpp"
 #include "tdist/call_state.hpp"
 #include "tdist/common.hpp"
@@ -33,7 +36,8 @@ struct GemmRsParams {
   const uint16_t* B;     // [N, K_local]
   uint16_t* scatter;     // symmetric, this parity: [w][M_per_rank][N]
   int* flags;            // symmetric (signal arena), this parity: [w * cpr]
-  int* counters;         // local [w * cpr + 4]; counters[w*cpr] is the ticket. zeroed before launch
+  int* counters;         // local [w * cpr + 4]; [w*cpr] is the ticket, [w*cpr + 1] counts finished workgroups.
+                         // Zero at launch; the last workgroup of every launch re-arms them (call_state.hpp).
   int* err;
   uint16_t* out;         // [M_per_rank, N]
   long long lda, ldb, ldo;
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_rs_kernel(GemmRsParams p) {
       }
     }
   }
-  if (p.state) call_end(p.state, call);
+  call_end(p.state, call, ticket + 1, p.counters, w * cpr + 1);
 }
 
 TDIST_API int tdist_gemm_rs(const tdist::SymmCtx* ctx, const void* A, const void* B, void* scatter, int* flags,
@@ -271,8 +275,14 @@ TDIST_API int tdist_gemm_rs(const tdist::SymmCtx* ctx, const void* A, const void
                                       LDS_BYTES + 16));
     attr_set = true;
   }
-  TDIST_HIP_TRY(hipMemsetAsync(counters, 0, counter_bytes, (hipStream_t)stream));
   int grid = num_ctas > 0 ? num_ctas : 256;
+  static const bool trace = getenv("TDIST_TRACE_LAUNCH") != nullptr;
+  if (trace)
+    fprintf(stderr,
+            "[tdist] gemm_rs rank %d/%d A=%p B=%p scatter0=%p scatter1=%p flags0=%p flags1=%p counters=%p(%zu B) "
+            "err=%p out=%p state=%p Mr=%d N=%d K=%d rpc=%d grid=%d\n",
+            ctx->rank, w, A, B, scatter, scatter1, (void*)flags, (void*)flags1, (void*)counters, counter_bytes,
+            (void*)err, out, (void*)state, M_per_rank, N, K, rows_per_chunk, grid);
   if (dtype == 0)
     hipLaunchKernelGGL(gemm_rs_kernel<true>, dim3(grid), dim3(THREADS), LDS_BYTES + 16, (hipStream_t)stream, p);
   else

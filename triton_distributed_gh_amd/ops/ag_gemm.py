@@ -67,6 +67,11 @@ class AllGatherGEMMTensorParallelContext:
     # in-kernel producer only: [call number, finished workgroups] int32, owned by the kernels (the
     # call number selects parity and epoch on the device, so the launch can be replayed from a graph)
     state: Optional[torch.Tensor] = None
+    # Buffers a captured HIP graph may still point at: once a call ran under stream capture the
+    # context refuses to grow scratch / partial (a replay would write into freed memory); buffers that
+    # were outgrown before that are parked here instead of being freed while launches may be queued.
+    captured: bool = False
+    retired: List[torch.Tensor] = dataclasses.field(default_factory=list)
 
     # names the reference exposes on its context
     @property
@@ -102,7 +107,9 @@ def create_ag_gemm_intra_node_context(max_M, N, K, input_dtype, output_dtype, ra
     epoch_table = scratch = state = None
     if env.backend == "hip":
         epoch_table = torch.arange(EPOCH_MOD + 2, dtype=torch.int32, device=env.device)
-        scratch = torch.zeros(8 + max_chunks, dtype=torch.int32, device=env.device)
+        # sized once for the largest call this context admits (every split-K arrival counter of max_M x N):
+        # a later, larger shape must never re-allocate what an earlier captured launch still uses
+        scratch = torch.zeros(_scratch_ints(max_M, num_ranks, N, max_chunks), dtype=torch.int32, device=env.device)
         state = torch.zeros(4, dtype=torch.int32, device=env.device)
         if ag_streams is None and num_ranks > 1 and getattr(env, "side_stream", None) is not None:
             ag_streams = [env.side_stream]
@@ -183,7 +190,7 @@ def ag_gemm_intra_node_op(a, b, c, ctx: AllGatherGEMMTensorParallelContext):
     device_calls = ctx.backend == "hip" and ctx.producer == "kernel" and ctx.state is not None
     # Capture is accepted for the configuration covered by the replay tests: whole 256-row tiles per
     # rank.  (Shapes whose tiles straddle ranks run the same kernels eagerly.)
-    if not device_calls or M_per_rank % _BM != 0:
+    if not device_calls or (M_per_rank % _BM != 0 and os.environ.get("TDIST_ALLOW_STRADDLE_CAPTURE") != "1"):
         forbid_graph_capture("ag_gemm", w)
     parity = ctx.call_count & 1
     epoch = ctx.call_count % EPOCH_MOD + 1
@@ -224,16 +231,25 @@ def ag_gemm_intra_node_op(a, b, c, ctx: AllGatherGEMMTensorParallelContext):
     split_k = _pick_split_k(tiles, K, ctx.num_ctas or 256)
     cpr = M_per_rank // rpc
     need = (8 + cpr + (tiles if split_k > 1 else 0) + 3) & ~3
+    capturing = torch.cuda.is_current_stream_capturing()
     if ctx.scratch.numel() < need:
-        assert not torch.cuda.is_current_stream_capturing(), "ag_gemm: run this shape once before capturing it"
+        # (only reachable when N_local exceeds the context's N: contexts size scratch for max_M x N)
+        _may_grow(ctx, capturing, "scratch")
+        torch.cuda.synchronize()                 # the old words are live until queued launches have re-armed them
+        ctx.retired.append(ctx.scratch)
         ctx.scratch = torch.zeros(need, dtype=torch.int32, device=env.device)
     partial, partial_bytes = None, 0
     if split_k > 1:
         partial_bytes = tiles * split_k * _BM * _BM * 4
         if ctx.partial is None or ctx.partial.numel() < partial_bytes:
-            assert not torch.cuda.is_current_stream_capturing(), "ag_gemm: run this shape once before capturing it"
-            ctx.partial = torch.empty(partial_bytes, dtype=torch.uint8, device=env.device)
+            _may_grow(ctx, capturing, "split-K partial buffer")
+            if ctx.partial is not None:
+                ctx.retired.append(ctx.partial)
+            # one allocation for the worst case of this grid: split-K only runs while tiles * split_k <= grid
+            ctx.partial = torch.empty(max(partial_bytes, (ctx.num_ctas or 256) * _BM * _BM * 4), dtype=torch.uint8,
+                                      device=env.device)
         partial = ctx.partial
+    ctx.captured = ctx.captured or capturing
     _lib.check(
         lib.tdist_ag_gemm_consumer(ctypes.byref(env.heap.ctx_struct()), _lib.ptr(a), _lib.ptr(ws), _lib.ptr(b),
                                    _lib.ptr(c), _lib.ptr(fl), _lib.ptr(ctx.scratch),
@@ -252,6 +268,19 @@ def ag_gemm_intra_node_op(a, b, c, ctx: AllGatherGEMMTensorParallelContext):
     for s in used:
         cur.wait_stream(s)
     return c
+
+
+def _scratch_ints(max_M: int, w: int, N_local: int, max_chunks: int) -> int:
+    """[0] error word, [1] finished workgroups, [4] ticket, [8:] push counters + split-K arrival counters."""
+    max_tiles = (-(-max_M // _BM) + w) * -(-N_local // _BM)
+    return (8 + max_chunks + max_tiles + 3) & ~3
+
+
+def _may_grow(ctx, capturing: bool, what: str) -> None:
+    if capturing or ctx.captured:
+        raise RuntimeError(f"ag_gemm: this call needs a larger {what} than the context holds, but launches of this "
+                           "context were captured into a HIP graph that still points at the old one; create the "
+                           "context with the largest shape (max_M, N) or run the largest shape once before capturing")
 
 
 def _num_tiles(M_per_rank: int, w: int, N_local: int, straddle: bool) -> int:

@@ -31,6 +31,10 @@ def add_common_args(ap: argparse.ArgumentParser) -> argparse.ArgumentParser:
     return ap
 
 
+MAX_HW_QUEUES = 32                                   # upper bound this library ever asks HIP for
+MAX_VIRTUAL_RANKS = (MAX_HW_QUEUES - 4) // 2          # 14
+
+
 class Runner:
 
     def __init__(self, args):
@@ -41,8 +45,12 @@ class Runner:
             # Every virtual rank's two streams need hardware queues of their own: kernels that
             # share a queue start in order with limited overlap, so a rank spinning on a peer
             # queued behind it in the same hardware queue would wait for its spin budget.
-            # A smaller value in the environment (some machines export HIP's default of 4) is raised.
-            need = max(8, 2 * args.virtual_ranks + 4)
+            # A smaller value in the environment (some machines export HIP's default of 4) is raised,
+            # never past MAX_HW_QUEUES: more ranks than that allows are refused instead.
+            if args.virtual_ranks > MAX_VIRTUAL_RANKS:
+                raise SystemExit(f"--virtual-ranks {args.virtual_ranks}: at most {MAX_VIRTUAL_RANKS} virtual ranks fit "
+                                 f"{MAX_HW_QUEUES} hardware queues (two streams per rank plus four for the harness)")
+            need = min(MAX_HW_QUEUES, max(8, 2 * args.virtual_ranks + 4))
             if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < need:
                 os.environ["GPU_MAX_HW_QUEUES"] = str(need)
             self.vc = VirtualCluster(args.virtual_ranks, heap_bytes=args.heap_mb << 20)

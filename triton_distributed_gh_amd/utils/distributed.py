@@ -42,6 +42,9 @@ class DistEnv:
     shared_gpu: bool = False         # several ranks on one device
     has_rccl: bool = False
     side_stream: Optional[object] = None   # virtual ranks: the one side stream that owns a hardware queue
+    heap_mode: str = "coarse"        # memory mode of the data arena: coarse | fine | uncached | host
+    selftest: Optional[object] = None      # utils.selftest.ProbeResult of the mode in use (None: not run)
+    selftest_log: tuple = ()               # (mode name, description) of every mode that was probed
 
     @property
     def num_ranks(self) -> int:
@@ -109,11 +112,48 @@ def initialize_distributed(seed: Optional[int] = None, heap_bytes: Optional[int]
         dist.barrier(group=cpu_group)
 
     init_seed((seed if seed is not None else 0) + rank)
-    heap = SymmetricHeap(rank, world_size, cpu_group, "hip" if use_gpu else "host", heap_bytes, sig_bytes)
+    if use_gpu:
+        heap, heap_mode, probe, log = _create_checked_heap(rank, world_size, cpu_group, heap_bytes, sig_bytes)
+    else:
+        heap = SymmetricHeap(rank, world_size, cpu_group, "host", heap_bytes, sig_bytes)
+        heap_mode, probe, log = "host", None, ()
     _ENV = DistEnv(rank, local_rank, world_size, local_world_size, device, "hip" if use_gpu else "host",
-                   tp_group, cpu_group, heap, shared_gpu, has_rccl)
+                   tp_group, cpu_group, heap, shared_gpu, has_rccl, heap_mode=heap_mode, selftest=probe,
+                   selftest_log=log)
     atexit.register(finalize_distributed)
     return _ENV
+
+
+def _create_checked_heap(rank: int, world_size: int, cpu_group, heap_bytes, sig_bytes):
+    """Create the GPU symmetric heap and prove, before any op uses it, that payloads written by a peer are
+    read correctly through this GPU's caches (utils/selftest.py).  Modes are tried in the order
+    coarse-grained -> fine-grained -> uncached; the first one that passes on EVERY rank is kept.
+
+    Environment: ``TDIST_HEAP_ALLOC_MODE=m`` pins the mode (still probed; a failure raises),
+    ``TDIST_SELFTEST=0`` skips the probe, ``TDIST_SELFTEST_ROUNDS`` sets its length and
+    ``TDIST_SELFTEST_FAIL_MODES=0,1`` treats the listed modes as failed (exercises the fall-back)."""
+    from .selftest import HEAP_MODE_NAMES, coherence_probe, probe_rounds
+
+    pinned = os.environ.get("TDIST_HEAP_ALLOC_MODE")
+    modes = [int(pinned)] if pinned is not None else [0, 1, 2]
+    run_probe = world_size > 1 and os.environ.get("TDIST_SELFTEST", "1") != "0"
+    forced_bad = {int(x) for x in os.environ.get("TDIST_SELFTEST_FAIL_MODES", "").split(",") if x.strip()}
+    log = []
+    for mode in modes:
+        heap = SymmetricHeap(rank, world_size, cpu_group, "hip", heap_bytes, sig_bytes, data_mode=mode)
+        if not run_probe:
+            return heap, HEAP_MODE_NAMES[mode], None, ()
+        res = coherence_probe(heap, cpu_group, rounds=probe_rounds())
+        if mode in forced_bad:
+            res.ok = False
+        log.append((HEAP_MODE_NAMES[mode], ("ok " if res.ok else "FAILED ") + res.describe()))
+        if res.ok:
+            return heap, HEAP_MODE_NAMES[mode], res, tuple(log)
+        if rank == 0:
+            print(f"[tdist] symmetric heap self-test FAILED in mode {HEAP_MODE_NAMES[mode]}: {res.describe()}",
+                  flush=True)
+        heap.close(sync_group=cpu_group)
+    raise RuntimeError("symmetric heap self-test failed in every memory mode: " + "; ".join(f"{m}: {d}" for m, d in log))
 
 
 def create_virtual_node(world_size: int, heap_bytes: int = 1 << 28, sig_bytes: int = 1 << 22,
@@ -122,7 +162,8 @@ def create_virtual_node(world_size: int, heap_bytes: int = 1 << 28, sig_bytes: i
     group).  Every rank's symmetric arena is an ordinary allocation of this process, so fused
     multi-rank kernels can be exercised on one GPU by launching each rank's op on its own stream.
     Hardware queues: a rank that spins on a peer must not share a queue with it, so run with
-    GPU_MAX_HW_QUEUES >= 2 * world_size (set before HIP initialises)."""
+    GPU_MAX_HW_QUEUES = min(32, 2 * world_size + 4), set before HIP initialises (at most 14 virtual
+    ranks: utils/cli.py refuses more)."""
     backend = backend or ("hip" if torch.cuda.is_available() else "host")
     device = torch.device("cuda", torch.cuda.current_device()) if backend == "hip" else torch.device("cpu")
     heaps = SymmetricHeap.create_virtual(world_size, backend, heap_bytes, sig_bytes)

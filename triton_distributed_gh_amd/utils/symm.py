@@ -137,9 +137,13 @@ class SymmetricHeap:
         backend: str,
         heap_bytes: Optional[int] = None,
         sig_bytes: Optional[int] = None,
+        data_mode: Optional[int] = None,
     ):
         assert world_size <= MAX_RANKS, f"at most {MAX_RANKS} ranks per node"
         self.rank, self.world_size, self.group, self.backend = rank, world_size, group, backend
+        # memory mode of the data arena and its growth segments: 0 = coarse-grained hipMalloc,
+        # 1 = fine-grained, 2 = uncached (csrc/runtime/runtime_hip.cc: tdist_malloc)
+        self.data_mode = int(os.environ.get("TDIST_HEAP_ALLOC_MODE", "0")) if data_mode is None else int(data_mode)
         default_heap = MAX_IPC_BYTES if backend == "hip" else (1 << 26)
         self.heap_bytes = int(heap_bytes or os.environ.get("TDIST_SYMM_HEAP_BYTES", default_heap))
         # total capacity the arena may grow to (segments are added on demand)
@@ -202,6 +206,7 @@ class SymmetricHeap:
             h._owned = [bases[a][r] for a in bases] if backend == "hip" else []
             h._opened, h._shm_names, h._closed, h._tensor_info = [], [], False, {}
             h._virtual = True
+            h.data_mode = 0
             heaps.append(h)
         return heaps
 
@@ -217,14 +222,14 @@ class SymmetricHeap:
         lib = _lib.hip()
         hsz = lib.tdist_ipc_handle_size()
         sig_mode = int(os.environ.get("TDIST_SIG_ALLOC_MODE", "1"))  # 1 = fine-grained
-        data_mode = int(os.environ.get("TDIST_HEAP_ALLOC_MODE", "0"))  # 0 = hipMalloc
+        data_mode = self.data_mode
         handles = {}
         for arena, nbytes, mode in (("data", self.heap_bytes, data_mode), ("sig", self.sig_bytes, sig_mode)):
             p = ctypes.c_void_p()
             rc = lib.tdist_malloc(ctypes.byref(p), ctypes.c_size_t(nbytes), mode)
-            if rc != 0 and mode != 0:
+            if rc != 0 and mode != 0 and arena == "sig":
                 rc = lib.tdist_malloc(ctypes.byref(p), ctypes.c_size_t(nbytes), 0)
-            _lib.check(rc, f"symmetric {arena} arena allocation ({nbytes} bytes)")
+            _lib.check(rc, f"symmetric {arena} arena allocation ({nbytes} bytes, mode {mode})")
             _lib.check(lib.tdist_memset(p, 0, ctypes.c_size_t(nbytes)), "arena memset")
             self._owned.append(p.value)
             self._bases[arena][self.rank] = p.value
@@ -325,8 +330,8 @@ class SymmetricHeap:
         elif self.backend == "hip":
             lib = _lib.hip()
             p = ctypes.c_void_p()
-            _lib.check(lib.tdist_malloc(ctypes.byref(p), ctypes.c_size_t(nbytes),
-                                        int(os.environ.get("TDIST_HEAP_ALLOC_MODE", "0"))), f"symmetric {name} segment")
+            _lib.check(lib.tdist_malloc(ctypes.byref(p), ctypes.c_size_t(nbytes), self.data_mode),
+                       f"symmetric {name} segment")
             _lib.check(lib.tdist_memset(p, 0, ctypes.c_size_t(nbytes)), "segment memset")
             self._owned.append(p.value)
             bases[self.rank] = p.value
@@ -447,7 +452,10 @@ class SymmetricHeap:
         return self._bases[arena][r]
 
     # ------------------------------------------------------------------ teardown
-    def close(self) -> None:
+    def close(self, sync_group=None) -> None:
+        """Unmap the peers' arenas and free this rank's.  ``sync_group``: process group to barrier on
+        between the two steps, for a collective close while every rank is alive (nobody frees an arena
+        a peer still has mapped)."""
         if self._closed:
             return
         self._closed = True
@@ -460,6 +468,8 @@ class SymmetricHeap:
                 lib.tdist_device_sync()
                 for p in getattr(self, "_opened", []):
                     lib.tdist_ipc_close_handle(ctypes.c_void_p(p))
+                if sync_group is not None:
+                    dist.barrier(group=sync_group)
                 for p in self._owned:
                     lib.tdist_free(ctypes.c_void_p(p))
             except Exception:
