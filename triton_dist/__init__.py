@@ -79,6 +79,7 @@ ALIASES = {
     "models.engine": ["models.engine"],
     "tools": ["tools"],
     "tools.compile_aot": ["tools.compile_aot"],
+    "tools.runtime": ["tools.runtime"],
     "mega_triton_kernel": ["mega"],
     "mega_triton_kernel.core": ["mega.core"],
     "mega_triton_kernel.core.task_base": ["mega.core"],

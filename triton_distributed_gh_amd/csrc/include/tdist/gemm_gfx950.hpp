@@ -289,7 +289,22 @@ __device__ __forceinline__ void mainloop_256(const TileArgs& t, char* smem, Acc<
 // but its vmcnt waits removed, or its sources pinned to K-step 0 (cache hits), it stays within 3 % of
 // the full kernel - the cost is the issue of the eight LDS-DMA pieces per wave and K-step itself,
 // not HBM latency or bandwidth.
-template <bool IS_BF16, bool PERM_B = false, int OPT = 0>
+//
+// DS (how the eight LDS-DMA pieces a wave issues per K-step are split over the two read segments;
+// the read segment of phase 0 carries 16 fragment reads, that of phase 1 only 8):
+//   0 = 4 + 4: phase 0 of step t stages A0, A1 of step t+1, phase 1 stages B0, B1 of step t+2;
+//   1 = 2 + 6: phase 0 stages A0 of step t+1, phase 1 stages A1 of step t+1 and B0, B1 of step t+2.  A1(t+1) is
+//       then waited for in phase 0 of step t+1 (counted vmcnt before that phase's first barrier) instead of in
+//       phase 1 of step t; its slot (other ring buffer) was last read in phase 1 of step t-1.
+//   3 = 2 + 6, everything one whole K-step ahead: phase 0 of step t stages A1 of step t+1 (its slot was read in
+//       phase 1 of step t-1 ... no: see below), phase 1 stages A0, B0, B1 of step t+2.  Precisely: phase 1 of step t
+//       refills the slots phase 0 of step t has just read (A0, B0, B1 of ring buffer t&1) with step t+2, and phase
+//       0 of step t+1 refills the slot phase 1 of step t has read (A1 of buffer t&1) with step t+2.  Every piece is
+//       in flight for a full K-step (two MFMA segments) before the counted wait that retires it, against one MFMA
+//       segment for the A pieces of DS 0.  Phase 0 then retires ALL its fragment reads before its first barrier
+//       (the other wave group restages the A0 slot right after that barrier).
+// OPT bit 4: issue a segment's LDS-DMA pieces before its fragment reads instead of after them.
+template <bool IS_BF16, bool PERM_B = false, int OPT = 0, int DS = 0>
 __device__ __forceinline__ void mainloop_256_2ph(const TileArgs& t, char* smem, Acc<IS_BF16>& acc) {
   using F = Frag<IS_BF16>;
   using V = typename F::T;
@@ -348,13 +363,18 @@ __device__ __forceinline__ void mainloop_256_2ph(const TileArgs& t, char* smem, 
     for (int j = 0; j < 4; ++j) acc.v[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   stage(0, K0{}); stage(0, K1{}); stage(0, K2{}); stage(0, K3{});
-  stage(1, K0{}); stage(1, K2{});
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if constexpr (DS == 3) {
+    stage(1, K1{}); stage(1, K0{}); stage(1, K2{});
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    stage(1, K0{}); stage(1, K2{});
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
   if (late_group) __builtin_amdgcn_s_barrier();
 
   V a[4][2], b0[2][2], b1[2][2];
-  constexpr bool PROG = (OPT & 1) != 0, NOPRIO = (OPT & 2) != 0;
+  constexpr bool PROG = (OPT & 1) != 0, NOPRIO = (OPT & 2) != 0, DMA_FIRST = (OPT & 4) != 0;
   // MFMAs of one 16-row block m of the current 64-row half (both k halves, all four column tiles)
   auto mfma_row = [&](int m, int mo) {
 #pragma unroll
@@ -368,6 +388,11 @@ __device__ __forceinline__ void mainloop_256_2ph(const TileArgs& t, char* smem, 
   for (int kt = 0; kt < nt; ++kt) {
     const int boff = (kt & 1) * BUF_BYTES;
     // ---------------- phase 0: rows 0..63 of the wave tile ----------------
+    if constexpr (DMA_FIRST) {
+      stage(kt + 1, K1{});
+      if constexpr (DS == 0) stage(kt + 1, K3{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -381,10 +406,34 @@ __device__ __forceinline__ void mainloop_256_2ph(const TileArgs& t, char* smem, 
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) a[m][ks] = *(const V*)(a_rd + boff + OFF_A0 + (m * 2 + ks) * 1024);
-    stage(kt + 1, K1{});
-    stage(kt + 1, K3{});
+    if constexpr (DS == 3) {
+      // A1 of step kt+1 into the slot phase 1 of step kt-1 read; then retire A1 of THIS step (younger: A0, B0,
+      // B1 of step kt+1 and the piece just issued = 8 pieces, if step kt+1 exists)
+      stage(kt + 1, K3{});
+      if (kt + 1 < nt) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    } else if constexpr (!DMA_FIRST) {
+      stage(kt + 1, K1{});
+      if constexpr (DS == 0) stage(kt + 1, K3{});
+    }
+    if constexpr (DS == 1) {
+      // A1 of THIS step (issued in phase 1 of the previous step, or in the prologue) must have landed
+      // before the first barrier of this phase; younger: B0, B1, A0 of step kt+1 (6 pieces), if they exist
+      if (kt + 1 < nt) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    if constexpr (DS == 3) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     if constexpr (!PROG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -417,16 +466,45 @@ __device__ __forceinline__ void mainloop_256_2ph(const TileArgs& t, char* smem, 
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     // ---------------- phase 1: rows 64..127 of the wave tile ----------------
+    if constexpr (DMA_FIRST) {
+      if constexpr (DS == 1) stage(kt + 1, K3{});
+      stage(kt + 2, K0{});
+      stage(kt + 2, K2{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) a[m][ks] = *(const V*)(a_rd + boff + OFF_A1 + (m * 2 + ks) * 1024);
-    stage(kt + 2, K0{});
-    stage(kt + 2, K2{});
-    if (kt + 2 < nt) {
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if constexpr (DS == 3) {
+      stage(kt + 2, K1{});
+      stage(kt + 2, K0{});
+      stage(kt + 2, K2{});
+    } else if constexpr (!DMA_FIRST) {
+      if constexpr (DS == 1) stage(kt + 1, K3{});
+      stage(kt + 2, K0{});
+      stage(kt + 2, K2{});
+    }
+    // retire what phase 0 of the next step reads (A0, B0, B1 of step kt+1): everything but the younger pieces -
+    // DS 0: B0, B1 of step kt+2; DS 1: those and A1 of step kt+1; DS 3: A1 of step kt+1 and A0, B0, B1 of step kt+2
+    if constexpr (DS == 3) {
+      if (kt + 2 < nt) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else if (kt + 1 < nt) {
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      }
+    } else if (kt + 2 < nt) {
+      if constexpr (DS == 1) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      }
     } else if (kt + 1 < nt) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (DS == 1) {
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     }
     // (always complete here: the other wave group restages this buffer's A1 slot one barrier later)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -548,7 +626,7 @@ struct Acc4 {
   f32x4 v[8][8];
 };
 
-template <bool IS_BF16>
+template <bool IS_BF16, bool SPREAD = false>
 __device__ __forceinline__ void mainloop_256_4w(const TileArgs& t, char* smem, Acc4<IS_BF16>& acc) {
   using F = Frag<IS_BF16>;
   using V = typename F::T;
@@ -629,6 +707,38 @@ __device__ __forceinline__ void mainloop_256_4w(const TileArgs& t, char* smem, A
     __builtin_amdgcn_s_barrier();
     const int nb = ((s + 1) & 3) * W4_SLAB;
     const bool restage = STEADY || s + 4 < ns;
+    if constexpr (SPREAD) {
+      // One memory instruction behind every second (reads) or fourth (LDS-DMA pieces) MFMA instead of
+      // groups of four behind every eight: a 16x16x32 MFMA occupies the matrix pipe for 16 cycles but
+      // the wave's issue port for 8, so a single filler per gap issues for free while a group of
+      // them lets the pipe run dry.  Reads come B first (all eight are needed by row 0), then A in row order.
+#pragma unroll
+      for (int i = 0; i < 64; ++i) {
+        const int m = i >> 3, n = i & 7;
+        F::mfma_acc(fb[P][n], fa[P][m], acc.v[m][n]);
+        if (i < 32 && (i & 1) == 0) {
+          const int j = i >> 1;
+          if (more) {
+            if (j < 8)
+              fb[P ^ 1][j] = *(const V*)(b_rd + nb + j * 1024);
+            else
+              fa[P ^ 1][j - 8] = *(const V*)(a_rd + nb + (j - 8) * 1024);
+          }
+        } else if (i >= 32 && (i & 3) == 0 && restage) {
+          switch ((i - 32) >> 2) {
+            case 0: stage_piece(s + 4, std::integral_constant<int, 0>{}); break;
+            case 1: stage_piece(s + 4, std::integral_constant<int, 1>{}); break;
+            case 2: stage_piece(s + 4, std::integral_constant<int, 2>{}); break;
+            case 3: stage_piece(s + 4, std::integral_constant<int, 3>{}); break;
+            case 4: stage_piece(s + 4, std::integral_constant<int, 4>{}); break;
+            case 5: stage_piece(s + 4, std::integral_constant<int, 5>{}); break;
+            case 6: stage_piece(s + 4, std::integral_constant<int, 6>{}); break;
+            default: stage_piece(s + 4, std::integral_constant<int, 7>{}); break;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       // row m of the wave tile first, then this row's share of the memory work: the compiler

@@ -39,6 +39,18 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_256_kernel(const uint16_t*
   Acc<IS_BF16> acc;
   if constexpr (VARIANT == 2)
     mainloop_256_2ph<IS_BF16>(t, smem, acc);
+  else if constexpr (VARIANT == 5)
+    mainloop_256_2ph<IS_BF16, false, 0, 1>(t, smem, acc);
+  else if constexpr (VARIANT == 6)
+    mainloop_256_2ph<IS_BF16, false, 4, 1>(t, smem, acc);
+  else if constexpr (VARIANT == 7)
+    mainloop_256_2ph<IS_BF16, false, 4, 0>(t, smem, acc);
+  else if constexpr (VARIANT == 8)
+    mainloop_256_2ph<IS_BF16, false, 3, 1>(t, smem, acc);
+  else if constexpr (VARIANT == 9)
+    mainloop_256_2ph<IS_BF16, false, 0, 3>(t, smem, acc);
+  else if constexpr (VARIANT == 10)
+    mainloop_256_2ph<IS_BF16, false, 2, 3>(t, smem, acc);
   else
     mainloop_256<IS_BF16>(t, smem, acc);
   const int mrem = M - row0, nrem = N - col0;
@@ -88,7 +100,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_256_persistent_kernel(cons
 }
 
 // Four-wave persistent form (variant 4): see mainloop_256_4w.
-template <bool IS_BF16>
+template <bool IS_BF16, bool SPREAD>
 __global__ __launch_bounds__(W4_THREADS) void gemm_nt_256_4w_kernel(const uint16_t* __restrict__ A,
                                                                     const uint16_t* __restrict__ B,
                                                                     uint16_t* __restrict__ C, int M, int N, int K,
@@ -112,7 +124,7 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_nt_256_4w_kernel(const uint16
     t.b_rows = N - col0;
     t.K = K;
     Acc4<IS_BF16> acc;
-    mainloop_256_4w<IS_BF16>(t, smem, acc);
+    mainloop_256_4w<IS_BF16, SPREAD>(t, smem, acc);
     const int mrem = M - row0, nrem = N - col0;
     uint16_t* cbase = C + (long long)row0 * ldc + col0;
     epilogue_256_4w_direct<IS_BF16>(acc, [&](int r, int c, const uint4& v) {
@@ -299,35 +311,50 @@ TDIST_API int tdist_gemm_nt(const void* A, const void* B, void* C, int M, int N,
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   if (group_m <= 0) group_m = 8;
   typedef void (*kern_t)(const uint16_t*, const uint16_t*, uint16_t*, int, int, int, long long, long long, long long, int, int);
-  kern_t table[2][2] = {{gemm_nt_256_kernel<true, 1>, gemm_nt_256_kernel<true, 2>},
-                        {gemm_nt_256_kernel<false, 1>, gemm_nt_256_kernel<false, 2>}};
+  // columns: schedule variants 1 (four phases), 2 (two phases), 5..8 (two phases, staging / issue-order knobs;
+  // bf16 only - see mainloop_256_2ph)
+  kern_t table[2][8] = {{gemm_nt_256_kernel<true, 1>, gemm_nt_256_kernel<true, 2>, gemm_nt_256_kernel<true, 5>,
+                         gemm_nt_256_kernel<true, 6>, gemm_nt_256_kernel<true, 7>, gemm_nt_256_kernel<true, 8>,
+                         gemm_nt_256_kernel<true, 9>, gemm_nt_256_kernel<true, 10>},
+                        {gemm_nt_256_kernel<false, 1>, gemm_nt_256_kernel<false, 2>, gemm_nt_256_kernel<false, 2>,
+                         gemm_nt_256_kernel<false, 2>, gemm_nt_256_kernel<false, 2>, gemm_nt_256_kernel<false, 2>,
+                         gemm_nt_256_kernel<false, 2>, gemm_nt_256_kernel<false, 2>}};
   static bool attr_set = false;
   if (!attr_set) {
     for (int i = 0; i < 2; ++i)
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 8; ++j)
         TDIST_HIP_TRY(hipFuncSetAttribute((const void*)table[i][j], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set = true;
   }
-  if ((variant & 255) == 4) {
+  if ((variant & 255) == 4 || (variant & 255) == 11) {
+    const bool spread = (variant & 255) == 11;
     static int num_cus4 = 0;
     if (!num_cus4) {
       int dev = 0;
       TDIST_HIP_TRY(hipGetDevice(&dev));
       TDIST_HIP_TRY(hipDeviceGetAttribute(&num_cus4, hipDeviceAttributeMultiprocessorCount, dev));
-      TDIST_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_256_4w_kernel<true>,
+      TDIST_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_256_4w_kernel<true, false>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES));
-      TDIST_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_256_4w_kernel<false>,
+      TDIST_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_256_4w_kernel<true, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES));
+      TDIST_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_256_4w_kernel<false, false>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES));
     }
     int grid = num_cus4 & ~7;
     if (grid < 8) grid = 8;
     if (tiles < grid) grid = tiles;
-    if (dtype == 0)
-      hipLaunchKernelGGL(gemm_nt_256_4w_kernel<true>, dim3(grid), dim3(W4_THREADS), W4_LDS_BYTES, (hipStream_t)stream,
-                         (const uint16_t*)A, (const uint16_t*)B, (uint16_t*)C, M, N, K, lda, ldb, ldc, group_m);
+    if (dtype == 0 && spread)
+      hipLaunchKernelGGL((gemm_nt_256_4w_kernel<true, true>), dim3(grid), dim3(W4_THREADS), W4_LDS_BYTES,
+                         (hipStream_t)stream, (const uint16_t*)A, (const uint16_t*)B, (uint16_t*)C, M, N, K, lda, ldb,
+                         ldc, group_m);
+    else if (dtype == 0)
+      hipLaunchKernelGGL((gemm_nt_256_4w_kernel<true, false>), dim3(grid), dim3(W4_THREADS), W4_LDS_BYTES,
+                         (hipStream_t)stream, (const uint16_t*)A, (const uint16_t*)B, (uint16_t*)C, M, N, K, lda, ldb,
+                         ldc, group_m);
     else
-      hipLaunchKernelGGL(gemm_nt_256_4w_kernel<false>, dim3(grid), dim3(W4_THREADS), W4_LDS_BYTES, (hipStream_t)stream,
-                         (const uint16_t*)A, (const uint16_t*)B, (uint16_t*)C, M, N, K, lda, ldb, ldc, group_m);
+      hipLaunchKernelGGL((gemm_nt_256_4w_kernel<false, false>), dim3(grid), dim3(W4_THREADS), W4_LDS_BYTES,
+                         (hipStream_t)stream, (const uint16_t*)A, (const uint16_t*)B, (uint16_t*)C, M, N, K, lda, ldb,
+                         ldc, group_m);
     TDIST_HIP_TRY(hipGetLastError());
     return 0;
   }
@@ -357,7 +384,8 @@ TDIST_API int tdist_gemm_nt(const void* A, const void* B, void* C, int M, int N,
     TDIST_HIP_TRY(hipGetLastError());
     return 0;
   }
-  kern_t k = table[dtype == 0 ? 0 : 1][(variant & 255) == 2 ? 1 : 0];
+  const int v = variant & 255;
+  kern_t k = table[dtype == 0 ? 0 : 1][v == 2 ? 1 : (v >= 5 && v <= 10 ? v - 3 : 0)];
   hipLaunchKernelGGL(k, dim3(tiles), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, (const uint16_t*)A,
                      (const uint16_t*)B, (uint16_t*)C, M, N, K, lda, ldb, ldc, group_m, variant >> 8);
   TDIST_HIP_TRY(hipGetLastError());

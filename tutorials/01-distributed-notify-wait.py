@@ -19,9 +19,12 @@ In device code they are HIP functions (csrc/include/tdist/primitives.hpp):
     read queue + slot * elems;  __syncthreads();
     if (threadIdx.x == 0) notify(ctx, signal + slot, rank, 2 * r + 2, ...);           // hand it back
 
-Part 1 runs exactly that kernel (csrc/ops/primitives_test.hip: ring_queue_kernel).  Part 2 replays
-the same protocol from the HOST with triton_dist.language (stream-ordered on a GPU, immediate on the
-CPU backend) - handy for prototyping a protocol before writing the kernel.
+Part 1 writes that kernel the way a USER of the framework does: tutorials/kernels/ring_queue_user.hip is
+a stand-alone HIP file that includes nothing but tdist/primitives.hpp; it is compiled here with hipcc
+(triton_dist.tools.compile_hip), loaded as a code object (load_module) and launched from Python with the
+symmetric heap as its SymmCtx argument.  Part 2 replays the same protocol from the HOST with
+triton_dist.language (stream-ordered on a GPU, immediate on the CPU backend) - handy for prototyping a
+protocol before writing the kernel.
 
     python tutorials/01-distributed-notify-wait.py --virtual-ranks 4
     bash scripts/launch_amd.sh tutorials/01-distributed-notify-wait.py
@@ -37,7 +40,7 @@ import torch  # noqa: E402
 from triton_distributed_gh_amd.utils.cli import Runner, add_common_args, rel_err  # noqa: E402,F401
 
 import triton_dist.language as dl  # noqa: E402
-from triton_distributed_gh_amd.ops import primitives  # noqa: E402
+from triton_dist.tools import compile_hip, load_module  # noqa: E402
 
 
 def main():
@@ -51,13 +54,19 @@ def main():
     sigs = R.collective(lambda r, env: env.heap.create_tensor([Q], torch.int32, arena="sig"))
     ins = {r: torch.arange(N * E, dtype=torch.int32, device=dev) + 1000 * r for r in R.local_ranks}
     outs = {r: torch.zeros(N * E, dtype=torch.int32, device=dev) for r in R.local_ranks}
-    if dev.type == "cuda":          # ---- part 1: the device kernel
+    if dev.type == "cuda":          # ---- part 1: the user's device kernel, built and loaded at run time
+        src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kernels", "ring_queue_user.hip")
+        kernel = load_module(compile_hip(src)).get("ring_queue_user")
+        errs = {r: torch.zeros(4, dtype=torch.int32, device=dev) for r in R.local_ranks}
         R.barrier()
-        R.run(lambda r, env: primitives.ring_queue(queues[r], sigs[r], ins[r], outs[r], (r + 1) % w, Q, E, N, 4, 2, env=env))
+        # grid = 4 producer + 2 consumer workgroups; arguments in the kernel's parameter order
+        R.run(lambda r, env: kernel(6, 256, torch.cuda.current_stream(), env.heap, queues[r], sigs[r], ins[r], outs[r],
+                                    (r + 1) % w, Q, E, N, 0, 4, 2, errs[r]))
         sent = R.all_gather(ins)
         for r in R.local_ranks:
+            assert int(errs[r][0]) == 0, "a wait timed out"
             assert torch.equal(outs[r], sent[(r - 1) % w])
-        R.print("device ring queue: every rank received its left neighbour's items")
+        R.print("user kernel ring queue: every rank received its left neighbour's items")
     # ---- part 2: the same hand-over driven from the host, one item
     for r in R.local_ranks:
         sigs[r].zero_()
