@@ -1,12 +1,16 @@
 // AllGather + GEMM, one persistent kernel per rank:  C[M, N_local] = AllGather_M(A[M/w, K]) * B[N_local, K]^T.
 //
-// Work items are handed out by a device-side ticket counter.  The first `push_wgs` tickets are
-// PRODUCER items: they store this rank's shard of A into every peer's symmetric workspace [M, K]
-// over xGMI, chunk by chunk, and raise one int32 flag per (source rank, chunk) to the call's epoch
-// value on every peer.  All later tickets are 256x256 tile jobs in expected-arrival order (own
-// rows first, then chunk 0 of every peer, chunk 1 of every peer, ...); a tile job waits -
-// workgroup-collectively, system scope, acquire - for the flags covering its rows and runs the
-// MFMA main loop.  Producer and consumer share one launch because the GEMM workgroups fill the
+// Work items are handed out by device-side ticket counters.  The first `push_wgs` tickets of the push
+// counter are PRODUCER items: they store this rank's shard of A into every peer's symmetric workspace
+// [M, K] over xGMI, chunk by chunk, and raise one int32 flag per (source rank, chunk) to the call's
+// epoch value on every peer.  Tile jobs (256x256) live in EIGHT queues, one per XCD (workgroups are dealt
+// to the XCDs round-robin by index): a queue owns a band of column tiles (and, when there are fewer than
+// eight column tiles, every qm-th row block), each in expected-arrival order (own rows first, then chunk
+// 0 of every peer, chunk 1 of every peer, ...).  The workgroups of one XCD therefore work on a compact
+// rows x columns patch whose A row blocks and B panels they share in that XCD's L2 - the mapping the plain
+// GEMM gets from its block-id remap - instead of a random eighth of everything; a workgroup whose queue
+// has run dry moves on to the next XCD's queue.  A tile job waits - workgroup-collectively, system scope,
+// acquire - for the flags covering its rows and runs the MFMA main loop.  Producer and consumer share one launch because the GEMM workgroups fill the
 // register file of every CU: a separate push kernel that reaches the GPU after the GEMM could
 // not be scheduled until GEMM workgroups exit, and those are waiting for the peers' pushes.
 // Producer items never wait and hold the lowest tickets, so progress does not depend on dispatch
@@ -33,6 +37,7 @@
 #include "tdist/common.hpp"
 #include "tdist/gemm_gfx950.hpp"
 #include "tdist/primitives.hpp"
+#include "tdist/race_debug.hpp"
 #include "tdist/shmem_device.hpp"
 
 using namespace tdist;
@@ -45,7 +50,8 @@ struct AgGemmParams {
   const uint16_t* B;         // [N_local, K]
   uint16_t* C;               // [M, N_local]
   int* flags;                // [w * chunks_per_rank] of this call's parity (symmetric, signal arena)
-  int* ticket;               // work counters: zero at launch (re-armed by the last workgroup of every launch)
+  int* ticket;               // work counters: zero at launch (re-armed by the last workgroup of every launch):
+                             // [0] push items, [4 .. 12) the eight tile queues
   int* err;                  // sticky error word (bit 0 = wait timeout)
   int* fin;                  // finished-workgroup counter of this launch
   int n_counters;            // ints from `ticket` on that the last workgroup zeroes
@@ -60,6 +66,8 @@ struct AgGemmParams {
   int straddle;              // 1: tiles walk the whole [M, K] workspace (own rows copied in too)
   int push_wgs;              // first push_wgs tickets push the local shard to every peer
   int split_k;               // K is cut into split_k ranges, one work item each
+  int qn;                    // tile queues: qn column bands x (8 / qn) row-block residues
+  int race_debug;            // tdist/race_debug.hpp
   // Device-side call numbering (tdist/call_state.hpp).  When `state` is set, ws / flags / epoch above
   // are ignored by the host and resolved on the device from the call number: the launch is then the
   // same every time and can be replayed from a HIP graph.
@@ -99,6 +107,7 @@ __device__ __forceinline__ void push_item(const AgGemmParams& p, const AgCall& c
   const int pieces_per_row = (int)(row_bytes >> 4);
   const int first_peer = p.straddle ? 0 : 1;
   for (int chunk = 0; chunk < cpr; ++chunk) {
+    race_debug_delay(p.race_debug, 2 * chunk);
     const long long src_row = (long long)chunk * p.rows_per_chunk;
     const long long dst_off = ((long long)rank * p.M_per_rank + src_row) * row_bytes + b0;
     for (int base = 0; base < n16; base += U * THREADS) {
@@ -124,6 +133,7 @@ __device__ __forceinline__ void push_item(const AgGemmParams& p, const AgCall& c
       }
     }
     drain_stores();
+    race_debug_delay(p.race_debug, 2 * chunk + 1);
     __syncthreads();
     if (threadIdx.x == 0) {
       // every slice's stores completed before its own add; the completing add is ordered after
@@ -157,8 +167,12 @@ __global__ __launch_bounds__(THREADS, 2) void ag_gemm_consumer_kernel(AgGemmPara
     total_mb = mb_per_rank * w;
   }
   const int S = p.split_k;
-  const int total = p.push_wgs + total_mb * num_pid_n * S;
   const int ksteps = p.K / BK;
+  const int qn = p.qn, qm = 8 / qn;
+  const int cols_per = (num_pid_n + qn - 1) / qn;
+  const int xcd = blockIdx.x & 7;
+  int hop = 0;
+  bool pushing = p.push_wgs > 0;
   int call = 0;
   AgCall cv{p.ws, p.flags, p.epoch};
   if (p.state) {
@@ -167,19 +181,36 @@ __global__ __launch_bounds__(THREADS, 2) void ag_gemm_consumer_kernel(AgGemmPara
     cv.flags = call_parity(call) ? p.flags1 : p.flags0;
     cv.epoch = call_epoch(call);
   }
+  race_debug_check_flags(p.race_debug, cv.flags, w * cpr, cv.epoch, p.err);
 
   while (true) {
-    int item = fetch_ticket_block(p.ticket, s_ticket);
-    if (item >= total) break;
-    if (item < p.push_wgs) {
-      push_item(p, cv, item);
-      continue;
+    if (pushing) {
+      const int item = fetch_ticket_block(p.ticket, s_ticket);
+      if (item < p.push_wgs) {
+        push_item(p, cv, item);
+        continue;
+      }
+      pushing = false;
     }
-    item -= p.push_wgs;
-    const int tile = item / S;
-    const int ks = item - tile * S;           // K range; the item with ks == S-1 owns the tile
-    const int o = tile / num_pid_n;
-    const int pid_n = tile - o * num_pid_n;
+    // next job of this XCD's queue; queues that have run dry are left behind for good
+    int local = 0, q = 0, n_cols = 0;
+    for (; hop < 8; ++hop) {
+      q = (xcd + hop) & 7;
+      const int qmi = q / qn, qni = q - qmi * qn;
+      const int n_o = total_mb > qmi ? (total_mb - qmi + qm - 1) / qm : 0;
+      n_cols = min(max(num_pid_n - qni * cols_per, 0), cols_per);
+      const int qsize = n_o * n_cols * S;
+      if (qsize == 0) continue;
+      local = fetch_ticket_block(p.ticket + 4 + q, s_ticket);
+      if (local < qsize) break;
+    }
+    if (hop == 8) break;
+    const int per_o = n_cols * S;
+    const int o_idx = local / per_o, rem = local - o_idx * per_o;
+    const int o = o_idx * qm + q / qn;
+    const int pid_n = (q % qn) * cols_per + rem / S;
+    const int ks = rem % S;                   // K range
+    const int tile = o * num_pid_n + pid_n;
 
     // ---- which rows does this tile cover -----------------------------------------------
     int g0, rows;          // first global row, valid rows (<= 256)
@@ -365,8 +396,9 @@ static int check_common(const void* B, const void* C, int N_local, int K, long l
 }
 
 // scratch layout (int32): [0] error word (sticky, never cleared here), [1] finished-workgroup counter,
-// [4] ticket, [8, 8 + cpr) push counters, [8 + cpr, 8 + cpr + tiles) split-K arrival counters.  Everything
-// from [1] on must be zero at the first launch; every launch leaves it zero again (call_state.hpp).
+// [4] push ticket, [8, 16) tile-queue tickets, [16, 16 + cpr) push counters, [16 + cpr, 16 + cpr + tiles)
+// split-K arrival counters.  Everything from [1] on must be zero at the first launch; every launch leaves
+// it zero again (call_state.hpp).
 // `state` != nullptr: device-side call numbering; ws / flags are then parity 0 and ws1 / flags1 parity 1,
 // and `epoch` is ignored.
 TDIST_API int tdist_ag_gemm_consumer(const tdist::SymmCtx* ctx, const void* a_local, void* ws, const void* B, void* C,
@@ -390,7 +422,7 @@ TDIST_API int tdist_ag_gemm_consumer(const tdist::SymmCtx* ctx, const void* a_lo
   const int cpr = M_per_rank / rows_per_chunk;
   const int total_mb = straddle ? (M + BM - 1) / BM : ((M_per_rank + BM - 1) / BM) * world;
   const int tiles = total_mb * ((N_local + BN - 1) / BN);
-  const long long need_ints = 8 + cpr + (split_k > 1 ? tiles : 0);
+  const long long need_ints = 16 + cpr + (split_k > 1 ? tiles : 0);
   TDIST_REQUIRE(scratch_ints >= ((need_ints + 3) & ~3ll), "scratch too small");
   TDIST_REQUIRE(split_k == 1 || (partial && partial_bytes >= (long long)tiles * split_k * 32 * THREADS * 16),
                 "split-K partial buffer too small");
@@ -405,8 +437,8 @@ TDIST_API int tdist_ag_gemm_consumer(const tdist::SymmCtx* ctx, const void* a_lo
   p.fin = scratch + 1;
   p.n_counters = (int)((need_ints - 4 + 3) & ~3ll);
   p.ticket = scratch + 4;
-  p.push_done = scratch + 8;
-  p.tile_flags = scratch + 8 + cpr;
+  p.push_done = scratch + 16;
+  p.tile_flags = scratch + 16 + cpr;
   p.partial = (float*)partial;
   p.lda_local = lda_local;
   p.ld_ws = ld_ws;
@@ -422,6 +454,14 @@ TDIST_API int tdist_ag_gemm_consumer(const tdist::SymmCtx* ctx, const void* a_lo
   p.straddle = straddle;
   p.push_wgs = world > 1 ? push_wgs : 0;
   p.split_k = split_k;
+  {
+    // column bands first (B panels are the larger operand to share), row-block residues for the rest
+    const int npn = (N_local + BN - 1) / BN;
+    int qn = 1;
+    while (qn < 8 && qn * 2 <= npn) qn *= 2;
+    p.qn = qn;
+  }
+  p.race_debug = race_debug_enabled();
   p.state = state;
   p.ws0 = (uint16_t*)ws;
   p.ws1 = (uint16_t*)ws1;

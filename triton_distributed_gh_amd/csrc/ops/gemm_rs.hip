@@ -1,7 +1,11 @@
 // GEMM + ReduceScatter, tile-pipelined, one persistent kernel per rank:
 //     out[M/w, N] = ReduceScatter_M( A[M, K_local] * B[N, K_local]^T ).
 //
-// Work items are handed out by a device-side ticket counter in this order (cpr = chunks per rank):
+// Work items are handed out by eight device-side ticket queues, one per XCD (workgroups are dealt to the
+// XCDs round-robin by index; a workgroup whose queue is empty moves on to the next one).  A queue owns a
+// band of column tiles (and, with fewer than eight column tiles, every qm-th row block) plus every eighth
+// reduction item, so the workgroups of one XCD share A row blocks and B panels in that XCD's L2 the way the
+// plain GEMM's block-id remap arranges it.  Every queue runs in this order (cpr = chunks per rank):
 //     GEMM(chunk 0), GEMM(chunk 1), REDUCE(chunk 0), GEMM(chunk 2), REDUCE(chunk 1), ... REDUCE(cpr-1)
 // GEMM(c) covers chunk c of EVERY destination rank, destinations visited as rank+1, rank+2, ...,
 // rank (own rows last), so in each step every xGMI link of the full mesh carries one stream.  The
@@ -26,6 +30,7 @@
 #include "tdist/common.hpp"
 #include "tdist/gemm_gfx950.hpp"
 #include "tdist/primitives.hpp"
+#include "tdist/race_debug.hpp"
 
 using namespace tdist;
 using namespace tdist::gemm;
@@ -36,8 +41,11 @@ struct GemmRsParams {
   const uint16_t* B;     // [N, K_local]
   uint16_t* scatter;     // symmetric, this parity: [w][M_per_rank][N]
   int* flags;            // symmetric (signal arena), this parity: [w * cpr]
-  int* counters;         // local [w * cpr + 4]; [w*cpr] is the ticket, [w*cpr + 1] counts finished workgroups.
-                         // Zero at launch; the last workgroup of every launch re-arms them (call_state.hpp).
+  int* counters;         // local [w * cpr + 12]: [0, w*cpr) tiles finished per (destination, chunk), then the eight
+                         // queue tickets, then the finished-workgroup counter.  Zero at launch; the last
+                         // workgroup of every launch re-arms them (call_state.hpp).
+  int qn;                // queues: qn column bands x (8 / qn) row-block residues
+  int race_debug;        // tdist/race_debug.hpp
   int* err;
   uint16_t* out;         // [M_per_rank, N]
   long long lda, ldb, ldo;
@@ -130,12 +138,14 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_rs_kernel(GemmRsParams p) {
   const int mbpc = (p.rows_per_chunk + BM - 1) / BM;
   const int num_pid_n = (p.N + BN - 1) / BN;
   const int tiles_per_dc = mbpc * num_pid_n;          // tiles per (destination, chunk)
-  const int Gc = w * tiles_per_dc;                    // GEMM items per chunk
   const int ncb = (p.N + RED_COLS - 1) / RED_COLS;
   const int Rc = ((p.rows_per_chunk + RED_ROWS - 1) / RED_ROWS) * ncb;  // reduce items per chunk
-  const int S = Gc + Rc;
-  const int total = cpr * S;
-  int* ticket = p.counters + w * cpr;
+  int* tickets = p.counters + w * cpr;
+  const int qn = p.qn, qm = 8 / qn;
+  const int cols_per = (num_pid_n + qn - 1) / qn;
+  const int n_rb_all = w * mbpc;                      // row blocks of one chunk over all destinations
+  const int xcd = blockIdx.x & 7;
+  int hop = 0;
   int call = 0;
   RsCall cv{p.scatter, p.flags, p.epoch};
   if (p.state) {
@@ -144,30 +154,44 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_rs_kernel(GemmRsParams p) {
     cv.flags = call_parity(call) ? p.flags1 : p.flags0;
     cv.epoch = call_epoch(call);
   }
+  race_debug_check_flags(p.race_debug, cv.flags, w * cpr, cv.epoch, p.err);
 
   while (true) {
-    const int item = fetch_ticket_block(ticket, s_ticket);
-    if (item >= total) break;
+    int item = 0, q = 0, gq = 0, rq = 0, n_cols = 0;
+    for (; hop < 8; ++hop) {
+      q = (xcd + hop) & 7;
+      const int qmi = q / qn, qni = q - qmi * qn;
+      const int n_rb = n_rb_all > qmi ? (n_rb_all - qmi + qm - 1) / qm : 0;
+      n_cols = min(max(num_pid_n - qni * cols_per, 0), cols_per);
+      gq = n_rb * n_cols;                              // GEMM items of this queue per chunk
+      rq = Rc > q ? (Rc - q + 7) >> 3 : 0;             // reduce items of this queue per chunk
+      const int qsize = cpr * (gq + rq);
+      if (qsize == 0) continue;
+      item = fetch_ticket_block(tickets + q, s_ticket);
+      if (item < qsize) break;
+    }
+    if (hop == 8) break;
     if (p.dbg && threadIdx.x == 0) { p.dbg[blockIdx.x * 4 + 0] = item; p.dbg[blockIdx.x * 4 + 1] = 1; }
 
     bool is_gemm;
     int c, i;
-    if (item < Gc) {
+    if (item < gq) {
       is_gemm = true;
       c = 0;
       i = item;
     } else {
-      const int i2 = item - Gc;
+      const int S = gq + rq;
+      const int i2 = item - gq;
       const int blk = i2 / S, rem = i2 - blk * S;
       if (blk < cpr - 1) {
-        if (rem < Gc) {
+        if (rem < gq) {
           is_gemm = true;
           c = blk + 1;
           i = rem;
         } else {
           is_gemm = false;
           c = blk;
-          i = rem - Gc;
+          i = rem - gq;
         }
       } else {
         is_gemm = false;
@@ -177,14 +201,14 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_rs_kernel(GemmRsParams p) {
     }
 
     if (!is_gemm) {
-      reduce_item<IS_BF16>(p, cv, c, i, cpr, ncb);
+      reduce_item<IS_BF16>(p, cv, c, i * 8 + q, cpr, ncb);
       if (p.dbg && threadIdx.x == 0) { p.dbg[blockIdx.x * 4 + 1] = 5; p.dbg[blockIdx.x * 4 + 2] += 1; }
       continue;
     }
 
-    const int dd = i / tiles_per_dc;
-    const int rest = i - dd * tiles_per_dc;
-    const int b = rest / num_pid_n, pid_n = rest - b * num_pid_n;
+    const int rb = (i / n_cols) * qm + q / qn;        // row block of this chunk over all destinations
+    const int pid_n = (q % qn) * cols_per + i % n_cols;
+    const int dd = rb / mbpc, b = rb - dd * mbpc;
     const int d = (rank + 1 + dd) % w;
     const int r_in = c * p.rows_per_chunk + b * BM;    // row inside the destination's shard
     const int rows = min(BM, min((c + 1) * p.rows_per_chunk, p.M_per_rank) - r_in);
@@ -206,6 +230,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_rs_kernel(GemmRsParams p) {
     uint16_t* cbase = dst_buf + ((long long)rank * p.M_per_rank + r_in) * p.N + pid_n * BN;
     const int nrem = p.N - pid_n * BN;
     const long long ldn = p.N;
+    race_debug_delay(p.race_debug, (unsigned)i);
     // Tile stores are write-through (they leave this XCD's L2 at once, bound for a peer over xGMI
     // or for the local reduction on another XCD), so publishing needs no release fence: drain,
     // barrier, count.
@@ -214,6 +239,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_rs_kernel(GemmRsParams p) {
     });
     if (p.dbg && threadIdx.x == 0) p.dbg[blockIdx.x * 4 + 1] = 3;
     drain_stores();
+    race_debug_delay(p.race_debug, (unsigned)i + 7u);
     __syncthreads();
     if (threadIdx.x == 0) {
       // Every tile's stores completed before its own add; the add that completes the chunk is
@@ -225,7 +251,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_rs_kernel(GemmRsParams p) {
       }
     }
   }
-  call_end(p.state, call, ticket + 1, p.counters, w * cpr + 1);
+  call_end(p.state, call, tickets + 8, p.counters, w * cpr + 8);
 }
 
 TDIST_API int tdist_gemm_rs(const tdist::SymmCtx* ctx, const void* A, const void* B, void* scatter, int* flags,
@@ -258,6 +284,13 @@ TDIST_API int tdist_gemm_rs(const tdist::SymmCtx* ctx, const void* A, const void
   p.rows_per_chunk = rows_per_chunk;
   p.epoch = epoch;
   p.dbg = dbg;
+  p.race_debug = race_debug_enabled();
+  {
+    const int npn = (N + BN - 1) / BN;
+    int qn = 1;
+    while (qn < 8 && qn * 2 <= npn) qn *= 2;
+    p.qn = qn;
+  }
   TDIST_REQUIRE(!state || (scatter1 && flags1 && (((uintptr_t)scatter1) & 15) == 0),
                 "device-side call numbering needs both parities");
   p.state = state;
@@ -266,7 +299,7 @@ TDIST_API int tdist_gemm_rs(const tdist::SymmCtx* ctx, const void* A, const void
   p.flags0 = flags;
   p.flags1 = flags1;
   const int cpr = M_per_rank / rows_per_chunk;
-  const size_t counter_bytes = (((size_t)(w * cpr + 4) * sizeof(int)) + 15) & ~(size_t)15;
+  const size_t counter_bytes = (((size_t)(w * cpr + 12) * sizeof(int)) + 15) & ~(size_t)15;
   static bool attr_set = false;
   if (!attr_set) {
     TDIST_HIP_TRY(hipFuncSetAttribute((const void*)gemm_rs_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -23,16 +23,15 @@ from ..utils.distributed import get_env
 
 
 def shard_local(tensor: torch.Tensor, world_size: int, dim: int, local_rank: int) -> torch.Tensor:
-    n = tensor.shape[dim]
-    if n % world_size != 0:
-        raise ValueError(f"Tensor dimension {n} is not divisible by world size {world_size}.")
-    if not 0 <= local_rank < world_size:
-        raise ValueError(f"Local rank {local_rank} is out of bounds for world size {world_size}.")
+    """This rank's equal share of ``tensor`` along ``dim`` (contiguous copy)."""
     if not 0 <= dim < tensor.dim():
-        raise ValueError(f"Dimension {dim} is out of bounds for tensor with {tensor.dim()} dimensions.")
-    per = n // world_size
-    if per == 0:
-        raise ValueError(f"Tensor slice size is zero for tensor dimension {n} and world size {world_size}.")
+        raise ValueError(f"shard_local: dim={dim} but the tensor has shape {tuple(tensor.shape)}")
+    if not 0 <= local_rank < world_size:
+        raise ValueError(f"shard_local: rank {local_rank} outside [0, {world_size})")
+    n = tensor.shape[dim]
+    per, rem = divmod(n, world_size)
+    if rem != 0 or per == 0:
+        raise ValueError(f"shard_local: cannot cut {n} entries of dim {dim} into {world_size} equal non-empty shards")
     return tensor.narrow(dim, local_rank * per, per).contiguous()
 
 

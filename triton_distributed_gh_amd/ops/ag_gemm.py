@@ -35,6 +35,7 @@ from .gemm import _DT, gemm_nt
 
 EPOCH_MOD = 4093
 _BM = 256
+DEBUG_RACES = os.environ.get("TDIST_DEBUG_RACES", "0") == "1"      # csrc/include/tdist/race_debug.hpp
 
 
 @dataclasses.dataclass(repr=False)
@@ -48,7 +49,7 @@ class AllGatherGEMMTensorParallelContext:
     workspaces: List[List[torch.Tensor]]        # [parity][rank] -> [max_M, K]
     flags: List[List[torch.Tensor]]             # [parity][rank] -> int32 [max chunks]
     epoch_table: Optional[torch.Tensor]
-    scratch: Optional[torch.Tensor]             # int32: [0] error word, [4] ticket, [8:] push / split-K counters
+    scratch: Optional[torch.Tensor]             # int32: [0] error word, [4:16] tickets, [16:] push / split-K counters
     env: Any = None
     ag_streams: Optional[List["torch.cuda.Stream"]] = None
     serial: bool = False
@@ -83,7 +84,11 @@ class AllGatherGEMMTensorParallelContext:
         return self.flags[self.call_count & 1]
 
     def check_error(self) -> None:
-        if self.scratch is not None and int(self.scratch[0]) != 0:
+        code = int(self.scratch[0]) if self.scratch is not None else 0
+        if code & 4:
+            raise RuntimeError("ag_gemm: a flag held a value that belongs to no call that may touch this parity "
+                               "(TDIST_DEBUG_RACES entry check)")
+        if code:
             raise RuntimeError("ag_gemm: a device-side wait timed out (peer data never arrived)")
 
 
@@ -166,9 +171,12 @@ def _push_kernel(ctx, a, parity, epoch, rpc, include_self, stream):
     cstruct = ctx.env.heap.ctx_struct()
     chunk_bytes = rpc * K * a.element_size()
     slices = max(1, min(16, chunk_bytes // (256 * 1024)))
+    # (its own counters: the consumer kernel's words in ctx.scratch must stay zero between launches)
+    if getattr(ctx, "push_counters", None) is None or ctx.push_counters.numel() < M_per_rank // rpc:
+        ctx.push_counters = torch.zeros(max(64, M_per_rank // rpc), dtype=torch.int32, device=a.device)
     _lib.check(
         lib.tdist_ag_push_kernel(ctypes.byref(cstruct), _lib.ptr(a), _lib.ptr(ctx.workspaces[parity][ctx.rank]),
-                                 _lib.ptr(ctx.flags[parity][ctx.rank]), _lib.ptr(ctx.scratch[8:]),
+                                 _lib.ptr(ctx.flags[parity][ctx.rank]), _lib.ptr(ctx.push_counters),
                                  ctypes.c_longlong(K * a.element_size()), M_per_rank, rpc, slices, epoch,
                                  1 if include_self else 0, _lib.stream_handle(stream)), "tdist_ag_push_kernel")
 
@@ -230,7 +238,7 @@ def ag_gemm_intra_node_op(a, b, c, ctx: AllGatherGEMMTensorParallelContext):
     tiles = _num_tiles(M_per_rank, w, N_local, straddle)
     split_k = _pick_split_k(tiles, K, ctx.num_ctas or 256)
     cpr = M_per_rank // rpc
-    need = (8 + cpr + (tiles if split_k > 1 else 0) + 3) & ~3
+    need = (16 + cpr + (tiles if split_k > 1 else 0) + 3) & ~3
     capturing = torch.cuda.is_current_stream_capturing()
     if ctx.scratch.numel() < need:
         # (only reachable when N_local exceeds the context's N: contexts size scratch for max_M x N)
@@ -267,13 +275,18 @@ def ag_gemm_intra_node_op(a, b, c, ctx: AllGatherGEMMTensorParallelContext):
     # `a` is read by the copy-engine streams; joining them keeps the caller free to reuse it in stream order
     for s in used:
         cur.wait_stream(s)
+    if DEBUG_RACES and w > 1 and not capturing:
+        # every row of this call has been consumed: poison the parity buffer so that a read of the NEXT call on
+        # this parity that is not ordered behind its flag sees NaNs instead of this call's plausible values
+        ctx.workspaces[parity][rank].view(torch.int16).fill_(0x7FC0)
     return c
 
 
 def _scratch_ints(max_M: int, w: int, N_local: int, max_chunks: int) -> int:
-    """[0] error word, [1] finished workgroups, [4] ticket, [8:] push counters + split-K arrival counters."""
+    """[0] error word, [1] finished workgroups, [4] push ticket, [8:16] tile-queue tickets, [16:] push counters +
+    split-K arrival counters (layout of csrc/ops/ag_gemm.hip)."""
     max_tiles = (-(-max_M // _BM) + w) * -(-N_local // _BM)
-    return (8 + max_chunks + max_tiles + 3) & ~3
+    return (16 + max_chunks + max_tiles + 3) & ~3
 
 
 def _may_grow(ctx, capturing: bool, what: str) -> None:

@@ -26,6 +26,7 @@ from ..utils.distributed import default_num_ctas, forbid_graph_capture, get_env
 from .gemm import _DT, gemm_nt
 
 EPOCH_MOD = 4093
+DEBUG_RACES = os.environ.get("TDIST_DEBUG_RACES", "0") == "1"      # csrc/include/tdist/race_debug.hpp
 
 
 @dataclasses.dataclass(repr=False)
@@ -56,7 +57,11 @@ class GEMMReduceScatterTensorParallelContext:
         return self.flags[self.call_count & 1]
 
     def check_error(self) -> None:
-        if self.scratch is not None and int(self.scratch[-4]) != 0:
+        code = int(self.scratch[-4]) if self.scratch is not None else 0
+        if code & 4:
+            raise RuntimeError("gemm_rs: a flag held a value that belongs to no call that may touch this parity "
+                               "(TDIST_DEBUG_RACES entry check)")
+        if code:
             raise RuntimeError("gemm_rs: a device-side wait timed out (peer partials never arrived)")
 
 
@@ -133,6 +138,9 @@ def gemm_rs_intra_node_op(a, b, ctx: GEMMReduceScatterTensorParallelContext, out
                           _DT[a.dtype], _lib.stream_handle(), _lib.ptr(getattr(ctx, "debug_trace", None)),
                           _lib.ptr(ctx.state), _lib.ptr(ctx.scatter[1][rank]), _lib.ptr(ctx.flags[1][rank])),
         "tdist_gemm_rs")
+    if DEBUG_RACES and not torch.cuda.is_current_stream_capturing():
+        # all w partials of this call were reduced: poison them (see ops/ag_gemm.py)
+        ctx.scatter[parity][rank].view(torch.int16).fill_(0x7FC0)
     return out
 
 
