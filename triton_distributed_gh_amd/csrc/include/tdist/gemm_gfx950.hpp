@@ -569,25 +569,39 @@ __device__ __forceinline__ void epilogue_256_from(GetFn&& get, char* smem, Store
 // values and hands sixteen 16-byte pieces to `store(row_in_tile, col_in_tile, uint4)`; one wave
 // instruction covers 16 rows x 64 contiguous bytes.  Because LDS is not touched, a persistent kernel
 // can issue the next tile's first loads right behind these stores and the write-out drains under
-// the next main loop.
-template <bool IS_BF16, class StoreFn>
-__device__ __forceinline__ void epilogue_256_direct(const Acc<IS_BF16>& acc, StoreFn&& store) {
+// the next main loop.  `get(m, v)` fills v[0..3] with the calling thread's fp32 values of accumulator tiles
+// (m, 0..3) in the Acc layout (epilogue_256_direct: the accumulators themselves).
+template <bool IS_BF16, class GetFn, class StoreFn>
+__device__ __forceinline__ void epilogue_256_direct_from(GetFn&& get, StoreFn&& store) {
   using F = Frag<IS_BF16>;
   const int tid = threadIdx.x;
   const int w = tid >> 6, l = tid & 63;
   const int row = (w >> 2) * 128 + (l & 15);
   const int col = (w & 3) * 64 + (l >> 4) * 8;
 #pragma unroll
-  for (int m = 0; m < 8; ++m)
+  for (int m = 0; m < 8; ++m) {
+    f32x4 x[4];
+    get(m, x);
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       uint4 v;
-      v.x = F::pack2(acc.v[m][2 * p][0], acc.v[m][2 * p][1]);
-      v.y = F::pack2(acc.v[m][2 * p][2], acc.v[m][2 * p][3]);
-      v.z = F::pack2(acc.v[m][2 * p + 1][0], acc.v[m][2 * p + 1][1]);
-      v.w = F::pack2(acc.v[m][2 * p + 1][2], acc.v[m][2 * p + 1][3]);
+      v.x = F::pack2(x[2 * p][0], x[2 * p][1]);
+      v.y = F::pack2(x[2 * p][2], x[2 * p][3]);
+      v.z = F::pack2(x[2 * p + 1][0], x[2 * p + 1][1]);
+      v.w = F::pack2(x[2 * p + 1][2], x[2 * p + 1][3]);
       store(row + m * 16, col + 32 * p, v);
     }
+  }
+}
+
+template <bool IS_BF16, class StoreFn>
+__device__ __forceinline__ void epilogue_256_direct(const Acc<IS_BF16>& acc, StoreFn&& store) {
+  epilogue_256_direct_from<IS_BF16>(
+      [&](int m, f32x4(&v)[4]) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) v[n] = acc.v[m][n];
+      },
+      store);
 }
 
 template <bool IS_BF16, class StoreFn>

@@ -113,13 +113,20 @@ template <typename T>
 __device__ __forceinline__ int wait(const T* barrier_ptrs, int num_barriers, int scope, int semantic,
                                     T wait_value = 1, int* err_word = nullptr) {
   int failed = 0;
-  // Once any wait of this launch has timed out the error word is sticky and later waits give up
-  // at once, so a lost peer costs one spin budget, not one per tile.
-  const bool dead = err_word && load_relaxed_agent(err_word) != 0;
   for (int i = threadIdx.x; i < num_barriers; i += blockDim.x) {
-    if (dead || !spin_until_eq(barrier_ptrs + i, wait_value, scope)) failed = 1;
+    // the common case - the flag is already there - costs one load
+    const T v = (scope == SCOPE_SYS) ? load_relaxed_system(barrier_ptrs + i) : load_relaxed_agent(barrier_ptrs + i);
+    if (v == wait_value) continue;
+    // Once any wait of this launch has timed out the error word is sticky and later waits give up
+    // at once, so a lost peer costs one spin budget, not one per tile.
+    const bool dead = err_word && load_relaxed_agent(err_word) != 0;
+    if (dead) {
+      failed = 1;
+    } else if (!spin_until_eq(barrier_ptrs + i, wait_value, scope)) {
+      failed = 1;
+      if (err_word) atomicOr(err_word, 1);
+    }
   }
-  if (failed && err_word && !dead) atomicOr(err_word, 1);
   // Only waves that polled need the cache invalidate; it covers the whole CU's L1, and the
   // barrier below orders every other wave's loads behind it.
   const int wave_first = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));

@@ -1,10 +1,10 @@
 // AllGather + GEMM, one persistent kernel per rank:  C[M, N_local] = AllGather_M(A[M/w, K]) * B[N_local, K]^T.
 //
-// Work items are handed out by device-side ticket counters.  The first `push_wgs` tickets of the push
-// counter are PRODUCER items: they store this rank's shard of A into every peer's symmetric workspace
-// [M, K] over xGMI, chunk by chunk, and raise one int32 flag per (source rank, chunk) to the call's
-// epoch value on every peer.  Tile jobs (256x256) live in EIGHT queues, one per XCD (workgroups are dealt
-// to the XCDs round-robin by index): a queue owns a band of column tiles (and, when there are fewer than
+// The first `push_wgs` workgroups of the grid are PRODUCERS: they store this rank's shard of A into every
+// peer's symmetric workspace [M, K] over xGMI, chunk by chunk, and raise one int32 flag per (source rank,
+// chunk) to the call's epoch value on every peer; when they are done they join the consumers.  Tile jobs
+// (256x256) live in EIGHT queues, one per XCD (tdist/work_queue.hpp: static first item, tickets drawn ahead
+// of the main loop): a queue owns a band of column tiles (and, when there are fewer than
 // eight column tiles, every qm-th row block), each in expected-arrival order (own rows first, then chunk
 // 0 of every peer, chunk 1 of every peer, ...).  The workgroups of one XCD therefore work on a compact
 // rows x columns patch whose A row blocks and B panels they share in that XCD's L2 - the mapping the plain
@@ -13,8 +13,9 @@
 // acquire - for the flags covering its rows and runs the MFMA main loop.  Producer and consumer share one launch because the GEMM workgroups fill the
 // register file of every CU: a separate push kernel that reaches the GPU after the GEMM could
 // not be scheduled until GEMM workgroups exit, and those are waiting for the peers' pushes.
-// Producer items never wait and hold the lowest tickets, so progress does not depend on dispatch
-// order.  (With push_wgs == 0 the data is expected from the SDMA copy engines instead.)
+// Producers never wait and the whole grid is resident at once (the host clamps it to the number of CUs),
+// so progress does not depend on dispatch order.  (With push_wgs == 0 the data is expected from the SDMA
+// copy engines instead.)
 //
 // When the problem has fewer tiles than the chip has CUs (large TP degree), K is cut into
 // `split_k` ranges, one work item each: every item parks its fp32 accumulators in a scratch
@@ -39,6 +40,8 @@
 #include "tdist/primitives.hpp"
 #include "tdist/race_debug.hpp"
 #include "tdist/shmem_device.hpp"
+#include "tdist/wg_trace.hpp"
+#include "tdist/work_queue.hpp"
 
 using namespace tdist;
 using namespace tdist::gemm;
@@ -68,6 +71,7 @@ struct AgGemmParams {
   int split_k;               // K is cut into split_k ranges, one work item each
   int qn;                    // tile queues: qn column bands x (8 / qn) row-block residues
   int race_debug;            // tdist/race_debug.hpp
+  WgTrace trace;             // tdist/wg_trace.hpp (off unless the host armed a sink)
   // Device-side call numbering (tdist/call_state.hpp).  When `state` is set, ws / flags / epoch above
   // are ignored by the host and resolved on the device from the call number: the launch is then the
   // same every time and can be replayed from a HIP graph.
@@ -87,14 +91,15 @@ struct AgCall {
 
 constexpr int TICKET_SLOT = LDS_BYTES;  // 16 bytes after the tile staging area: [0] ticket, [1] split-K arrival, [2] call number
 
-// Producer work item `pw` of `p.push_wgs`: for every chunk in order, copy slice pw of the chunk
-// to every peer's workspace.  Each thread keeps eight 16-byte pieces in flight; every piece is
-// loaded once and stored w-1 times with write-through stores, peers rotated per workgroup so all
-// xGMI links carry traffic at any moment.  The workgroup that completes a chunk raises that
-// chunk's flag on every peer.  Chunks go out in order so the consumers of every peer can start on
-// chunk 0 while chunk 1 is still on the wire.
+// Producer work of workgroup `pw` (of `p.push_wgs`): for every chunk in order, copy slice pw of the chunk
+// to every peer's workspace.  Each thread keeps two batches of eight 16-byte pieces in flight (the next
+// batch is loaded before the current one is stored); every piece is loaded once and stored w-1 times
+// with write-through stores, peers rotated per workgroup so all xGMI links carry traffic at any moment.
+// The workgroup that completes a chunk raises that chunk's flag on every peer.  Chunks go out in order so
+// the consumers of every peer can start on chunk 0 while chunk 1 is still on the wire.
 __device__ __forceinline__ void push_item(const AgGemmParams& p, const AgCall& cv, int pw) {
   constexpr int U = 8;
+  constexpr int STEP = U * THREADS;
   const int w = p.world, rank = p.rank;
   const int cpr = p.M_per_rank / p.rows_per_chunk;
   const long long row_bytes = (long long)p.K * 2;
@@ -110,8 +115,7 @@ __device__ __forceinline__ void push_item(const AgGemmParams& p, const AgCall& c
     race_debug_delay(p.race_debug, 2 * chunk);
     const long long src_row = (long long)chunk * p.rows_per_chunk;
     const long long dst_off = ((long long)rank * p.M_per_rank + src_row) * row_bytes + b0;
-    for (int base = 0; base < n16; base += U * THREADS) {
-      uint4 v[U];
+    auto load_batch = [&](uint4(&v)[U], int base) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int i = base + u * THREADS + (int)threadIdx.x;
@@ -122,6 +126,8 @@ __device__ __forceinline__ void push_item(const AgGemmParams& p, const AgCall& c
                                  ((long long)(q - r * pieces_per_row) << 4));
         }
       }
+    };
+    auto store_batch = [&](const uint4(&v)[U], int base) {
       for (int j = first_peer; j < w; ++j) {
         const int peer = j == 0 ? rank : (rank + 1 + (j - 1 + pw) % (w - 1)) % w;
         char* dst = (char*)(peer == rank ? cv.ws : symm_at(p.ctx, cv.ws, peer)) + dst_off;
@@ -130,6 +136,17 @@ __device__ __forceinline__ void push_item(const AgGemmParams& p, const AgCall& c
           const int i = base + u * THREADS + (int)threadIdx.x;
           if (i < n16) st_wt128_sys(dst + ((long long)i << 4), v[u]);
         }
+      }
+    };
+    uint4 va[U], vb[U];
+    if (n16 > 0) load_batch(va, 0);
+    for (int base = 0; base < n16; base += 2 * STEP) {
+      const bool second = base + STEP < n16;
+      if (second) load_batch(vb, base + STEP);
+      store_batch(va, base);
+      if (second) {
+        if (base + 2 * STEP < n16) load_batch(va, base + 2 * STEP);
+        store_batch(vb, base + STEP);
       }
     }
     drain_stores();
@@ -150,7 +167,8 @@ __device__ __forceinline__ void push_item(const AgGemmParams& p, const AgCall& c
   }
 }
 
-template <bool IS_BF16>
+// SPLIT: false = every tile is one item (split_k == 1; no fix-up code in the kernel at all), true = split-K.
+template <bool IS_BF16, bool SPLIT>
 __global__ __launch_bounds__(THREADS, 2) void ag_gemm_consumer_kernel(AgGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   volatile int* s_ticket = (volatile int*)(smem + TICKET_SLOT);
@@ -166,15 +184,22 @@ __global__ __launch_bounds__(THREADS, 2) void ag_gemm_consumer_kernel(AgGemmPara
     mb_per_rank = (p.M_per_rank + BM - 1) / BM;
     total_mb = mb_per_rank * w;
   }
-  const int S = p.split_k;
+  const int S = SPLIT ? p.split_k : 1;
   const int ksteps = p.K / BK;
   const int qn = p.qn, qm = 8 / qn;
   const int cols_per = (num_pid_n + qn - 1) / qn;
-  const int xcd = blockIdx.x & 7;
-  int hop = 0;
-  bool pushing = p.push_wgs > 0;
+  // queue q = (row-block residue q / qn, column band q % qn); items ordered row block, column, K range
+  auto queue_cols = [=](int q) { return min(max(num_pid_n - (q % qn) * cols_per, 0), cols_per); };
+  auto queue_size = [=](int q) {
+    const int qmi = q / qn;
+    const int n_o = total_mb > qmi ? (total_mb - qmi + qm - 1) / qm : 0;
+    return n_o * queue_cols(q) * S;
+  };
+  WorkQueues<decltype(queue_size)> wq(p.ticket + 4, s_ticket, p.push_wgs, queue_size);
   int call = 0;
   AgCall cv{p.ws, p.flags, p.epoch};
+  WgTraceCursor tr = wg_trace_begin(p.trace);
+  wg_trace(tr, 1, 0);
   if (p.state) {
     call = call_begin(p.state, s_ticket + 2);
     cv.ws = call_parity(call) ? p.ws1 : p.ws0;
@@ -183,34 +208,29 @@ __global__ __launch_bounds__(THREADS, 2) void ag_gemm_consumer_kernel(AgGemmPara
   }
   race_debug_check_flags(p.race_debug, cv.flags, w * cpr, cv.epoch, p.err);
 
-  while (true) {
-    if (pushing) {
-      const int item = fetch_ticket_block(p.ticket, s_ticket);
-      if (item < p.push_wgs) {
-        push_item(p, cv, item);
-        continue;
-      }
-      pushing = false;
-    }
-    // next job of this XCD's queue; queues that have run dry are left behind for good
-    int local = 0, q = 0, n_cols = 0;
-    for (; hop < 8; ++hop) {
-      q = (xcd + hop) & 7;
-      const int qmi = q / qn, qni = q - qmi * qn;
-      const int n_o = total_mb > qmi ? (total_mb - qmi + qm - 1) / qm : 0;
-      n_cols = min(max(num_pid_n - qni * cols_per, 0), cols_per);
-      const int qsize = n_o * n_cols * S;
-      if (qsize == 0) continue;
-      local = fetch_ticket_block(p.ticket + 4 + q, s_ticket);
-      if (local < qsize) break;
-    }
-    if (hop == 8) break;
-    const int per_o = n_cols * S;
+  int local = 0;
+  bool have;
+  if ((int)blockIdx.x < p.push_wgs) {
+    // dedicated producers first push (they never wait, so progress does not depend on anybody else),
+    // then help with whatever tiles are left
+    push_item(p, cv, (int)blockIdx.x);
+    wg_trace(tr, 6, (int)blockIdx.x);
+    have = wq.next(local);
+  } else {
+    have = wq.first(local);
+    if (!have) have = wq.next(local);
+  }
+  int seen_f0 = -1, seen_f1 = -1;       // flag range this workgroup has already acquired
+  while (have) {
+    const int q = wq.q;
+    const int per_o = queue_cols(q) * S;
     const int o_idx = local / per_o, rem = local - o_idx * per_o;
     const int o = o_idx * qm + q / qn;
     const int pid_n = (q % qn) * cols_per + rem / S;
     const int ks = rem % S;                   // K range
     const int tile = o * num_pid_n + pid_n;
+    wg_trace(tr, 2, tile);
+    wq.prefetch();
 
     // ---- which rows does this tile cover -----------------------------------------------
     int g0, rows;          // first global row, valid rows (<= 256)
@@ -253,8 +273,17 @@ __global__ __launch_bounds__(THREADS, 2) void ag_gemm_consumer_kernel(AgGemmPara
       const int g1 = g0 + rows - 1;
       const int f0 = (g0 / p.M_per_rank) * cpr + (g0 % p.M_per_rank) / p.rows_per_chunk;
       const int f1 = (g1 / p.M_per_rank) * cpr + (g1 % p.M_per_rank) / p.rows_per_chunk;
-      const int token = wait((const int*)cv.flags + f0, f1 - f0 + 1, SCOPE_SYS, SEM_ACQUIRE, cv.epoch, p.err);
-      a_ptr = consume_token(a_ptr, token);
+      // Consecutive items of a queue mostly share their row block.  Rows this workgroup has waited for
+      // before landed before that wait's acquire and do not change within the call: no second wait.
+      if (f0 != seen_f0 || f1 != seen_f1) {
+        const int token = wait((const int*)cv.flags + f0, f1 - f0 + 1, SCOPE_SYS, SEM_ACQUIRE, cv.epoch, p.err);
+        a_ptr = consume_token(a_ptr, token);
+        if (token == 0) {
+          seen_f0 = f0;
+          seen_f1 = f1;
+        }
+        wg_trace(tr, 3, tile);
+      }
     }
 
     const int k0 = (int)((long long)ksteps * ks / S) * BK;
@@ -268,7 +297,18 @@ __global__ __launch_bounds__(THREADS, 2) void ag_gemm_consumer_kernel(AgGemmPara
     t.b_rows = p.N_local - pid_n * BN;
     t.K = k1 - k0;
     Acc<IS_BF16> acc;
-    mainloop_256_2ph<IS_BF16>(t, smem, acc);
+    // accumulator columns permuted (PERM_B) so the epilogue stores 16-byte pieces straight from registers:
+    // no LDS staging, no barrier, and the next item's first loads go out right behind the stores
+    mainloop_256_2ph<IS_BF16, true, 3>(t, smem, acc);
+    wg_trace(tr, 4, tile);
+    // The next item is looked up HERE, before this tile is written out: the main loop ends with every load
+    // drained and all waves in step, so collecting the ticket and the barrier that broadcasts it cost
+    // nothing now - after the epilogue the same barrier would wait for the slowest wave to get its stores
+    // into the memory pipeline (2-3 us when every CU of the chip writes its tile at the same moment).
+    // With it out of the way each wave goes from its last store straight to the next tile's first loads.
+    wq.stash();
+    int next_local = 0;
+    const bool have_next = wq.next(next_local);
 
     const int nrem = p.N_local - pid_n * BN;
     uint16_t* cbase = p.C + (long long)g0 * p.ldc + pid_n * BN;
@@ -276,16 +316,14 @@ __global__ __launch_bounds__(THREADS, 2) void ag_gemm_consumer_kernel(AgGemmPara
     auto store_c = [&](int r, int c, const uint4& v) {
       if (r < rows && c < nrem) *(uint4*)(cbase + (long long)r * ldc + c) = v;
     };
-    if (S == 1) {
-      epilogue_256<IS_BF16>(acc, smem, store_c);
-      continue;
-    }
+    if constexpr (!SPLIT) {
+      epilogue_256_direct<IS_BF16>(acc, store_c);
+      wg_trace(tr, 5, tile);
+    } else {
     // Split-K fix-up, wait-free: every item parks its fp32 accumulators (register layout, so both
-    // directions are fully coalesced) and counts itself; whichever item of the tile counts last
-    // sums the split_k partials piece by piece straight into the epilogue's LDS staging.  The
-    // accumulators are dead after the store, which keeps the fix-up out of the main loop's
-    // register budget.  The per-thread offset is made opaque so it is not hoisted out of the
-    // persistent loop (it would stay live across the main loop).
+    // directions are fully coalesced) and counts itself; whichever item of the tile counts last adds the
+    // other partials to its own accumulators and stores the tile.  The per-thread offset is made opaque so
+    // it is not hoisted out of the persistent loop (it would stay live across the main loop).
     unsigned voff = threadIdx.x * 16u;
     asm volatile("" : "+v"(voff));
     char* tbase = (char*)p.partial + (long long)tile * S * (32 * THREADS * 16);
@@ -302,36 +340,35 @@ __global__ __launch_bounds__(THREADS, 2) void ag_gemm_consumer_kernel(AgGemmPara
     if (threadIdx.x == 0) s_ticket[1] = atom_add_relaxed_agent(p.tile_flags + tile, 1);
     __syncthreads();
     const int arrived = __builtin_amdgcn_readfirstlane(s_ticket[1]);
-    if (arrived != S - 1) continue;
-    // last arriver: one acquire drops this CU's stale L1 lines, then plain loads
-    if (threadIdx.x < 64) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (arrived == S - 1) {
+      // last arriver: one acquire drops this CU's stale L1 lines, then plain loads
+      if (threadIdx.x < 64) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+      // This item's own partial is still in its accumulator registers: add the other split_k - 1 partials
+      // to it (loads only, so they pipeline freely) and store the tile straight from registers.
+      for (int qq = 0; qq < S; ++qq) {
+        if (qq == ks) continue;
+        const char* src = tbase + (long long)qq * (32 * THREADS * 16);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          f32x4 x[4];
+#pragma unroll
+          for (int n = 0; n < 4; ++n) x[n] = *(const f32x4*)(src + (voff + (unsigned)((m * 4 + n) * THREADS * 16)));
+#pragma unroll
+          for (int n = 0; n < 4; ++n) acc.v[m][n] += x[n];
+        }
+      }
+      epilogue_256_direct<IS_BF16>(acc, store_c);
     }
-    __syncthreads();
-    epilogue_256_from<IS_BF16>(
-        [&](int m, f32x4(&v)[4]) {
-          // all 4 * split_k loads of this row of accumulator tiles are issued before the first add
-          f32x4 x[4][4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (q < S) {
-#pragma unroll
-              for (int n = 0; n < 4; ++n)
-                x[q][n] = *(const f32x4*)(tbase + (long long)q * (32 * THREADS * 16) +
-                                          (voff + (unsigned)((m * 4 + n) * THREADS * 16)));
-            }
-#pragma unroll
-          for (int n = 0; n < 4; ++n) v[n] = x[0][n];
-#pragma unroll
-          for (int q = 1; q < 4; ++q)
-            if (q < S) {
-#pragma unroll
-              for (int n = 0; n < 4; ++n) v[n] += x[q][n];
-            }
-        },
-        smem, store_c);
+    wg_trace(tr, 5, tile);
+    }
+    have = have_next;
+    local = next_local;
   }
+  wg_trace(tr, 7, 0);
   call_end(p.state, call, p.fin, p.ticket, p.n_counters);
 }
 
@@ -462,14 +499,25 @@ TDIST_API int tdist_ag_gemm_consumer(const tdist::SymmCtx* ctx, const void* a_lo
     p.qn = qn;
   }
   p.race_debug = race_debug_enabled();
+  p.trace = wg_trace_sink();
   p.state = state;
   p.ws0 = (uint16_t*)ws;
   p.ws1 = (uint16_t*)ws1;
   p.flags0 = flags;
   p.flags1 = flags1;
   const int total = p.push_wgs + tiles * split_k;
-  int grid = num_ctas > 0 ? num_ctas : 256;
+  // The whole grid must be resident at once: consumers spin on flags that this rank's producers (and the
+  // peers') raise, and a producer that cannot be scheduled behind spinning consumers never would.
+  static int num_cus = 0;
+  if (!num_cus) {
+    int dev = 0;
+    TDIST_HIP_TRY(hipGetDevice(&dev));
+    TDIST_HIP_TRY(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  int grid = num_ctas > 0 ? num_ctas : num_cus;
+  if (grid > num_cus) grid = num_cus;
   if (grid > total) grid = total;
+  if (p.push_wgs > grid) p.push_wgs = grid;     // (they all push first and compute afterwards)
   static const bool trace = getenv("TDIST_TRACE_LAUNCH") != nullptr;
   if (trace)
     fprintf(stderr,
@@ -480,16 +528,22 @@ TDIST_API int tdist_ag_gemm_consumer(const tdist::SymmCtx* ctx, const void* a_lo
             total);
   static bool attr_set = false;
   if (!attr_set) {
-    TDIST_HIP_TRY(hipFuncSetAttribute((const void*)ag_gemm_consumer_kernel<true>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 16));
-    TDIST_HIP_TRY(hipFuncSetAttribute((const void*)ag_gemm_consumer_kernel<false>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 16));
+    typedef void (*kern_t)(AgGemmParams);
+    const kern_t all[4] = {ag_gemm_consumer_kernel<true, false>, ag_gemm_consumer_kernel<true, true>,
+                           ag_gemm_consumer_kernel<false, false>, ag_gemm_consumer_kernel<false, true>};
+    for (int i = 0; i < 4; ++i)
+      TDIST_HIP_TRY(hipFuncSetAttribute((const void*)all[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 16));
     attr_set = true;
   }
-  if (dtype == 0)
-    hipLaunchKernelGGL(ag_gemm_consumer_kernel<true>, dim3(grid), dim3(THREADS), LDS_BYTES + 16, (hipStream_t)stream, p);
+  const dim3 g(grid), b(THREADS);
+  if (dtype == 0 && split_k == 1)
+    hipLaunchKernelGGL((ag_gemm_consumer_kernel<true, false>), g, b, LDS_BYTES + 16, (hipStream_t)stream, p);
+  else if (dtype == 0)
+    hipLaunchKernelGGL((ag_gemm_consumer_kernel<true, true>), g, b, LDS_BYTES + 16, (hipStream_t)stream, p);
+  else if (split_k == 1)
+    hipLaunchKernelGGL((ag_gemm_consumer_kernel<false, false>), g, b, LDS_BYTES + 16, (hipStream_t)stream, p);
   else
-    hipLaunchKernelGGL(ag_gemm_consumer_kernel<false>, dim3(grid), dim3(THREADS), LDS_BYTES + 16, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((ag_gemm_consumer_kernel<false, true>), g, b, LDS_BYTES + 16, (hipStream_t)stream, p);
   TDIST_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -10,6 +10,7 @@
 
 #include "tdist/common.hpp"
 #include "tdist/gemm_gfx950.hpp"
+#include "tdist/wg_trace.hpp"
 
 using namespace tdist::gemm;
 
@@ -71,16 +72,20 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_256_persistent_kernel(cons
                                                                             const uint16_t* __restrict__ B,
                                                                             uint16_t* __restrict__ C, int M, int N,
                                                                             int K, long long lda, long long ldb,
-                                                                            long long ldc, int group_m) {
+                                                                            long long ldc, int group_m,
+                                                                            tdist::WgTrace trace) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int num_pid_m = (M + BM - 1) / BM;
   const int num_pid_n = (N + BN - 1) / BN;
   const int nwg = num_pid_m * num_pid_n;
+  tdist::WgTraceCursor tr = tdist::wg_trace_begin(trace);
+  tdist::wg_trace(tr, 1, 0);
   for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
     const int id = xcd_remap(vb, nwg);
     int pid_m, pid_n;
     tile_coords(id, num_pid_m, num_pid_n, group_m, pid_m, pid_n);
     const int row0 = pid_m * BM, col0 = pid_n * BN;
+    tdist::wg_trace(tr, 2, id);
     TileArgs t;
     t.A = A + (long long)row0 * lda;
     t.B = B + (long long)col0 * ldb;
@@ -91,12 +96,15 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_256_persistent_kernel(cons
     t.K = K;
     Acc<IS_BF16> acc;
     mainloop_256_2ph<IS_BF16, true, OPT>(t, smem, acc);
+    tdist::wg_trace(tr, 4, id);
     const int mrem = M - row0, nrem = N - col0;
     uint16_t* cbase = C + (long long)row0 * ldc + col0;
     epilogue_256_direct<IS_BF16>(acc, [&](int r, int c, const uint4& v) {
       if (r < mrem && c < nrem) *(uint4*)(cbase + (long long)r * ldc + c) = v;
     });
+    tdist::wg_trace(tr, 5, id);
   }
+  tdist::wg_trace(tr, 7, 0);
 }
 
 // Four-wave persistent form (variant 4): see mainloop_256_4w.
@@ -359,7 +367,8 @@ TDIST_API int tdist_gemm_nt(const void* A, const void* B, void* C, int M, int N,
     return 0;
   }
   if ((variant & 255) == 3) {
-    typedef void (*pkern_t)(const uint16_t*, const uint16_t*, uint16_t*, int, int, int, long long, long long, long long, int);
+    typedef void (*pkern_t)(const uint16_t*, const uint16_t*, uint16_t*, int, int, int, long long, long long, long long, int,
+                            tdist::WgTrace);
     // bits 16..17 of `variant` pick the schedule knobs of mainloop_256_2ph (fp16: defaults only)
     static const pkern_t ptable[5] = {
         gemm_nt_256_persistent_kernel<true, 0>, gemm_nt_256_persistent_kernel<true, 1>,
@@ -380,7 +389,7 @@ TDIST_API int tdist_gemm_nt(const void* A, const void* B, void* C, int M, int N,
     if (tiles < grid) grid = tiles;               // (fewer tiles than CUs: one tile each, no remap constraint)
     const pkern_t pk = dtype == 0 ? ptable[(variant >> 16) & 3] : ptable[4];
     hipLaunchKernelGGL(pk, dim3(grid), dim3(THREADS), 2 * BUF_BYTES, (hipStream_t)stream, (const uint16_t*)A,
-                       (const uint16_t*)B, (uint16_t*)C, M, N, K, lda, ldb, ldc, group_m);
+                       (const uint16_t*)B, (uint16_t*)C, M, N, K, lda, ldb, ldc, group_m, tdist::wg_trace_sink());
     TDIST_HIP_TRY(hipGetLastError());
     return 0;
   }

@@ -1,8 +1,8 @@
 // GEMM + ReduceScatter, tile-pipelined, one persistent kernel per rank:
 //     out[M/w, N] = ReduceScatter_M( A[M, K_local] * B[N, K_local]^T ).
 //
-// Work items are handed out by eight device-side ticket queues, one per XCD (workgroups are dealt to the
-// XCDs round-robin by index; a workgroup whose queue is empty moves on to the next one).  A queue owns a
+// Work items live in eight queues, one per XCD (tdist/work_queue.hpp: static first item, tickets drawn ahead
+// of the main loop, a workgroup whose queue is empty moves on to one that is not).  A queue owns a
 // band of column tiles (and, with fewer than eight column tiles, every qm-th row block) plus every eighth
 // reduction item, so the workgroups of one XCD share A row blocks and B panels in that XCD's L2 the way the
 // plain GEMM's block-id remap arranges it.  Every queue runs in this order (cpr = chunks per rank):
@@ -31,6 +31,8 @@
 #include "tdist/gemm_gfx950.hpp"
 #include "tdist/primitives.hpp"
 #include "tdist/race_debug.hpp"
+#include "tdist/wg_trace.hpp"
+#include "tdist/work_queue.hpp"
 
 using namespace tdist;
 using namespace tdist::gemm;
@@ -45,7 +47,9 @@ struct GemmRsParams {
                          // queue tickets, then the finished-workgroup counter.  Zero at launch; the last
                          // workgroup of every launch re-arms them (call_state.hpp).
   int qn;                // queues: qn column bands x (8 / qn) row-block residues
+  int red_rows;          // rows per reduce item (multiple of 4)
   int race_debug;        // tdist/race_debug.hpp
+  WgTrace trace;         // tdist/wg_trace.hpp (off unless the host armed a sink)
   int* err;
   uint16_t* out;         // [M_per_rank, N]
   long long lda, ldb, ldo;
@@ -69,14 +73,19 @@ struct RsCall {
 };
 
 constexpr int RS_TICKET_SLOT = LDS_BYTES;
-constexpr int RED_ROWS = 4;
 constexpr int RED_COLS = THREADS * 8;  // 4096 columns per item
 
-template <bool IS_BF16>
-__device__ __forceinline__ void reduce_item(const GemmRsParams& p, const RsCall& cv, int c, int i, int cpr, int ncb) {
+// Reduce item i of chunk c: p.red_rows rows x 4096 columns of this rank's output.  Four rows are in
+// flight at a time (every thread: 4 rows x up to 4 sources x 16 bytes of loads before the first add).
+// `acquired` is the last chunk this workgroup has already waited for: its partials landed before that
+// wait's acquire and do not change within the call, so the flags are not polled again.
+// `wq`: the draw for the next item was issued before the call; it is parked in LDS once the last loads have
+// been consumed, i.e. before the item's last stores (collecting it afterwards would wait for those stores).
+template <bool IS_BF16, class WQ>
+__device__ __forceinline__ void reduce_item(const GemmRsParams& p, const RsCall& cv, int c, int i, int cpr, int ncb,
+                                            int& acquired, WQ& wq) {
   const int w = p.ctx.num_ranks;
-  // wait for every source's partial of chunk c
-  {
+  if (acquired != c) {
     int failed = 0;
     const bool dead = load_relaxed_agent(p.err) != 0;
     if ((int)threadIdx.x < w) {
@@ -85,47 +94,63 @@ __device__ __forceinline__ void reduce_item(const GemmRsParams& p, const RsCall&
     if (failed && !dead) atomicOr(p.err, 1);
     if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (__syncthreads_or(failed) == 0) acquired = c;
   }
   const int rb = i / ncb, cb = i - rb * ncb;
   const int col = cb * RED_COLS + threadIdx.x * 8;
-  const int row0 = c * p.rows_per_chunk + rb * RED_ROWS;
-  const int row_end = min(min(row0 + RED_ROWS, (c + 1) * p.rows_per_chunk), p.M_per_rank);
-  if (col < p.N) {
-    const long long seg_stride = (long long)p.M_per_rank * p.N;
-    for (int row = row0; row < row_end; ++row) {
-      const uint16_t* src = cv.scatter + (long long)row * p.N + col;
-      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      for (int s0 = 0; s0 < w; s0 += 4) {
-        uint4 v[4];
+  const int row0 = c * p.rows_per_chunk + rb * p.red_rows;
+  const int row_end = min(min(row0 + p.red_rows, (c + 1) * p.rows_per_chunk), p.M_per_rank);
+  const long long seg_stride = (long long)p.M_per_rank * p.N;
+  // Threads beyond the last column run the same (uniform) control flow on column 0 and only skip the store:
+  // stash() must stay workgroup-uniform, and per-lane conditions around the loads would serialise them.
+  const bool active = col < p.N;
+  const int colc = active ? col : 0;
+  for (int row = row0; row < row_end; row += 4) {
+    float acc[4][8];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[rr][e] = 0.f;
+    const uint16_t* src = cv.scatter + (long long)row * p.N + colc;
+    for (int s0 = 0; s0 < w; s0 += 4) {
+      uint4 v[4][4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-          if (s0 + u < w) v[u] = *(const uint4*)(src + (long long)(s0 + u) * seg_stride);
+          if (row + rr < row_end && s0 + u < w)
+            v[rr][u] = *(const uint4*)(src + (long long)rr * p.N + (long long)(s0 + u) * seg_stride);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-          if (s0 + u < w) {
-            const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+          if (row + rr < row_end && s0 + u < w) {
+            const uint32_t x[4] = {v[rr][u].x, v[rr][u].y, v[rr][u].z, v[rr][u].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               if (IS_BF16) {
-                acc[2 * e] += __builtin_bit_cast(float, x[e] << 16);
-                acc[2 * e + 1] += __builtin_bit_cast(float, x[e] & 0xffff0000u);
+                acc[rr][2 * e] += __builtin_bit_cast(float, x[e] << 16);
+                acc[rr][2 * e + 1] += __builtin_bit_cast(float, x[e] & 0xffff0000u);
               } else {
                 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
                 const f16x2 h = __builtin_bit_cast(f16x2, x[e]);
-                acc[2 * e] += (float)h[0];
-                acc[2 * e + 1] += (float)h[1];
+                acc[rr][2 * e] += (float)h[0];
+                acc[rr][2 * e + 1] += (float)h[1];
               }
             }
           }
-      }
-      uint4 o;
-      o.x = Frag<IS_BF16>::pack2(acc[0], acc[1]);
-      o.y = Frag<IS_BF16>::pack2(acc[2], acc[3]);
-      o.z = Frag<IS_BF16>::pack2(acc[4], acc[5]);
-      o.w = Frag<IS_BF16>::pack2(acc[6], acc[7]);
-      *(uint4*)(p.out + (long long)row * p.ldo + col) = o;
     }
+    if (row + 4 >= row_end) wq.stash();
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+      if (active && row + rr < row_end) {
+        uint4 o;
+        o.x = Frag<IS_BF16>::pack2(acc[rr][0], acc[rr][1]);
+        o.y = Frag<IS_BF16>::pack2(acc[rr][2], acc[rr][3]);
+        o.z = Frag<IS_BF16>::pack2(acc[rr][4], acc[rr][5]);
+        o.w = Frag<IS_BF16>::pack2(acc[rr][6], acc[rr][7]);
+        *(uint4*)(p.out + (long long)(row + rr) * p.ldo + col) = o;
+      }
   }
 }
 
@@ -139,15 +164,25 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_rs_kernel(GemmRsParams p) {
   const int num_pid_n = (p.N + BN - 1) / BN;
   const int tiles_per_dc = mbpc * num_pid_n;          // tiles per (destination, chunk)
   const int ncb = (p.N + RED_COLS - 1) / RED_COLS;
-  const int Rc = ((p.rows_per_chunk + RED_ROWS - 1) / RED_ROWS) * ncb;  // reduce items per chunk
+  const int Rc = ((p.rows_per_chunk + p.red_rows - 1) / p.red_rows) * ncb;  // reduce items per chunk
   int* tickets = p.counters + w * cpr;
   const int qn = p.qn, qm = 8 / qn;
   const int cols_per = (num_pid_n + qn - 1) / qn;
   const int n_rb_all = w * mbpc;                      // row blocks of one chunk over all destinations
-  const int xcd = blockIdx.x & 7;
-  int hop = 0;
+  // queue q = (row-block residue q / qn, column band q % qn) plus every eighth reduce item
+  auto queue_cols = [=](int q) { return min(max(num_pid_n - (q % qn) * cols_per, 0), cols_per); };
+  auto queue_gemm = [=](int q) {                      // GEMM items of queue q per chunk
+    const int qmi = q / qn;
+    const int n_rb = n_rb_all > qmi ? (n_rb_all - qmi + qm - 1) / qm : 0;
+    return n_rb * queue_cols(q);
+  };
+  auto queue_red = [=](int q) { return Rc > q ? (Rc - q + 7) >> 3 : 0; };   // reduce items of queue q per chunk
+  auto queue_size = [=](int q) { return cpr * (queue_gemm(q) + queue_red(q)); };
+  WorkQueues<decltype(queue_size)> wq(tickets, s_ticket, 0, queue_size);
   int call = 0;
   RsCall cv{p.scatter, p.flags, p.epoch};
+  WgTraceCursor tr = wg_trace_begin(p.trace);
+  wg_trace(tr, 1, 0);
   if (p.state) {
     call = call_begin(p.state, s_ticket + 2);
     cv.scatter = call_parity(call) ? p.scatter1 : p.scatter0;
@@ -156,22 +191,15 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_rs_kernel(GemmRsParams p) {
   }
   race_debug_check_flags(p.race_debug, cv.flags, w * cpr, cv.epoch, p.err);
 
-  while (true) {
-    int item = 0, q = 0, gq = 0, rq = 0, n_cols = 0;
-    for (; hop < 8; ++hop) {
-      q = (xcd + hop) & 7;
-      const int qmi = q / qn, qni = q - qmi * qn;
-      const int n_rb = n_rb_all > qmi ? (n_rb_all - qmi + qm - 1) / qm : 0;
-      n_cols = min(max(num_pid_n - qni * cols_per, 0), cols_per);
-      gq = n_rb * n_cols;                              // GEMM items of this queue per chunk
-      rq = Rc > q ? (Rc - q + 7) >> 3 : 0;             // reduce items of this queue per chunk
-      const int qsize = cpr * (gq + rq);
-      if (qsize == 0) continue;
-      item = fetch_ticket_block(tickets + q, s_ticket);
-      if (item < qsize) break;
-    }
-    if (hop == 8) break;
+  int item = 0;
+  int acquired = -1;
+  bool have = wq.first(item);
+  if (!have) have = wq.next(item);
+  while (have) {
+    const int q = wq.q;
+    const int gq = queue_gemm(q), rq = queue_red(q), n_cols = queue_cols(q);
     if (p.dbg && threadIdx.x == 0) { p.dbg[blockIdx.x * 4 + 0] = item; p.dbg[blockIdx.x * 4 + 1] = 1; }
+    wg_trace(tr, 2, item);
 
     bool is_gemm;
     int c, i;
@@ -201,8 +229,11 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_rs_kernel(GemmRsParams p) {
     }
 
     if (!is_gemm) {
-      reduce_item<IS_BF16>(p, cv, c, i * 8 + q, cpr, ncb);
+      wq.prefetch();
+      reduce_item<IS_BF16>(p, cv, c, i * 8 + q, cpr, ncb, acquired, wq);
       if (p.dbg && threadIdx.x == 0) { p.dbg[blockIdx.x * 4 + 1] = 5; p.dbg[blockIdx.x * 4 + 2] += 1; }
+      wg_trace(tr, 6, c);
+      have = wq.next(item);
       continue;
     }
 
@@ -223,8 +254,12 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_rs_kernel(GemmRsParams p) {
     t.b_rows = p.N - pid_n * BN;
     t.K = p.K;
     Acc<IS_BF16> acc;
-    mainloop_256_2ph<IS_BF16>(t, smem, acc);
+    mainloop_256_2ph<IS_BF16, false, 3>(t, smem, acc);
+    // GEMM and reduce items differ in length by 10-40x: the next item is drawn only now, under the epilogue,
+    // so a workgroup does not commit to another tile while idle workgroups could take it
+    wq.prefetch();
     if (p.dbg && threadIdx.x == 0) p.dbg[blockIdx.x * 4 + 1] = 2;
+    wg_trace(tr, 4, c);
 
     uint16_t* dst_buf = (d == rank) ? cv.scatter : symm_at(p.ctx, cv.scatter, d);
     uint16_t* cbase = dst_buf + ((long long)rank * p.M_per_rank + r_in) * p.N + pid_n * BN;
@@ -233,7 +268,9 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_rs_kernel(GemmRsParams p) {
     race_debug_delay(p.race_debug, (unsigned)i);
     // Tile stores are write-through (they leave this XCD's L2 at once, bound for a peer over xGMI
     // or for the local reduction on another XCD), so publishing needs no release fence: drain,
-    // barrier, count.
+    // barrier, count.  The tile is staged through LDS so that every row leaves as one contiguous 512-byte
+    // run: write-through stores are not merged in L2, and 64-byte pieces straight from the accumulator
+    // layout cost 1.5x the time in HBM (and would halve the xGMI packet size).
     epilogue_256<IS_BF16>(acc, smem, [&](int r, int cc, const uint4& v) {
       if (r < rows && cc < nrem) st_wt128_sys(cbase + (long long)r * ldn + cc, v);
     });
@@ -250,7 +287,10 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_rs_kernel(GemmRsParams p) {
         store_relaxed_system(flag, cv.epoch);
       }
     }
+    wg_trace(tr, 5, c);
+    have = wq.next(item);
   }
+  wg_trace(tr, 7, 0);
   call_end(p.state, call, tickets + 8, p.counters, w * cpr + 8);
 }
 
@@ -285,6 +325,7 @@ TDIST_API int tdist_gemm_rs(const tdist::SymmCtx* ctx, const void* A, const void
   p.epoch = epoch;
   p.dbg = dbg;
   p.race_debug = race_debug_enabled();
+  p.trace = wg_trace_sink();
   {
     const int npn = (N + BN - 1) / BN;
     int qn = 1;
@@ -308,7 +349,24 @@ TDIST_API int tdist_gemm_rs(const tdist::SymmCtx* ctx, const void* A, const void
                                       LDS_BYTES + 16));
     attr_set = true;
   }
-  int grid = num_ctas > 0 ? num_ctas : 256;
+  // The whole grid must be resident at once (reduce items spin on flags raised by this rank's and the
+  // peers' GEMM items).
+  static int num_cus = 0;
+  if (!num_cus) {
+    int dev = 0;
+    TDIST_HIP_TRY(hipGetDevice(&dev));
+    TDIST_HIP_TRY(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  int grid = num_ctas > 0 ? num_ctas : num_cus;
+  if (grid > num_cus) grid = num_cus;
+  {
+    // Reduce items: as coarse as still gives every workgroup one item per chunk (the last chunk's
+    // reduction is the exposed tail and should run on the whole chip).
+    const int ncb = (N + RED_COLS - 1) / RED_COLS;
+    int rr = 16;
+    while (rr > 4 && ((rows_per_chunk + rr - 1) / rr) * ncb < grid) rr >>= 1;
+    p.red_rows = rr;
+  }
   static const bool trace = getenv("TDIST_TRACE_LAUNCH") != nullptr;
   if (trace)
     fprintf(stderr,

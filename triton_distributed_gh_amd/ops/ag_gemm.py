@@ -236,7 +236,7 @@ def ag_gemm_intra_node_op(a, b, c, ctx: AllGatherGEMMTensorParallelContext):
     fl = ctx.flags[0 if device_calls else parity][rank]
     straddle = straddle and w > 1
     tiles = _num_tiles(M_per_rank, w, N_local, straddle)
-    split_k = _pick_split_k(tiles, K, ctx.num_ctas or 256)
+    split_k = _pick_split_k(tiles, K, (ctx.num_ctas or _num_cus()) - push_wgs)
     cpr = M_per_rank // rpc
     need = (16 + cpr + (tiles if split_k > 1 else 0) + 3) & ~3
     capturing = torch.cuda.is_current_stream_capturing()
@@ -254,7 +254,7 @@ def ag_gemm_intra_node_op(a, b, c, ctx: AllGatherGEMMTensorParallelContext):
             if ctx.partial is not None:
                 ctx.retired.append(ctx.partial)
             # one allocation for the worst case of this grid: split-K only runs while tiles * split_k <= grid
-            ctx.partial = torch.empty(max(partial_bytes, (ctx.num_ctas or 256) * _BM * _BM * 4), dtype=torch.uint8,
+            ctx.partial = torch.empty(max(partial_bytes, (ctx.num_ctas or _num_cus()) * _BM * _BM * 4), dtype=torch.uint8,
                                       device=env.device)
         partial = ctx.partial
     ctx.captured = ctx.captured or capturing
@@ -301,9 +301,22 @@ def _num_tiles(M_per_rank: int, w: int, N_local: int, straddle: bool) -> int:
     return mb * -(-N_local // _BM)
 
 
+_NUM_CUS = 0
+
+
+def _num_cus() -> int:
+    global _NUM_CUS
+    if not _NUM_CUS:
+        _NUM_CUS = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    return _NUM_CUS
+
+
 def _pick_split_k(tiles: int, K: int, grid: int) -> int:
-    """Cut K when there are fewer tiles than workgroups (large TP degree): up to 4 ranges, each at
-    least 512 deep.  ``ag_gemm.SPLIT_K`` (tuning knob / TDIST_AG_SPLIT_K) overrides."""
+    """Cut K when there are fewer tiles than consumer workgroups (large TP degree): up to 4 ranges, each at
+    least 512 deep.  ``grid`` is the number of workgroups that compute from the start (the grid minus the
+    dedicated producers): all items then run in ONE round - with one item per workgroup of the whole grid,
+    the producers' items would form a second round behind their pushes.
+    ``ag_gemm.SPLIT_K`` (tuning knob / TDIST_AG_SPLIT_K) overrides."""
     forced = int(os.environ.get("TDIST_AG_SPLIT_K", "0")) or tuning.get("ag_gemm.SPLIT_K", 0)
     s = forced if forced else max(1, min(4, grid // max(tiles, 1), K // 512))
     return max(1, min(s, 4, K // 128))
