@@ -28,6 +28,9 @@ _DT = {torch.bfloat16: 0, torch.float16: 1}
 GEMM_VARIANT = int(os.environ.get("TDIST_GEMM_VARIANT", str(3 | (3 << 16))))
 # decode layers (M <= 16, K >= 4096) with at least this many MiB of weights go to the library (0 = never)
 DECODE_LIB_BYTES = int(os.environ.get("TDIST_DECODE_GEMM_LIB_MB", "0")) << 20
+# the band between the decode kernel and chip-filling 256x256 tiles: "native" (mid-M kernel) or "lib"
+MID_GEMM = os.environ.get("TDIST_MID_GEMM", "native")
+MID_MAX_M = int(os.environ.get("TDIST_MID_MAX_M", "1024"))
 
 
 def gemm_supported(a: torch.Tensor, b: torch.Tensor) -> bool:
@@ -58,11 +61,15 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
         torch.matmul(a, b.t(), out=out)
         return out
     # Between the decode kernel (M <= 16, weights streamed once) and shapes that fill the chip with
-    # 256x256 tiles lies a band (17..255 rows x few column tiles) where the big tile leaves most
-    # CUs idle; a plain library GEMM is the right tool there.
-    if not force_native and M > 16 and -(-M // 256) * -(-N // 256) < 128:
-        torch.matmul(a, b.t(), out=out)
-        return out
+    # 256x256 tiles lies a band (17 .. a few hundred rows, or few column tiles) where the big tile leaves
+    # most CUs idle: the weight-streaming mid-M kernel with split-K (csrc/ops/gemm_mid.hip) takes it.
+    # TDIST_MID_GEMM=lib hands the band to the library instead (A/B comparisons).
+    if M > 16 and -(-M // 256) * -(-N // 256) < 128 and variant == GEMM_VARIANT:
+        if MID_GEMM == "lib" and not force_native:
+            torch.matmul(a, b.t(), out=out)
+            return out
+        if M <= MID_MAX_M:
+            return gemm_nt_mid(a, b, out)
     # Decode shapes stay on the weight-streaming kernel.  Called back to back on ONE 100-270 MB layer the
     # library's 64x16x512 kernel looks faster (6.3-6.6 vs 4-5 TB/s), but there the weights partly sit in
     # the 256 MB memory-side cache; in a real decode step (Qwen3-8B, every layer streamed from HBM) the
@@ -77,6 +84,47 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
         lib.tdist_gemm_nt(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), M, N, K, ctypes.c_longlong(a.stride(0)),
                           ctypes.c_longlong(b.stride(0)), ctypes.c_longlong(out.stride(0)), _DT[a.dtype], group_m,
                           _lib.stream_handle(), variant), "tdist_gemm_nt")
+    return out
+
+
+_MID_WS = {}      # device index -> (fp32 split-K workspace, arrival counters)
+
+
+def gemm_nt_mid(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, wn: int = 0,
+                splits: int = 0) -> torch.Tensor:
+    """``a @ b^T`` on the mid-M kernel (csrc/ops/gemm_mid.hip): weights streamed once, activations through
+    LDS, K split across workgroups.  ``wn`` (1 / 2: 64 / 128 columns per workgroup) and ``splits`` override the
+    plan (tuning knobs ``gemm_mid.WN`` / ``gemm_mid.SPLITS``)."""
+    M, K = a.shape
+    N = b.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    lib = _lib.hip()
+    dev = a.device.index if a.device.index is not None else torch.cuda.current_device()
+    mt, wn_, sp = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    pbytes, ncnt = ctypes.c_longlong(), ctypes.c_int()
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    _lib.check(lib.tdist_gemm_nt_mid_plan(M, N, K, cus, wn or tuning.get("gemm_mid.WN", 0),
+                                          splits or tuning.get("gemm_mid.SPLITS", 0), ctypes.byref(mt),
+                                          ctypes.byref(wn_), ctypes.byref(sp), ctypes.byref(pbytes),
+                                          ctypes.byref(ncnt)), "tdist_gemm_nt_mid_plan")
+    # One workspace per device and STREAM: launches on one stream run in order and every launch leaves
+    # its counters zero, so consecutive GEMMs can share it; concurrent streams must not.
+    key = (dev, torch.cuda.current_stream().cuda_stream)
+    ws = _MID_WS.get(key)
+    if ws is None or ws[0].numel() < pbytes.value or ws[1].numel() < ncnt.value:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("gemm_nt_mid: the split-K workspace must exist before graph capture; run the "
+                               "shape once eagerly on the capturing stream's device first")
+        old = ws
+        ws = (torch.empty(max(pbytes.value, 1 << 20, old[0].numel() if old else 0), dtype=torch.uint8, device=a.device),
+              torch.zeros(max(ncnt.value, 4096, old[1].numel() if old else 0), dtype=torch.int32, device=a.device))
+        _MID_WS[key] = ws
+    _lib.check(
+        lib.tdist_gemm_nt_mid(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), M, N, K, ctypes.c_longlong(a.stride(0)),
+                              ctypes.c_longlong(b.stride(0)), ctypes.c_longlong(out.stride(0)), _DT[a.dtype],
+                              mt.value, wn_.value, sp.value, _lib.ptr(ws[0]), _lib.ptr(ws[1]),
+                              _lib.stream_handle()), "tdist_gemm_nt_mid")
     return out
 
 
