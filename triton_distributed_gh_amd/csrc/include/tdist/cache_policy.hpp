@@ -36,6 +36,13 @@ __device__ __forceinline__ void st_wt128_agent(void* p, const __attribute__((ext
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
+// 8-byte form (four 16-bit values: one lane's share of a 16x16 accumulator tile)
+__device__ __forceinline__ void st_wt64_sys(void* p, const uint2& v) {
+  typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+  const u32x2_t d = {v.x, v.y};
+  asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+}
+
 // Every storing wave calls this after its last write-through store and before the workgroup
 // barrier that precedes the flag / counter update.
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

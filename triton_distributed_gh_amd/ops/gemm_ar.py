@@ -18,11 +18,16 @@ from typing import Any, List, Optional
 import torch
 
 from .. import _lib
+import os
+
+from ..autotuner import tuning
 from ..utils.distributed import default_num_ctas, forbid_graph_capture, get_env
 from .gemm import _DT, gemm_nt
 
 EPOCH_MOD = 1 << 30
 _TILE = 256
+# rows up to which the low-latency form (mid-M tile body, two-shot per block, device-side call numbering) runs
+LL_MAX_M = int(os.environ.get("TDIST_GEMM_AR_LL_MAX_M", "256"))
 
 
 @dataclasses.dataclass(repr=False)
@@ -41,6 +46,7 @@ class GemmARContext:
     NUM_COMM_SMS: int = 0
     num_ctas: int = 0
     call_count: int = 0
+    ll: Any = None                         # low-latency form: dict of its buffers (hip back-end only)
 
     # reference attribute names
     @property
@@ -50,6 +56,8 @@ class GemmARContext:
     def check_error(self) -> None:
         if self.scratch is not None and int(self.scratch[4]) != 0:
             raise RuntimeError("gemm_allreduce: a device-side wait timed out")
+        if self.ll is not None and int(self.ll["err"][0]) != 0:
+            raise RuntimeError("gemm_allreduce (low-latency form): a device-side wait timed out")
 
 
 def create_gemm_ar_context(ar_stream, rank, world_size, local_world_size, max_M, N, dtype, MIN_BLOCK_SIZE_M=16,
@@ -66,12 +74,35 @@ def create_gemm_ar_context(ar_stream, rank, world_size, local_world_size, max_M,
         outs.append(heap.create_tensor_list([max_M, N], dtype, zero=False))
         flags.append(heap.create_tensor_list([max(tpo * world_size + tiles, 2 * world_size)], torch.int32, arena="sig"))
     scratch = torch.zeros(8, dtype=torch.int32, device=env.device) if env.backend == "hip" else None
+    ll = _create_ll_buffers(env, world_size, min(max_M, LL_MAX_M), N, dtype) if env.backend == "hip" else None
     if env.backend == "hip":
         torch.cuda.synchronize()
     if env.cpu_group is not None:
         torch.distributed.barrier(group=env.cpu_group)
     return GemmARContext(rank, world_size, max_M, N, dtype, slots, outs, flags, scratch, env, ar_stream,
-                         NUM_COMM_SMS, num_ctas)
+                         NUM_COMM_SMS, num_ctas, 0, ll)
+
+
+def _create_ll_buffers(env, world_size, max_M, N, dtype):
+    """Symmetric slots / outputs / flags (both parities) and the local state of the low-latency form."""
+    import ctypes as C
+
+    be, ms, mb, nc = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    pb = C.c_longlong()
+    _lib.check(_lib.hip().tdist_gemm_ar_ll_sizes(max_M, N, world_size, C.byref(be), C.byref(ms), C.byref(mb),
+                                                 C.byref(pb), C.byref(nc)), "tdist_gemm_ar_ll_sizes")
+    heap = env.heap
+    ll = dict(block_elems=be.value, max_slots=ms.value, max_blocks=mb.value, max_M=max_M, slots=[], outs=[], flags=[])
+    for _ in range(2):
+        ll["slots"].append(heap.create_tensor_list([world_size * ms.value * be.value], dtype, zero=False))
+        ll["outs"].append(heap.create_tensor_list([max_M, N], dtype, zero=False))
+        ll["flags"].append(heap.create_tensor_list([ms.value * world_size + mb.value], torch.int32, arena="sig"))
+    ll["partial"] = torch.empty(pb.value, dtype=torch.uint8, device=env.device)
+    ll["counters"] = torch.zeros(nc.value, dtype=torch.int32, device=env.device)
+    ll["state"] = torch.zeros(4, dtype=torch.int32, device=env.device)     # [0] call number, [1] finished workgroups
+    ll["err"] = torch.zeros(4, dtype=torch.int32, device=env.device)
+    ll["calls"] = 0                                                       # host mirror of state[0] (eager calls)
+    return ll
 
 
 # A separate low-latency context type is unnecessary here; keep the constructor name.
@@ -93,6 +124,8 @@ def gemm_allreduce_op(ctx: GemmARContext, a: torch.Tensor, b: torch.Tensor, gemm
     w, rank = ctx.world_size, ctx.rank
     if w == 1:
         return gemm_nt(a, b)
+    if ctx.ll is not None and M <= ctx.ll["max_M"] and K >= 128 and K % 64 == 0:
+        return _gemm_ar_ll(ctx, a, b, copy_to_local)
     forbid_graph_capture("gemm_allreduce", w)
     parity = ctx.call_count & 1
     epoch = ctx.call_count % EPOCH_MOD + 1
@@ -110,6 +143,36 @@ def gemm_allreduce_op(ctx: GemmARContext, a: torch.Tensor, b: torch.Tensor, gemm
                                  _lib.stream_handle()), "tdist_gemm_ar")
     res = out_sym.view(-1)[: M * N].view(M, N)
     return res.clone() if copy_to_local else res
+
+
+def _gemm_ar_ll(ctx: GemmARContext, a: torch.Tensor, b: torch.Tensor, copy_to_local: bool) -> torch.Tensor:
+    """Low-latency form (csrc/ops/gemm_ar.hip, second half).  Calls are numbered on the device, so the launch
+    may be captured into a HIP graph; the result is then copied by the kernel into a plain tensor whose address
+    does not alternate with the call parity."""
+    ll, env, rank = ctx.ll, ctx.env, ctx.rank
+    M, K = a.shape
+    N = b.shape[0]
+    a = a.contiguous()
+    capturing = torch.cuda.is_current_stream_capturing()
+    local = torch.empty((M, N), dtype=a.dtype, device=a.device) if (copy_to_local or capturing) else None
+    parity = ll["calls"] & 1
+    ll["calls"] += 1
+    cs = env.heap.ctx_struct()
+    _lib.check(
+        _lib.hip().tdist_gemm_ar_ll(ctypes.byref(cs), _lib.ptr(a), _lib.ptr(b), _lib.ptr(ll["slots"][0][rank]),
+                                    _lib.ptr(ll["slots"][1][rank]), _lib.ptr(ll["outs"][0][rank]),
+                                    _lib.ptr(ll["outs"][1][rank]), _lib.ptr(ll["flags"][0][rank]),
+                                    _lib.ptr(ll["flags"][1][rank]), ll["max_slots"], ll["max_blocks"],
+                                    ctypes.c_longlong(ll["block_elems"]), _lib.ptr(ll["partial"]),
+                                    ctypes.c_longlong(ll["partial"].numel()), _lib.ptr(ll["counters"]),
+                                    ll["counters"].numel(), _lib.ptr(ll["err"]), _lib.ptr(ll["state"]),
+                                    _lib.ptr(local) if local is not None else ctypes.c_void_p(0),
+                                    ctypes.c_longlong(a.stride(0)), ctypes.c_longlong(b.stride(0)), M, N, K,
+                                    ctx.num_ctas, tuning.get("gemm_ar.WN", 0), tuning.get("gemm_ar.SPLITS", 0),
+                                    _DT[a.dtype], _lib.stream_handle()), "tdist_gemm_ar_ll")
+    if local is not None:
+        return local
+    return ll["outs"][parity][rank].view(-1)[: M * N].view(M, N)
 
 
 def _gemm_ar_host(ctx, a, b, parity, epoch, copy_to_local):
