@@ -32,6 +32,7 @@ struct DecodeArgs {
   int page_size, page_shift;  // page_shift >= 0 when page_size is a power of two
   int q_heads, kv_heads, splits;
   int fused;                  // 0: partials only, 1: merged 16-bit out, 2: merged fp32 out + LSE column
+  int deep;                   // 1: two register sets (loads one block ahead): throughput launches, many workgroups per CU
   float sm_scale, soft_cap;
 };
 
@@ -45,6 +46,19 @@ __device__ __forceinline__ long long slot_of(const DecodeArgs& a, const int* tab
 }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// K / V rows are read exactly once per call.  Non-temporal loads were measured (TDIST_FDEC_NT_LOADS at build
+// time): 301 us against 289 us for plain loads at batch 64 x 4096 tokens - the L1 miss queue, not cache
+// pollution, is the limit - so plain loads stay.
+__device__ __forceinline__ uint4 ld_stream16(const uint16_t* p) {
+#ifndef TDIST_FDEC_NT_LOADS
+  return *(const uint4*)p;
+#else
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  const u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
+  return uint4{v.x, v.y, v.z, v.w};
+#endif
+}
 
 template <bool IS_BF16>
 __device__ __forceinline__ uint16_t to16(float f) {
@@ -164,40 +178,55 @@ __device__ __forceinline__ void decode_split_body(const DecodeArgs& a, const int
   const uint16_t* kbase = a.k_cache + (long long)kvh * a.k_stride_h + lg * 8;
   const uint16_t* vbase = a.v_cache + (long long)kvh * a.v_stride_h + li * NDV;
 
-  for (int n0 = start + wave * 32; n0 < end; n0 += 128) {
-    // ---- issue all loads of this block (16 x 16 B per lane for D = 128)
-    uint4 kreg[2][KS];
+  // Pages of a power-of-two size >= 32 tokens: a wave's 32-token block (32-aligned) lies in ONE page, so the
+  // page index is a single wave-uniform (scalar) look-up per block, fetched one block ahead, instead of ten
+  // per-lane look-ups through the vector L1 in front of the sixteen K / V loads that depend on them.
+  const bool one_page = a.page_shift >= 5;
+  auto block_slot0 = [&](int n0) -> long long {     // slot of token n0 (wave-uniform)
+    const int n0u = __builtin_amdgcn_readfirstlane(n0);
+    const int page = table[n0u >> a.page_shift];
+    return ((long long)page << a.page_shift) + (n0u & (a.page_size - 1));
+  };
+  // One 32-token block of K and V in registers (16 x 16 bytes per lane for D = 128).
+  struct KVBlock {
+    uint4 k[2][KS];
+    uint32_t v[8][VW];
+  };
+  auto load_block = [&](int n0, long long slot0, KVBlock& r) {
+    auto slot_in_block = [&](int tok) -> long long {      // tok in [n0, n0 + 32), already clamped to kv_len - 1
+      return one_page ? slot0 + (tok - n0) : slot_of(a, table, tok);
+    };
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
       const int tok = min(n0 + 16 * blk + li, kv_len - 1);
-      const uint16_t* kp = kbase + slot_of(a, table, tok) * a.k_stride_slot;
+      const uint16_t* kp = kbase + slot_in_block(tok) * a.k_stride_slot;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) kreg[blk][s] = *(const uint4*)(kp + 32 * s);
+      for (int s = 0; s < KS; ++s) r.k[blk][s] = ld_stream16(kp + 32 * s);
     }
-    uint32_t vreg[8][VW];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int tok = min(n0 + 16 * (t >> 2) + 4 * lg + (t & 3), kv_len - 1);
-      const uint16_t* vp = vbase + slot_of(a, table, tok) * a.v_stride_slot;
+      const uint16_t* vp = vbase + slot_in_block(tok) * a.v_stride_slot;
       if constexpr (VW >= 4) {
 #pragma unroll
         for (int c = 0; c < VW / 4; ++c) {
-          const uint4 v = *(const uint4*)(vp + 8 * c);
-          vreg[t][4 * c] = v.x, vreg[t][4 * c + 1] = v.y, vreg[t][4 * c + 2] = v.z, vreg[t][4 * c + 3] = v.w;
+          const uint4 v = ld_stream16(vp + 8 * c);
+          r.v[t][4 * c] = v.x, r.v[t][4 * c + 1] = v.y, r.v[t][4 * c + 2] = v.z, r.v[t][4 * c + 3] = v.w;
         }
       } else {
         const uint2 v = *(const uint2*)vp;
-        vreg[t][0] = v.x, vreg[t][1] = v.y;
+        r.v[t][0] = v.x, r.v[t][1] = v.y;
       }
     }
-
+  };
+  auto compute_block = [&](int n0, const KVBlock& r) {
     // ---- S^T = K . Q^T  (lane: head li, tokens 16 blk + 4 lg + i)
     f32x4 st[2];
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
       st[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < KS; ++s) st[blk] = F::mfma(__builtin_bit_cast(VT, kreg[blk][s]), qreg[s], st[blk]);
+      for (int s = 0; s < KS; ++s) st[blk] = F::mfma(__builtin_bit_cast(VT, r.k[blk][s]), qreg[s], st[blk]);
     }
     float sc[8];
     float mx = -INFINITY;
@@ -232,11 +261,36 @@ __device__ __forceinline__ void decode_split_body(const DecodeArgs& a, const int
       const uint32_t sel = (j & 1) ? 0x07060302u : 0x05040100u;
       uint32_t vw[4];
 #pragma unroll
-      for (int p = 0; p < 4; ++p) vw[p] = __builtin_amdgcn_perm(vreg[2 * p + 1][j >> 1], vreg[2 * p][j >> 1], sel);
+      for (int p = 0; p < 4; ++p) vw[p] = __builtin_amdgcn_perm(r.v[2 * p + 1][j >> 1], r.v[2 * p][j >> 1], sel);
       f32x4 c = acc[j];
 #pragma unroll
       for (int i = 0; i < 4; ++i) c[i] *= alpha;
       acc[j] = F::mfma(__builtin_bit_cast(VT, uint4{vw[0], vw[1], vw[2], vw[3]}), pfrag, c);
+    }
+  };
+  // Software pipeline over two register sets: the loads of block i + 1 are issued before block i is
+  // multiplied (D <= 128; at D = 256 a second set would not fit two waves per SIMD).  Batch 64 x 4096 tokens:
+  // 190-198 us against 204-211 us without it.  Latency launches (about one workgroup per CU: long-context
+  // decode of one sequence cut into many splits) keep the single set - 33.8 against 37.0 us at 1 x 32768.
+  constexpr bool DOUBLE = D <= 128;
+  int n0 = start + wave * 32;
+  if (DOUBLE && a.deep) {
+    KVBlock ra, rb;
+    if (n0 < end) load_block(n0, one_page ? block_slot0(n0) : 0, ra);
+    while (n0 < end) {
+      if (n0 + 128 < end) load_block(n0 + 128, one_page ? block_slot0(n0 + 128) : 0, rb);
+      compute_block(n0, ra);
+      n0 += 128;
+      if (n0 >= end) break;
+      if (n0 + 128 < end) load_block(n0 + 128, one_page ? block_slot0(n0 + 128) : 0, ra);
+      compute_block(n0, rb);
+      n0 += 128;
+    }
+  } else {
+    for (; n0 < end; n0 += 128) {
+      KVBlock r;
+      load_block(n0, one_page ? block_slot0(n0) : 0, r);
+      compute_block(n0, r);
     }
   }
 
