@@ -303,12 +303,11 @@ def test_model_modes_match_single_rank(name, mode, w):
         vc.close()
 
 
-@pytest.mark.parametrize("mode", ["triton_dist_AR"])
+@pytest.mark.parametrize("mode", ["triton_dist_AR", "triton_dist_gemm_ar", "triton_dist"])
 def test_fused_backend_decode_replays_from_graph(mode):
-    """World size 2: each rank captures ONE decode step and replays it; the all-reduce kernels
-    advance their call number on the device, so every replay matches the single-rank model.
-    (``triton_dist`` is not captured at decode shapes: AG-GEMM / GEMM-RS refuse capture when a
-    rank's rows are not whole 256-row tiles.)"""
+    """World size 2: each rank captures ONE decode step and replays it; the all-reduce kernels and the
+    low-latency forms of GEMM + all-reduce / AG + GEMM / GEMM + RS advance their call number on the device,
+    so every replay matches the single-rank model."""
     name, w, bsz, prompt, L, steps = "tdist/tiny-dense", 2, 4, 16, 128, 4
     sharded = mode == "triton_dist"
     per = bsz // w
@@ -334,6 +333,8 @@ def test_fused_backend_decode_replays_from_graph(mode):
             m.set_fwd(mode)
         if sharded:
             vc.collective(lambda r, env: models[r].init_triton_dist_ctx(max_M=bsz * prompt))
+        elif mode == "triton_dist_gemm_ar":
+            vc.collective(lambda r, env: models[r].init_triton_dist_gemm_ar_ctx(max_M=bsz * prompt))
         else:
             vc.collective(lambda r, env: models[r].init_triton_dist_AR_ctx(max_M=bsz * prompt))
         torch.cuda.synchronize()

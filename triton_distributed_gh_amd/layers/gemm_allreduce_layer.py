@@ -27,10 +27,7 @@ class GemmARLayer(torch.nn.Module):
         self.use_ll_kernel = use_ll_kernel
         self.copy_to_local = copy_to_local
         self.persistent = persistent
-        num_ctas = 0
-        if use_ll_kernel:
-            tiles = ((max_M + 255) // 256) * ((N + 255) // 256)
-            num_ctas = max(8, min(256, 2 * tiles))
+        num_ctas = 0        # the kernels size their grids themselves (ranks sharing one GPU split its CUs)
         self.ctx = create_gemm_ar_context(None, self.rank, self.world_size, local_world_size, max_M, N, output_dtype,
                                           NUM_COMM_SMS=NUM_COMM_SMS, num_ctas=num_ctas, env=env)
 

@@ -31,6 +31,7 @@ import torch
 from .. import _lib
 from ..autotuner import tuning
 from ..utils.distributed import default_num_ctas, forbid_graph_capture, get_env
+from . import tp_ll
 from .gemm import _DT, gemm_nt
 
 EPOCH_MOD = 4093
@@ -73,6 +74,7 @@ class AllGatherGEMMTensorParallelContext:
     # were outgrown before that are parked here instead of being freed while launches may be queued.
     captured: bool = False
     retired: List[torch.Tensor] = dataclasses.field(default_factory=list)
+    ll: Any = None                              # low-latency form for decode-sized calls (ops/tp_ll.py)
 
     # names the reference exposes on its context
     @property
@@ -84,6 +86,7 @@ class AllGatherGEMMTensorParallelContext:
         return self.flags[self.call_count & 1]
 
     def check_error(self) -> None:
+        tp_ll.check_error(self.ll, "ag_gemm")
         code = int(self.scratch[0]) if self.scratch is not None else 0
         if code & 4:
             raise RuntimeError("ag_gemm: a flag held a value that belongs to no call that may touch this parity "
@@ -123,6 +126,9 @@ def create_ag_gemm_intra_node_context(max_M, N, K, input_dtype, output_dtype, ra
             n_streams = num_ranks - 1 if producer == "copy_engine" else 1
             ag_streams = [torch.cuda.Stream(priority=-1) for _ in range(n_streams)]
         torch.cuda.synchronize()
+    ll = tp_ll.create_ll_state(env, num_ranks, max_M, N, K, input_dtype, "ag") if producer == "kernel" else None
+    if env.backend == "hip":
+        torch.cuda.synchronize()
     if env.cpu_group is not None:
         torch.distributed.barrier(group=env.cpu_group)
     return AllGatherGEMMTensorParallelContext(
@@ -131,7 +137,7 @@ def create_ag_gemm_intra_node_context(max_M, N, K, input_dtype, output_dtype, ra
         M_PER_CHUNK=M_PER_CHUNK, BLOCK_M=BLOCK_M, BLOCK_N=BLOCK_N, BLOCK_K=BLOCK_K, stages=stages, autotune=autotune,
         producer=producer,
         flag_mode=os.environ.get("TDIST_AG_FLAG_MODE", "write_value" if env.shared_gpu else "memcpy"),
-        num_ctas=num_ctas, backend=env.backend, state=state)
+        num_ctas=num_ctas, backend=env.backend, state=state, ll=ll)
 
 
 def _rows_per_chunk(M_per_rank: int, want: int) -> int:
@@ -192,6 +198,9 @@ def ag_gemm_intra_node_op(a, b, c, ctx: AllGatherGEMMTensorParallelContext):
     if w == 1 and os.environ.get("TDIST_FORCE_FUSED", "0") != "1":
         gemm_nt(a, b, out=c)
         return c
+    if w > 1 and tp_ll.ll_applies(ctx.ll, M_per_rank * w, N_local, K, a, b) and not DEBUG_RACES:
+        # decode-sized call: mid-M tile body, device-side call numbering, capturable (ops/tp_ll.py)
+        return tp_ll.ag_gemm_ll(ctx.ll, env, rank, a, b, c, ctx.num_ctas)
     a = a.contiguous()
     # The in-kernel producer numbers its calls on the device (ctx.state); every other producer takes
     # parity and epoch from the host and must not be captured in a graph.

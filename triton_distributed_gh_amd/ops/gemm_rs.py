@@ -23,6 +23,7 @@ import torch
 from .. import _lib
 from ..autotuner import tuning
 from ..utils.distributed import default_num_ctas, forbid_graph_capture, get_env
+from . import tp_ll
 from .gemm import _DT, gemm_nt
 
 EPOCH_MOD = 4093
@@ -47,6 +48,7 @@ class GEMMReduceScatterTensorParallelContext:
     call_count: int = 0
     backend: str = "hip"
     state: Optional[torch.Tensor] = None       # HIP path: device-side [call number, finished workgroups]
+    ll: Any = None                             # low-latency form for decode-sized calls (ops/tp_ll.py)
 
     @property
     def scatter_bufs(self):
@@ -57,6 +59,7 @@ class GEMMReduceScatterTensorParallelContext:
         return self.flags[self.call_count & 1]
 
     def check_error(self) -> None:
+        tp_ll.check_error(self.ll, "gemm_rs")
         code = int(self.scratch[-4]) if self.scratch is not None else 0
         if code & 4:
             raise RuntimeError("gemm_rs: a flag held a value that belongs to no call that may touch this parity "
@@ -88,13 +91,16 @@ def create_gemm_rs_intra_node_context(max_M, N, output_dtype, rank, num_ranks, t
         # value from it (csrc/include/tdist/call_state.hpp) - launches are replay-safe
         state = torch.zeros(4, dtype=torch.int32, device=env.device)
         torch.cuda.synchronize()
+    ll = tp_ll.create_ll_state(env, num_ranks, max_M, N, 0, output_dtype, "rs")
+    if env.backend == "hip":
+        torch.cuda.synchronize()
     if env.cpu_group is not None:
         torch.distributed.barrier(group=env.cpu_group)
     return GEMMReduceScatterTensorParallelContext(rank=rank, num_ranks=num_ranks, max_M=max_M, N=N,
                                                   output_dtype=output_dtype, scatter=scatter, flags=flags,
                                                   scratch=scratch, env=env, fuse_scatter=fuse_scatter,
                                                   transpose_weight=transpose_weight, M_PER_CHUNK=M_PER_CHUNK,
-                                                  num_ctas=num_ctas, backend=env.backend, state=state)
+                                                  num_ctas=num_ctas, backend=env.backend, state=state, ll=ll)
 
 
 def _rows_per_chunk(M_per_rank: int, want: int) -> int:
@@ -117,6 +123,10 @@ def gemm_rs_intra_node_op(a, b, ctx: GEMMReduceScatterTensorParallelContext, out
     if w == 1 and os.environ.get("TDIST_FORCE_FUSED", "0") != "1":
         gemm_nt(a, b, out=out)
         return out
+    if tp_ll.ll_applies(ctx.ll, M, N, K_local, a, b) and not DEBUG_RACES and out.stride(1) == 1 \
+            and out.stride(0) % 8 == 0 and out.data_ptr() % 16 == 0:
+        # decode-sized call: mid-M tile body, device-side call numbering, capturable (ops/tp_ll.py)
+        return tp_ll.gemm_rs_ll(ctx.ll, env, rank, w, a, b, out, ctx.num_ctas)
     # Capture is accepted for the configuration covered by the replay tests (whole 256-row tiles
     # per rank); the kernels number their calls on the device either way.
     if ctx.backend != "hip" or (M_per_rank % 256 != 0 and os.environ.get("TDIST_ALLOW_STRADDLE_CAPTURE") != "1"):
