@@ -64,7 +64,10 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     # 256x256 tiles lies a band (17 .. a few hundred rows, or few column tiles) where the big tile leaves
     # most CUs idle: the weight-streaming mid-M kernel with split-K (csrc/ops/gemm_mid.hip) takes it.
     # TDIST_MID_GEMM=lib hands the band to the library instead (A/B comparisons).
-    if M > 16 and -(-M // 256) * -(-N // 256) < 128 and variant == GEMM_VARIANT:
+    # Up to 64 rows the mid-M kernel also beats the 256x256 tile at any width (LM heads: 42 vs 76 us at
+    # 32768 x 4096, 144 vs 173 us at 151936 x 2048), up to 128 rows below ~100k columns.
+    if M > 16 and variant == GEMM_VARIANT and (-(-M // 256) * -(-N // 256) < 128 or M <= 64
+                                               or (M <= 128 and N < 100_000)):
         if MID_GEMM == "lib" and not force_native:
             torch.matmul(a, b.t(), out=out)
             return out
