@@ -13,10 +13,13 @@
 // (topk reduce + reduce-scatter), kernels/nvidia/threadblock_swizzle_ag_moe.cu (tile order by
 // arrival stage: here tiles are simply SORTED by the last source rank they need, in arrival
 // order, on the device side of `moe_align`).
+#include "tdist/ag_push.hpp"
 #include "tdist/cache_policy.hpp"
 #include "tdist/common.hpp"
 #include "tdist/gemm_gfx950.hpp"
 #include "tdist/primitives.hpp"
+#include "tdist/wg_trace.hpp"
+#include "tdist/work_queue.hpp"
 
 using namespace tdist;
 using namespace tdist::gemm;
@@ -129,60 +132,103 @@ struct GroupGemmParams {
   const int* meta;            // meta[0] = number of 256-row blocks
   const float* row_scale;     // [n] routing weight of flat pair i, or null
   const int* flags;           // arrival flags [w * cpr] (epoch valued) or null
-  int* ticket;
+  int* ticket;                // [8] queue tickets, then [cpr] producer counters; zero at launch
   int* err;
   long long lda, ldb, ldo, b_expert_stride;
   int N, K;
   int topk;                   // A row of flat pair i: a_mode 0 -> i / topk (token row), 1 -> i
   int a_mode;
   int cpr, epoch;
+  // In-kernel all-gather producer (AG + MoE, tdist/ag_push.hpp): the first push_wgs workgroups store this
+  // rank's shard into every rank's workspace (the own one included - tiles read every row from there) before
+  // they join the consumers.  push_wgs == 0: the data comes from elsewhere.
+  SymmCtx ctx;
+  const uint16_t* a_local;
+  long long lda_local;
+  uint16_t* ws;               // symmetric [M, K] workspace of this call = A
+  int* push_flags;            // = flags, as the symmetric pointer the producers store through
+  int* push_done;
+  int M_per_rank, rows_per_chunk, rank, world, push_wgs, straddle, race_debug;
+  WgTrace trace;              // tdist/wg_trace.hpp (off unless the host armed a sink)
 };
 
-constexpr int GG_TICKET = LDS_BYTES;        // int ticket
-constexpr int GG_ROWS = LDS_BYTES + 16;     // int[256] gather rows, then int[256] out rows, float[256] scales
+struct GroupCall {
+  uint16_t* ws;
+  int* flags;
+  int epoch;
+};
+
+constexpr int GG_TICKET = LDS_BYTES;        // 16 bytes: work-queue mailboxes
+constexpr int GG_ROWS = LDS_BYTES + 16;     // two sets of: int[256] gather rows, int[256] out rows, float[256] scales
 
 template <bool IS_BF16>
 __global__ __launch_bounds__(THREADS, 2) void moe_group_gemm_kernel(GroupGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   volatile int* s_ticket = (volatile int*)(smem + GG_TICKET);
-  int* s_arow = (int*)(smem + GG_ROWS);
-  int* s_orow = s_arow + BM;
-  float* s_scale = (float*)(s_orow + BM);
   const int num_pid_n = (p.N + BN - 1) / BN;
   const int nblocks = p.meta[0];
-  // Eight ticket queues, one per XCD (workgroups are dealt to the XCDs round-robin by index): queue q
-  // holds the row blocks bi with bi % 8 == q, all column tiles of a block on consecutive tickets.  The
-  // workgroups of one XCD therefore share a handful of A row blocks and one or two experts' B panels
-  // in their L2 instead of a random 1/8 of everything; a workgroup whose queue has run dry moves on
-  // to the next XCD's queue, so the tail is still balanced dynamically.
-  const int xcd = blockIdx.x & 7;
-  int hop = 0;
-  while (true) {
-    int q = 0, local = 0;
-    for (; hop < 8; ++hop) {
-      q = (xcd + hop) & 7;
-      const int qsize = q < nblocks ? ((nblocks - q + 7) >> 3) * num_pid_n : 0;
-      if (qsize == 0) continue;
-      local = fetch_ticket_block(p.ticket + q, s_ticket);
-      if (local < qsize) break;
+  // Eight work queues, one per XCD (tdist/work_queue.hpp): queue q holds the row blocks bi with bi % 8 == q,
+  // all column tiles of a block on consecutive items.  The workgroups of one XCD therefore share a handful
+  // of A row blocks and one or two experts' B panels in their L2 instead of a random 1/8 of everything; the
+  // first item of every workgroup is static, later ones are drawn ahead of the main loop, and a workgroup
+  // whose queue has run dry moves on to one that has not.
+  auto queue_size = [=](int q) { return q < nblocks ? ((nblocks - q + 7) >> 3) * num_pid_n : 0; };
+  WorkQueues<decltype(queue_size)> wq(p.ticket, s_ticket, p.push_wgs, queue_size);
+  int local = 0;
+  bool have;
+  WgTraceCursor tr = wg_trace_begin(p.trace);
+  wg_trace(tr, 1, 0);
+  if ((int)blockIdx.x < p.push_wgs) {
+    const GroupCall cv{p.ws, p.push_flags, p.epoch};
+    push_item(p, cv, (int)blockIdx.x);
+    wg_trace(tr, 6, 0);
+    have = wq.next(local);
+  } else {
+    have = wq.first(local);
+    if (!have) have = wq.next(local);
+  }
+  // Row tables of an item (gather row, output row, routing weight per tile row) are fetched into registers
+  // as soon as the item is known - for all but the first that is before the PREVIOUS item's epilogue, whose
+  // stores then cover the two dependent look-ups (sorted id, then weight) - and written to LDS at the top.
+  int it = 0;
+  int t_flat = -1;
+  float t_scale = 1.f;
+  auto fetch_tables = [&](int item_local, int item_q) {
+    const int bl = item_local / num_pid_n;
+    const int bi = bl * 8 + item_q;
+    const int b = p.order ? p.order[bi] : bi;
+    if (threadIdx.x < BM) {
+      t_flat = p.sorted_ids[b * BM + threadIdx.x];
+      t_scale = (t_flat >= 0 && p.row_scale) ? p.row_scale[t_flat] : 1.f;
     }
-    if (hop == 8) break;
+  };
+  if (have) fetch_tables(local, wq.q);
+  while (have) {
+    const int q = wq.q;
     const int bl = local / num_pid_n, pid_n = local - bl * num_pid_n;
     const int bi = bl * 8 + q;
     const int b = p.order ? p.order[bi] : bi;
     const int e = p.expert_of_block[b];
+    // Two sets in turn: the epilogue of item i still reads its set while a faster wave already fills the
+    // other one for item i + 1 (set i is rewritten for item i + 2, behind the main-loop barriers of i + 1).
+    int* s_arow = (int*)(smem + GG_ROWS) + (it & 1) * 3 * BM;
+    int* s_orow = s_arow + BM;
+    float* s_scale = (float*)(s_orow + BM);
+    ++it;
     if (threadIdx.x < BM) {
-      const int flat = p.sorted_ids[b * BM + threadIdx.x];
-      s_arow[threadIdx.x] = flat < 0 ? -1 : (p.a_mode == 0 ? flat / p.topk : flat);
-      s_orow[threadIdx.x] = flat;
-      s_scale[threadIdx.x] = (flat >= 0 && p.row_scale) ? p.row_scale[flat] : 1.f;
+      s_arow[threadIdx.x] = t_flat < 0 ? -1 : (p.a_mode == 0 ? t_flat / p.topk : t_flat);
+      s_orow[threadIdx.x] = t_flat;
+      s_scale[threadIdx.x] = t_scale;
     }
+    wg_trace(tr, 2, b);
+    wq.prefetch();
     if (p.flags && p.seg_range) {
       const int f0 = p.seg_range[2 * b] * p.cpr, f1 = (p.seg_range[2 * b + 1] + 1) * p.cpr;
       wait(p.flags + f0, f1 - f0, SCOPE_SYS, SEM_ACQUIRE, p.epoch, p.err);
     } else {
       __syncthreads();
     }
+    wg_trace(tr, 3, b);
     TileArgs t;
     t.A = p.A;
     t.B = p.B + (long long)e * p.b_expert_stride + (long long)pid_n * BN * p.ldb;
@@ -193,7 +239,14 @@ __global__ __launch_bounds__(THREADS, 2) void moe_group_gemm_kernel(GroupGemmPar
     t.K = p.K;
     t.a_gather = s_arow;
     Acc<IS_BF16> acc;
-    mainloop_256_2ph<IS_BF16>(t, smem, acc);
+    // accumulator columns permuted (PERM_B): the tile is stored straight from registers, and the next item
+    // is looked up before the stores so that no barrier follows them (see ops/ag_gemm.hip)
+    mainloop_256_2ph<IS_BF16, true, 3>(t, smem, acc);
+    wg_trace(tr, 4, b);
+    wq.stash();
+    int next_local = 0;
+    const bool have_next = wq.next(next_local);
+    if (have_next) fetch_tables(next_local, wq.q);
     if (p.row_scale) {
       // accumulator layout: lane holds tile-row (l & 15) of each 16-row block
       const int w_ = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -208,11 +261,15 @@ __global__ __launch_bounds__(THREADS, 2) void moe_group_gemm_kernel(GroupGemmPar
     const int nrem = p.N - pid_n * BN;
     uint16_t* obase = p.out + pid_n * BN;
     const long long ldo = p.ldo;
-    epilogue_256<IS_BF16>(acc, smem, [&](int r, int c, const uint4& v) {
+    epilogue_256_direct<IS_BF16>(acc, [&](int r, int c, const uint4& v) {
       const int orow = s_orow[r];
       if (orow >= 0 && c < nrem) *(uint4*)(obase + (long long)orow * ldo + c) = v;
     });
+    wg_trace(tr, 5, b);
+    have = have_next;
+    local = next_local;
   }
+  wg_trace(tr, 7, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -353,11 +410,17 @@ TDIST_API int tdist_moe_align(const int* topk_ids, int* sorted_ids, int* expert_
   return 0;
 }
 
+// `ticket`: 8 + cpr zero-initialisable ints (queue tickets, then the producer's per-chunk counters).
+// Producer (AG + MoE): ctx / a_local / ws / M_per_rank / rows_per_chunk / push_wgs describe the in-kernel
+// all-gather (push_wgs == 0 or ctx == null: no producer); `flags` is then also the symmetric flag array the
+// producers raise on every rank.
 TDIST_API int tdist_moe_group_gemm(const void* A, const void* B, void* out, const int* sorted_ids,
                                    const int* expert_of_block, const int* seg_range, const int* order, const int* meta,
                                    const float* row_scale, const int* flags, int* ticket, int* err, long long lda,
                                    long long ldb, long long ldo, long long b_expert_stride, int N, int K, int topk,
-                                   int a_mode, int cpr, int epoch, int num_ctas, int dtype, void* stream) {
+                                   int a_mode, int cpr, int epoch, int num_ctas, int dtype, void* stream,
+                                   const tdist::SymmCtx* ctx, const void* a_local, long long lda_local, void* ws,
+                                   int M_per_rank, int rows_per_chunk, int push_wgs) {
   TDIST_REQUIRE(K >= 128 && K % 64 == 0, "K must be a multiple of 64 and >= 128");
   TDIST_REQUIRE(N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldo % 8 == 0, "N/lda/ldb/ldo must be multiples of 8");
   GroupGemmParams p;
@@ -383,15 +446,56 @@ TDIST_API int tdist_moe_group_gemm(const void* A, const void* B, void* out, cons
   p.a_mode = a_mode;
   p.cpr = cpr;
   p.epoch = epoch;
-  const int lds = LDS_BYTES + 16 + 3 * BM * 4;
+  static int num_cus = 0;
+  if (!num_cus) {
+    int dev = 0;
+    TDIST_HIP_TRY(hipGetDevice(&dev));
+    TDIST_HIP_TRY(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  // the whole grid must be resident: consumers spin on flags that the producers of this launch raise
+  int grid = num_ctas > 0 ? num_ctas : num_cus;
+  if (grid > num_cus) grid = num_cus;
+  p.push_wgs = 0;
+  p.a_local = nullptr;
+  p.ws = nullptr;
+  p.push_flags = nullptr;
+  p.push_done = ticket + 8;
+  p.lda_local = 0;
+  p.M_per_rank = p.rows_per_chunk = 0;
+  p.rank = p.world = 0;
+  p.straddle = 1;
+  p.race_debug = 0;
+  p.trace = wg_trace_sink();
+  size_t counter_ints = 8;
+  if (ctx && push_wgs > 0 && ctx->num_ranks > 1) {
+    TDIST_REQUIRE(a_local && ws && flags && M_per_rank > 0 && rows_per_chunk > 0 && M_per_rank % rows_per_chunk == 0,
+                  "bad producer arguments");
+    TDIST_REQUIRE(lda == K && lda_local % 8 == 0, "the in-kernel producer needs a dense [M, K] workspace");
+    TDIST_REQUIRE((((uintptr_t)a_local | (uintptr_t)ws) & 15) == 0, "producer operands must be 16-byte aligned");
+    p.ctx = *ctx;
+    p.a_local = (const uint16_t*)a_local;
+    p.lda_local = lda_local;
+    p.ws = (uint16_t*)ws;
+    p.push_flags = (int*)flags;
+    p.M_per_rank = M_per_rank;
+    p.rows_per_chunk = rows_per_chunk;
+    p.rank = ctx->rank;
+    p.world = ctx->num_ranks;
+    p.push_wgs = push_wgs < 64 ? push_wgs : 64;
+    if (p.push_wgs >= grid) p.push_wgs = grid > 1 ? grid - 1 : 1;
+    counter_ints += (size_t)(M_per_rank / rows_per_chunk);
+  } else {
+    p.ctx.rank = 0;
+    p.ctx.num_ranks = 1;
+  }
+  const int lds = LDS_BYTES + 16 + 2 * 3 * BM * 4;
   static bool attr_set = false;
   if (!attr_set) {
     TDIST_HIP_TRY(hipFuncSetAttribute((const void*)moe_group_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     TDIST_HIP_TRY(hipFuncSetAttribute((const void*)moe_group_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  TDIST_HIP_TRY(hipMemsetAsync(ticket, 0, 32, (hipStream_t)stream));   // eight queue counters
-  const int grid = num_ctas > 0 ? num_ctas : 256;
+  TDIST_HIP_TRY(hipMemsetAsync(ticket, 0, counter_ints * sizeof(int), (hipStream_t)stream));
   if (dtype == 0)
     hipLaunchKernelGGL(moe_group_gemm_kernel<true>, dim3(grid), dim3(THREADS), lds, (hipStream_t)stream, p);
   else

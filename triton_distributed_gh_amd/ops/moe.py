@@ -23,6 +23,7 @@ import torch
 
 from .. import _lib
 from ..utils.distributed import default_num_ctas, forbid_graph_capture, get_env
+from ..autotuner import tuning
 from .ag_gemm import (AllGatherGEMMTensorParallelContext, EPOCH_MOD, _push_kernel, _rows_per_chunk,
                       create_ag_gemm_intra_node_context)
 from .gemm import _DT
@@ -178,7 +179,9 @@ def create_ag_group_gemm_context(max_ntokens, N_per_rank, K, num_experts, topk, 
     num_ctas = default_num_ctas(env, num_ranks, num_ctas)
     ag = create_ag_gemm_intra_node_context(max_ntokens, N_per_rank, K, dtype, dtype, rank, num_ranks,
                                            producer="kernel", num_ctas=num_ctas, ag_streams=ag_streams, env=env)
-    tickets = torch.zeros(8, dtype=torch.int32, device=env.device) if env.backend == "hip" else None
+    # eight work-queue tickets, then the in-kernel producer's per-chunk counters (csrc/ops/moe.hip)
+    max_chunks = max(1, (max_ntokens // num_ranks + 15) // 16)
+    tickets = torch.zeros(8 + max_chunks, dtype=torch.int32, device=env.device) if env.backend == "hip" else None
     return MoEAllGatherGroupGEMMTensorParallelContext(ag, num_experts, topk, N_per_rank, K, rank, num_ranks, env, num_ctas,
                                                       tickets)
 
@@ -206,15 +209,18 @@ def ag_group_gemm(a: torch.Tensor, b: torch.Tensor, ctx: MoEAllGatherGroupGEMMTe
     ag.call_count += 1
     rpc = _rows_per_chunk(M_per_rank, ag.M_PER_CHUNK)
     cur = torch.cuda.current_stream()
+    push_wgs = 0
     if w > 1:
-        # The push runs on the SAME stream, ahead of the grouped GEMM: the GEMM's workgroups fill
-        # every CU's register file, so a push kernel on another stream that reached the GPU after
-        # them could never start while they spin on the peers' flags.  Own push first, then compute
-        # while the peers' shards are still arriving.  (own shard goes into the workspace too)
-        _push_kernel(ag, a, parity, epoch, rpc, True, cur)
+        # The all-gather rides in the grouped GEMM's launch: its first push_wgs workgroups store this rank's
+        # shard into every rank's workspace (the own one too - tiles read every row from there) and then join
+        # the consumers, which start on the own-shard blocks at once.  (A separate push kernel in front of the
+        # GEMM cost 80 us before the first tile; one on another stream could never start once the GEMM's
+        # workgroups, which fill every CU's register file, spin on the peers' flags.)
         A, flags = ag.workspaces[parity][rank], ag.flags[parity][rank]
+        push_wgs = tuning.get("ag_moe.PUSH_WGS", 0) or max(8, min(32, 8 * (w - 1)))
     else:
         A, flags = a, None
+    cs = env.heap.ctx_struct() if w > 1 else None
     _lib.check(
         _lib.hip().tdist_moe_group_gemm(_lib.ptr(A), _lib.ptr(b), _lib.ptr(out), _lib.ptr(idx.sorted_ids),
                                         _lib.ptr(idx.expert_of_block), _lib.ptr(idx.seg_range) if w > 1 else None,
@@ -222,8 +228,10 @@ def ag_group_gemm(a: torch.Tensor, b: torch.Tensor, ctx: MoEAllGatherGroupGEMMTe
                                         _lib.ptr(flags), _lib.ptr(ctx.tickets), _lib.ptr(ag.scratch),
                                         ctypes.c_longlong(A.stride(0)), ctypes.c_longlong(b.stride(1)),
                                         ctypes.c_longlong(out.stride(0)), ctypes.c_longlong(b.stride(0)), N, K, topk, 0,
-                                        M_per_rank // rpc, epoch, ctx.num_ctas, _DT[a.dtype], _lib.stream_handle(cur)),
-        "tdist_moe_group_gemm")
+                                        M_per_rank // rpc, epoch, ctx.num_ctas, _DT[a.dtype], _lib.stream_handle(cur),
+                                        ctypes.byref(cs) if cs is not None else None, _lib.ptr(a),
+                                        ctypes.c_longlong(a.stride(0)), _lib.ptr(A) if w > 1 else None, M_per_rank, rpc,
+                                        push_wgs), "tdist_moe_group_gemm")
     return out
 
 
@@ -345,7 +353,8 @@ def run_moe_reduce_rs(x: torch.Tensor, weights: torch.Tensor, chosen_experts: to
                                  _lib.ptr(ctx.scratch[48:]), _lib.ptr(ctx.scratch[40:]), ctypes.c_longlong(x.stride(0)),
                                  ctypes.c_longlong(b.stride(1)), ctypes.c_longlong(gemm_out.stride(0)),
                                  ctypes.c_longlong(b.stride(0)), N, K, topk, 1, 1, 0, ctx.num_ctas, _DT[x.dtype],
-                                 _lib.stream_handle()), "tdist_moe_group_gemm")
+                                 _lib.stream_handle(), None, None, ctypes.c_longlong(0), None, 0, 0, 0),
+        "tdist_moe_group_gemm")
     if w == 1:
         from .moe import reduce_topk as _rt
 
