@@ -126,7 +126,9 @@ __device__ __forceinline__ void merge_rows(const float* part, long long stride, 
 
 // Split-KV body for work item (batch b, head block by, split z); writes the normalised partial row
 // (+ LSE) of every head of the block.  `smem` needs (128 + 64 * D) floats; 256 threads.
-template <bool IS_BF16, int D>
+// ALLOW_DEEP = false compiles the single-register-set loop only (the mega kernel: its task interpreter must
+// keep two workgroups per CU resident, and the second set costs 56 VGPRs).
+template <bool IS_BF16, int D, bool ALLOW_DEEP = true>
 __device__ __forceinline__ void decode_split_body(const DecodeArgs& a, const int b, const int by, const int z, char* smem) {
   using F = Frag<IS_BF16>;
   using VT = typename F::T;
@@ -272,7 +274,7 @@ __device__ __forceinline__ void decode_split_body(const DecodeArgs& a, const int
   // multiplied (D <= 128; at D = 256 a second set would not fit two waves per SIMD).  Batch 64 x 4096 tokens:
   // 190-198 us against 204-211 us without it.  Latency launches (about one workgroup per CU: long-context
   // decode of one sequence cut into many splits) keep the single set - 33.8 against 37.0 us at 1 x 32768.
-  constexpr bool DOUBLE = D <= 128;
+  constexpr bool DOUBLE = ALLOW_DEEP && D <= 128;
   int n0 = start + wave * 32;
   if (DOUBLE && a.deep) {
     KVBlock ra, rb;

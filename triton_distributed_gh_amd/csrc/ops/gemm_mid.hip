@@ -105,6 +105,16 @@ TDIST_API int tdist_gemm_nt_mid_plan(int M, int N, int K, int num_cus, int force
   return 0;
 }
 
+// Identity of the capture `stream` is recording into (0 = not capturing).  Unique per capture, so a caller
+// can keep one workspace per graph.
+TDIST_API int tdist_stream_capture_id(void* stream, unsigned long long* id_out) {
+  hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  TDIST_HIP_TRY(hipStreamGetCaptureInfo((hipStream_t)stream, &status, &id));
+  *id_out = status == hipStreamCaptureStatusActive ? id : 0;
+  return 0;
+}
+
 // dtype: 0 = bf16, 1 = fp16.  `partial` / `counters` as sized by tdist_gemm_nt_mid_plan for the same
 // (mt, wn, splits); the counters must be zero before the first launch (every launch leaves them zero).
 TDIST_API int tdist_gemm_nt_mid(const void* X, const void* W, void* C, int M, int N, int K, long long ldx, long long ldw,

@@ -391,9 +391,9 @@ __device__ __forceinline__ void task_attn_split(const MegaOp& op, int tile, char
   fdec::DecodeArgs a;
   fill_decode_args(op, a, s_lens);
   if (D == 128)
-    fdec::decode_split_body<true, 128>(a, b, by, z, smem);
+    fdec::decode_split_body<true, 128, false>(a, b, by, z, smem);
   else
-    fdec::decode_split_body<true, 64>(a, b, by, z, smem);
+    fdec::decode_split_body<true, 64, false>(a, b, by, z, smem);
 }
 
 __device__ __forceinline__ void task_attn_combine(const MegaOp& op, int b) {
@@ -446,7 +446,7 @@ __device__ __forceinline__ void task_prefetch(const MegaOp& op, int tile, int* s
   if (acc == 0x9e3779b9u && b1 < 0) *sink = (int)acc;
 }
 
-__global__ __launch_bounds__(256) void mega_kernel(MegaParams P) {
+__global__ __launch_bounds__(256, 2) void mega_kernel(MegaParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* s_task = (int*)smem;                  // [TASK_WORDS]
   int* s_lens = s_task + TASK_WORDS;         // [16] effective kv lengths
@@ -531,11 +531,18 @@ TDIST_API int tdist_mega_launch(const SymmCtx* ctx, const int* queues, const int
   P.max_tasks = max_tasks;
   P.max_tiles = max_tiles;
   P.epoch = epoch;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static int resident = 0;    // workgroups of this kernel the device keeps resident at once
+  if (resident == 0) {
     TDIST_HIP_TRY(hipFuncSetAttribute((const void*)mega_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MEGA_LDS));
-    attr_set = true;
+    int dev = 0, cus = 0, per_cu = 0;
+    TDIST_HIP_TRY(hipGetDevice(&dev));
+    TDIST_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    TDIST_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)mega_kernel, 256, MEGA_LDS));
+    resident = cus * per_cu;
   }
+  // Tasks wait for tasks of other queues: a queue whose workgroup is not resident would never run and the
+  // waiters would time out, so a grid larger than the resident set is refused up front.
+  TDIST_REQUIRE(num_queues <= resident, "more queues than workgroups the device keeps resident");
   hipLaunchKernelGGL(mega_kernel, dim3(num_queues), dim3(256), MEGA_LDS, (hipStream_t)stream, P);
   TDIST_HIP_TRY(hipGetLastError());
   return 0;

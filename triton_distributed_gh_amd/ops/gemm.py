@@ -31,6 +31,8 @@ DECODE_LIB_BYTES = int(os.environ.get("TDIST_DECODE_GEMM_LIB_MB", "0")) << 20
 # the band between the decode kernel and chip-filling 256x256 tiles: "native" (mid-M kernel) or "lib"
 MID_GEMM = os.environ.get("TDIST_MID_GEMM", "native")
 MID_MAX_M = int(os.environ.get("TDIST_MID_MAX_M", "1024"))
+# decode shapes (M <= 16) with long K / mid-sized weights on the mid-M kernel's split-K ("1"; default off)
+DECODE_SPLITK = os.environ.get("TDIST_DECODE_SPLITK", "0") != "0"
 
 
 def gemm_supported(a: torch.Tensor, b: torch.Tensor) -> bool:
@@ -73,7 +75,16 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
             return out
         if M <= MID_MAX_M:
             return gemm_nt_mid(a, b, out)
-    # Decode shapes stay on the weight-streaming kernel.  Called back to back on ONE 100-270 MB layer the
+    # Decode shapes (M <= 16): the weight-streaming kernel has no split of K across workgroups, and on one
+    # layer called back to back the mid-M kernel (rows padded to 32, split-K) is ahead on long-K / mid-sized
+    # weights (scripts/dev/probe_decode_splitk.py: 4096 x 12288 18.5 vs 22.9-30.9 us, 1024 x 16384 13.1 vs
+    # 25-36 us).  Inside a real decode step, where every layer streams from HBM instead of the memory-side
+    # cache, the step time is the same (Qwen3-8B, HIP graph: 4.399 vs 4.388 ms), so the rule is opt-in:
+    # TDIST_DECODE_SPLITK=1.
+    if (M <= 16 and DECODE_SPLITK and variant == GEMM_VARIANT and N <= 32768
+            and (K >= 8192 or N * K >= 20_000_000)):
+        return gemm_nt_mid(a, b, out)
+    # Otherwise decode shapes stay on the weight-streaming kernel.  Called back to back on ONE 100-270 MB layer the
     # library's 64x16x512 kernel looks faster (6.3-6.6 vs 4-5 TB/s), but there the weights partly sit in
     # the 256 MB memory-side cache; in a real decode step (Qwen3-8B, every layer streamed from HBM) the
     # step takes 4.51 ms with this kernel everywhere against 4.69 ms with those layers on the library
@@ -113,16 +124,31 @@ def gemm_nt_mid(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = 
                                           ctypes.byref(ncnt)), "tdist_gemm_nt_mid_plan")
     # One workspace per device and STREAM: launches on one stream run in order and every launch leaves
     # its counters zero, so consecutive GEMMs can share it; concurrent streams must not.
-    key = (dev, torch.cuda.current_stream().cuda_stream)
-    ws = _MID_WS.get(key)
-    if ws is None or ws[0].numel() < pbytes.value or ws[1].numel() < ncnt.value:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("gemm_nt_mid: the split-K workspace must exist before graph capture; run the "
-                               "shape once eagerly on the capturing stream's device first")
-        old = ws
-        ws = (torch.empty(max(pbytes.value, 1 << 20, old[0].numel() if old else 0), dtype=torch.uint8, device=a.device),
-              torch.zeros(max(ncnt.value, 4096, old[1].numel() if old else 0), dtype=torch.int32, device=a.device))
-        _MID_WS[key] = ws
+    if torch.cuda.is_current_stream_capturing():
+        # Capture runs on a stream of its own: the workspace comes from the graph's private pool (it lives as
+        # long as the graph does) and is shared by every call recorded into the same capture, so a graph
+        # replays ONE zero-fill node for all its split-K launches.  Keyed by the capture's identity: a later
+        # capture never picks up memory of a graph that may be gone.
+        cid = ctypes.c_ulonglong()
+        _lib.check(lib.tdist_stream_capture_id(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream),
+                                                 ctypes.byref(cid)), "stream_capture_id")
+        key = (dev, "capture", cid.value)
+        ws = _MID_WS.get(key)
+        if ws is None or ws[0].numel() < pbytes.value or ws[1].numel() < ncnt.value:
+            for k in [k for k in _MID_WS if len(k) == 3 and k[0] == dev and k[2] != cid.value]:
+                del _MID_WS[k]                       # workspaces of finished captures: the graphs hold their memory
+            ws = (torch.empty(max(pbytes.value, 8 << 20), dtype=torch.uint8, device=a.device),
+                  torch.zeros(max(ncnt.value, 4096), dtype=torch.int32, device=a.device))
+            _MID_WS[key] = ws
+    else:
+        key = (dev, torch.cuda.current_stream().cuda_stream)
+        ws = _MID_WS.get(key)
+        if ws is None or ws[0].numel() < pbytes.value or ws[1].numel() < ncnt.value:
+            old = ws
+            ws = (torch.empty(max(pbytes.value, 1 << 20, old[0].numel() if old else 0), dtype=torch.uint8,
+                              device=a.device),
+                  torch.zeros(max(ncnt.value, 4096, old[1].numel() if old else 0), dtype=torch.int32, device=a.device))
+            _MID_WS[key] = ws
     _lib.check(
         lib.tdist_gemm_nt_mid(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), M, N, K, ctypes.c_longlong(a.stride(0)),
                               ctypes.c_longlong(b.stride(0)), ctypes.c_longlong(out.stride(0)), _DT[a.dtype],
