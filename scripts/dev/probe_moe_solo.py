@@ -58,8 +58,16 @@ rw = torch.rand(M, topk, device="cuda")
 def prep_rs():
     c2.flags[c2.call_count & 1][0].fill_(c2.call_count % EPOCH_MOD + 1)
 
-med, mn = timed(lambda: run_moe_reduce_rs(X, W2, ids, rw, c2), prep_rs)
 fl = 2.0 * M * topk * hidden * (ffn // w)
-print(f"moe_reduce_rs  solo rank: median {med:.1f} us  min {mn:.1f} us  ({fl / med / 1e6:.0f} TFLOP/s)", flush=True)
-c2.check_error()
+from triton_distributed_gh_amd import autotuner
+sweep = [(1, 0), (2, 16), (2, 32), (4, 16), (4, 32), (4, 48), (8, 32)]
+if os.environ.get("NCK"):
+    sweep = [(int(os.environ["NCK"]), int(os.environ.get("RS_CUS", "32")))]
+for nck, rs_cus in sweep:
+    if rs_cus:
+        autotuner._ACTIVE["moe_rs.RS_CUS"] = rs_cus
+    med, mn = timed(lambda: run_moe_reduce_rs(X, W2, ids, rw, c2, n_chunks=nck), prep_rs)
+    print(f"moe_reduce_rs  solo rank, n_chunks {nck} (reduce keeps {rs_cus} CUs): median {med:.1f} us  min {mn:.1f} us  "
+          f"({fl / med / 1e6:.0f} TFLOP/s)", flush=True)
+    c2.check_error()
 vc.close()

@@ -12,7 +12,7 @@ from triton_distributed_gh_amd.ops.allgather import create_fast_allgather_contex
 from triton_distributed_gh_amd.ops.allreduce import AllReduceMethod, all_reduce, create_allreduce_ctx
 from triton_distributed_gh_amd.ops.ep_a2a import EPAll2AllLayer
 from triton_distributed_gh_amd.ops.gemm_ar import create_gemm_ar_context, gemm_allreduce_op
-from triton_distributed_gh_amd.utils.testing import VirtualCluster
+from triton_distributed_gh_amd.utils.testing import VirtualCluster, assert_close_elementwise
 
 pytestmark = pytest.mark.gpu
 
@@ -102,11 +102,14 @@ def test_gemm_allreduce(w, M, N, K):
             b = [(torch.rand(N, K // w, device="cuda") - 0.5).bfloat16() for _ in range(w)]
             torch.cuda.synchronize()
             outs = vc.run(lambda r, env: gemm_allreduce_op(ctxs[r], a[r], b[r]))
-            ref = sum((a[r].float() @ b[r].float().t()).bfloat16().float() for r in range(w))
+            parts = [(a[r].float() @ b[r].float().t()).bfloat16().float() for r in range(w)]
+            ref = sum(parts)
+            mag = sum(p.abs() for p in parts)        # rounding of the 16-bit partials scales with this
             for r in range(w):
                 ctxs[r].check_error()
                 rel = (outs[r].float() - ref).abs().max().item() / ref.abs().max().item()
                 assert rel < 1e-2
+                assert_close_elementwise(outs[r], ref, what=f"gemm_allreduce rank {r}", magnitude=mag)
                 assert torch.equal(outs[r], outs[0])
     finally:
         vc.close()
@@ -221,6 +224,39 @@ def test_ep_dispatch_combine(w, T, topk):
                     e = idx[r][:, k].long()
                     ref += wts[r][:, k:k + 1] * (xs[r].float() * (e + 1).unsqueeze(1)).bfloat16().float()
                 assert torch.allclose(outs[r].float(), ref, rtol=2e-2, atol=2e-2 * topk)
+    finally:
+        vc.close()
+
+
+def test_ep_two_dispatches_in_a_row():
+    """A dispatch that is not followed by a combine: the rows of the first dispatch stay intact while the
+    second one lands (parity buffers), the combine belongs to the second, and a second combine is refused."""
+    w, T, topk, hidden, epr = 4, 96, 2, 256, 2
+    E = w * epr
+    vc = VirtualCluster(w, heap_bytes=1 << 27)
+    try:
+        layers = vc.collective(lambda r, env: EPAll2AllLayer(None, T, hidden, topk, r, E, w, w, torch.bfloat16,
+                                                             num_sm=4, capacity_factor=float(w), env=env))
+        def fresh():
+            xs = [torch.randn(T, hidden, device="cuda").bfloat16() for _ in range(w)]
+            idx = [torch.stack([torch.randperm(E, device="cuda")[:topk] for _ in range(T)]).int() for _ in range(w)]
+            torch.cuda.synchronize()
+            return xs, idx
+
+        xs1, idx1 = fresh()
+        first = _dispatch_all(vc, layers, xs1, idx1)
+        snap = [t.clone() for t in first]
+        xs2, idx2 = fresh()
+        second = _dispatch_all(vc, layers, xs2, idx2)
+        for r in range(w):
+            layers[r].check_error()
+            assert torch.equal(first[r], snap[r]), "rows of dispatch 1 were overwritten by dispatch 2"
+        outs = vc.run(lambda r, env: layers[r].combine(second[r].clone()))
+        for r in range(w):
+            layers[r].check_error()
+            assert torch.allclose(outs[r].float(), xs2[r].float() * topk, rtol=2e-2, atol=2e-2 * topk)
+        with pytest.raises(RuntimeError, match="one combine per dispatch"):
+            layers[0].combine(second[0].clone())
     finally:
         vc.close()
 

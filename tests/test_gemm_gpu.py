@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from triton_distributed_gh_amd.ops.gemm import gemm_nt
+from triton_distributed_gh_amd.utils.testing import assert_close_elementwise
 
 pytestmark = pytest.mark.gpu
 
@@ -20,6 +21,7 @@ def test_gemm_nt_matches_fp32_reference(M, N, K, dtype):
     ref = a.float() @ b.float().t()
     rel = (c.float() - ref).abs().max().item() / ref.abs().max().item()
     assert rel < 1e-2
+    assert_close_elementwise(c, ref, what=f"gemm_nt {M}x{N}x{K}")
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES + [(4096, 4096, 512), (1000, 8200, 256)])
@@ -36,6 +38,7 @@ def test_persistent_gemm_matches_fp32_reference(M, N, K, knobs):
         ref = a.float() @ b.float().t()
         rel = (out[:, :N].float() - ref).abs().max().item() / ref.abs().max().item()
         assert rel < 1e-2
+        assert_close_elementwise(out[:, :N], ref, what=f"gemm_nt variant {M}x{N}x{K}")
         assert torch.all(out[:, N:] == 7.0), "wrote past the last column"
 
 
@@ -52,6 +55,7 @@ def test_four_wave_gemm_matches_fp32_reference(M, N, K):
         ref = a.float() @ b.float().t()
         rel = (out[:, :N].float() - ref).abs().max().item() / ref.abs().max().item()
         assert rel < 1e-2
+        assert_close_elementwise(out[:, :N], ref, what=f"gemm_nt variant {M}x{N}x{K}")
         assert torch.all(out[:, N:] == 7.0), "wrote past the last column"
 
 

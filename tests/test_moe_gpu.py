@@ -5,7 +5,7 @@ import torch
 
 from triton_distributed_gh_amd.ops.moe import (_align_cpu, ag_group_gemm, create_ag_group_gemm_context,
                                                create_moe_rs_context, moe_align_block_size, run_moe_reduce_rs)
-from triton_distributed_gh_amd.utils.testing import VirtualCluster
+from triton_distributed_gh_amd.utils.testing import VirtualCluster, assert_close_elementwise
 
 pytestmark = pytest.mark.gpu
 
@@ -62,6 +62,7 @@ def test_ag_group_gemm(w, ntokens, N, K, E, topk):
                     ref[m] = rows[m] @ b[r][e].float().t()
                 rel = (outs[r].float() - ref).abs().max().item() / ref.abs().max().item()
                 assert rel < 1e-2, f"rank {r}: {rel}"
+                assert_close_elementwise(outs[r], ref, what=f"ag_group_gemm rank {r}")
     finally:
         vc.close()
 
@@ -69,26 +70,32 @@ def test_ag_group_gemm(w, ntokens, N, K, E, topk):
 @pytest.mark.parametrize("w,ntokens,hidden,K,E,topk", [(1, 128, 512, 256, 4, 2), (2, 256, 512, 512, 8, 2),
                                                        (4, 512, 1024, 1024, 8, 2), (8, 512, 768, 2048, 16, 4),
                                                        (4, 88, 520, 512, 8, 2)])   # 22 tokens per rank: partial token group
-def test_moe_reduce_rs(w, ntokens, hidden, K, E, topk):
+@pytest.mark.parametrize("n_chunks", [1, 3])
+def test_moe_reduce_rs(w, ntokens, hidden, K, E, topk, n_chunks):
     vc = VirtualCluster(w, heap_bytes=1 << 27)
     try:
         ctxs = vc.collective(lambda r, env: create_moe_rs_context(r, w, w, ntokens, hidden, E, topk, torch.bfloat16,
-                                                                  num_ctas=max(8, 200 // w), env=env))
+                                                                  num_ctas=max(8, 200 // w), env=env,
+                                                                  rs_stream=vc.side_streams[r]))
         for it in range(2):
             x = [(torch.rand(ntokens * topk, K // w, device="cuda") - 0.5).bfloat16() for _ in range(w)]
             wt = [(torch.rand(E, hidden, K // w, device="cuda") - 0.5).bfloat16() for _ in range(w)]
             ids = _rand_topk(ntokens, E, topk)
             rw = torch.rand(ntokens, topk, device="cuda")
             torch.cuda.synchronize()
-            outs = vc.run(lambda r, env: run_moe_reduce_rs(x[r], wt[r], ids, rw, ctxs[r]))
+            # n_chunks = 3: bands of whole 256-column tiles (the last one ragged at hidden = 520 / 768), each
+            # reduced on a second stream while the next band multiplies
+            outs = vc.run(lambda r, env: run_moe_reduce_rs(x[r], wt[r], ids, rw, ctxs[r], n_chunks=n_chunks))
             flat = ids.reshape(-1).long()
             total = torch.zeros(ntokens, hidden, device="cuda")
+            mag = torch.zeros(ntokens, hidden, device="cuda")      # sum of |16-bit partials| per output element
             for r in range(w):
                 part = torch.empty(ntokens * topk, hidden, device="cuda")
                 for e in range(E):
                     m = flat == e
                     part[m] = x[r][m].float() @ wt[r][e].float().t()
                 part = (part * rw.reshape(-1, 1)).bfloat16().float()
+                mag += part.abs().view(ntokens, topk, hidden).sum(1)
                 total += part.view(ntokens, topk, hidden).sum(1).bfloat16().float() if w > 1 else part.view(ntokens, topk, hidden).sum(1)
             tpr = ntokens // w
             for r in range(w):
@@ -96,5 +103,7 @@ def test_moe_reduce_rs(w, ntokens, hidden, K, E, topk):
                 ref = total[r * tpr:(r + 1) * tpr]
                 rel = (outs[r].float() - ref).abs().max().item() / ref.abs().max().item()
                 assert rel < 2e-2, f"rank {r}: {rel}"
+                assert_close_elementwise(outs[r], ref, rtol=1e-2, atol=1e-2, what=f"moe_reduce_rs rank {r}",
+                                         magnitude=mag[r * tpr:(r + 1) * tpr])
     finally:
         vc.close()

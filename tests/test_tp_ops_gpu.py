@@ -9,7 +9,7 @@ import torch
 
 from triton_distributed_gh_amd.ops.ag_gemm import ag_gemm_intra_node, create_ag_gemm_intra_node_context
 from triton_distributed_gh_amd.ops.gemm_rs import create_gemm_rs_intra_node_context, gemm_rs_intra_node
-from triton_distributed_gh_amd.utils.testing import VirtualCluster
+from triton_distributed_gh_amd.utils.testing import VirtualCluster, assert_close_elementwise
 
 pytestmark = pytest.mark.gpu
 
@@ -27,6 +27,9 @@ def _ctas(w):
     (8, 2048, 1024, 128, 128, "kernel"),
     (4, 256, 1536, 512, 256, "kernel"),       # 384 columns per rank: partial N tile
     (2, 1024, 1024, 512, 256, "copy_engine"),
+    (4, 2048, 2048, 512, 256, "copy_engine"),
+    (8, 4096, 2048, 256, 256, "copy_engine"),
+    (4, 256, 2048, 256, 256, "copy_engine"),  # 64 rows per rank: tiles straddle ranks
     (4, 1024, 1024, 1024, 256, "kernel:split2"),
     (4, 1024, 2048, 2048, 128, "kernel:split4"),
     (4, 256, 1024, 512, 256, "kernel:split2"),   # straddling tiles + split-K
@@ -57,6 +60,7 @@ def test_ag_gemm_virtual_ranks(w, M, N, K, chunk, producer, monkeypatch):
                 ref = a_full @ b[r].float().t()
                 rel = (outs[r].float() - ref).abs().max().item() / ref.abs().max().item()
                 assert rel < 1e-2, f"rank {r} iteration {it}: {rel}"
+                assert_close_elementwise(outs[r], ref, what=f"ag_gemm rank {r} iteration {it}")
     finally:
         vc.close()
 
@@ -85,13 +89,17 @@ def test_gemm_rs_virtual_ranks(w, M, N, K, chunk):
                 return gemm_rs_intra_node(a[r], b[r], ctxs[r])
 
             outs = vc.run(step)
-            partial = sum((a[r].float() @ b[r].float().t()).bfloat16().float() for r in range(w))
+            parts = [(a[r].float() @ b[r].float().t()).bfloat16().float() for r in range(w)]
+            partial = sum(parts)
+            mag = sum(p.abs() for p in parts)        # rounding of the 16-bit partials scales with this
             Mr = M // w
             for r in range(w):
                 ctxs[r].check_error()
                 ref = partial[r * Mr:(r + 1) * Mr]
                 rel = (outs[r].float() - ref).abs().max().item() / ref.abs().max().item()
                 assert rel < 1e-2, f"rank {r} iteration {it}: {rel}"
+                assert_close_elementwise(outs[r], ref, what=f"gemm_rs rank {r} iteration {it}",
+                                         magnitude=mag[r * Mr:(r + 1) * Mr])
     finally:
         vc.close()
 
@@ -113,6 +121,7 @@ def test_ag_gemm_split_k_single_rank(split, monkeypatch):
             ref = a.float() @ b.float().t()
             rel = (out.float() - ref).abs().max().item() / ref.abs().max().item()
             assert rel < 1e-2, rel
+            assert_close_elementwise(out, ref, what=f"ag_gemm split-K {split}")
     finally:
         vc.close()
 

@@ -34,6 +34,10 @@ KNOWN_KNOBS: Dict[str, Sequence[Any]] = {
     "ag_gemm.PUSH_WGS": (0, 8, 16, 32),          # 0 = 8 per outgoing link
     "ag_gemm.SPLIT_K": (0, 1, 2, 4),             # 0 = fill the CUs
     "gemm_rs.M_PER_CHUNK": (256, 512),
+    "gemm_mid.WN": (0, 1, 2),                    # 0 = planned from the shape
+    "gemm_mid.SPLITS": (0, 1, 2, 4, 8),
+    "moe_rs.N_CHUNKS": (1, 2, 4),                # column bands of MoE+RS pipelined over two streams
+    "moe_rs.RS_CUS": (32, 16, 48),               # compute units the grouped GEMM leaves to the reduce
 }
 
 

@@ -273,7 +273,9 @@ __global__ __launch_bounds__(THREADS, 2) void moe_group_gemm_kernel(GroupGemmPar
 }
 
 // ------------------------------------------------------------------------------------------------
-// topk reduce + reduce-scatter.  gemm_out [ntokens*topk, N] (already weight-scaled).
+// topk reduce + reduce-scatter.  gemm_out [ntokens*topk, N] (already weight-scaled).  A launch may cover a
+// band of N columns only (row strides `ld`): the caller cuts N into chunks and runs the reduce of chunk c next
+// to the grouped GEMM of chunk c + 1 on a second stream, each chunk with flags and counters of its own.
 // Work items hold RS_TG consecutive tokens of one owner (per-item costs - ticket, drain, barrier,
 // counter - are paid once per group, and a thread keeps 4 x topk 16-byte loads in flight):
 //   push items   [0, w*gpo)      : item -> owner d = (rank+1 + item%w) % w, group item/w of that
@@ -287,11 +289,12 @@ __global__ __launch_bounds__(THREADS, 2) void moe_group_gemm_kernel(GroupGemmPar
 struct TopkRsParams {
   SymmCtx ctx;
   const uint16_t* gemm_out;
-  uint16_t* scatter;     // symmetric [w][tpr][N]
+  uint16_t* scatter;     // symmetric [w][tpr][ld]
   int* flags;            // symmetric [w]
   int* counters;         // local [w] + ticket at [w]; zeroed before launch
   int* err;
-  uint16_t* out;         // [tpr, N]
+  uint16_t* out;         // [tpr, ld]
+  long long ld;          // row stride of gemm_out / scatter / out in elements (N of the whole problem)
   int ntokens, topk, N, tpr, epoch;
 };
 
@@ -333,8 +336,8 @@ __global__ __launch_bounds__(256) void moe_topk_reduce_rs_kernel(TopkRsParams p)
       const int d = (rank + 1 + item % w) % w;
       const int tl0 = (item / w) * RS_TG;
       const int ntl = min(RS_TG, p.tpr - tl0);  // >= 1
-      const uint16_t* src = p.gemm_out + ((long long)d * p.tpr + tl0) * p.topk * p.N;
-      uint16_t* dst = ((d == rank) ? p.scatter : symm_at(p.ctx, p.scatter, d)) + ((long long)rank * p.tpr + tl0) * p.N;
+      const uint16_t* src = p.gemm_out + ((long long)d * p.tpr + tl0) * p.topk * p.ld;
+      uint16_t* dst = ((d == rank) ? p.scatter : symm_at(p.ctx, p.scatter, d)) + ((long long)rank * p.tpr + tl0) * p.ld;
       const int units = ntl * cpr;              // one unit = one 16-byte output piece
       for (int u0 = threadIdx.x; u0 < units; u0 += 4 * blockDim.x) {
         float acc[4][8];
@@ -346,13 +349,16 @@ __global__ __launch_bounds__(256) void moe_topk_reduce_rs_kernel(TopkRsParams p)
           if (u < units) {
             const int tl = u / cpr, c = (u - tl * cpr) << 3;
             for (int k = 0; k < p.topk; ++k)
-              acc_bf16x8(acc[j], *(const uint4*)(src + ((long long)tl * p.topk + k) * p.N + c));
+              acc_bf16x8(acc[j], *(const uint4*)(src + ((long long)tl * p.topk + k) * p.ld + c));
           }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int u = u0 + j * blockDim.x;
-          if (u < units) st_wt128_sys(dst + ((long long)u << 3), pack_bf16x8(acc[j]));   // rows of a group are contiguous
+          if (u < units) {
+            const int tl = u / cpr, c = (u - tl * cpr) << 3;
+            st_wt128_sys(dst + (long long)tl * p.ld + c, pack_bf16x8(acc[j]));
+          }
         }
       }
       // write-through stores: drain + barrier publish them, no release fence; the add that
@@ -378,14 +384,18 @@ __global__ __launch_bounds__(256) void moe_topk_reduce_rs_kernel(TopkRsParams p)
           for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
           const int u = u0 + j * blockDim.x;
           if (u < units) {
+            const int tl = u / cpr, c = (u - tl * cpr) << 3;
             for (int s = 0; s < w; ++s)
-              acc_bf16x8(acc[j], *(const uint4*)(p.scatter + ((long long)s * p.tpr + tl0) * p.N + ((long long)u << 3)));
+              acc_bf16x8(acc[j], *(const uint4*)(p.scatter + ((long long)s * p.tpr + tl0 + tl) * p.ld + c));
           }
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int u = u0 + j * blockDim.x;
-          if (u < units) *(uint4*)(p.out + (long long)tl0 * p.N + ((long long)u << 3)) = pack_bf16x8(acc[j]);
+          if (u < units) {
+            const int tl = u / cpr, c = (u - tl * cpr) << 3;
+            *(uint4*)(p.out + (long long)(tl0 + tl) * p.ld + c) = pack_bf16x8(acc[j]);
+          }
         }
       }
     }
@@ -505,10 +515,12 @@ TDIST_API int tdist_moe_group_gemm(const void* A, const void* B, void* out, cons
 }
 
 TDIST_API int tdist_moe_topk_reduce_rs(const SymmCtx* ctx, const void* gemm_out, void* scatter, int* flags,
-                                       int* counters, int* err, void* out, int ntokens, int topk, int N, int epoch,
-                                       int num_ctas, void* stream) {
+                                       int* counters, int* err, void* out, int ntokens, int topk, int N, long long ld,
+                                       int epoch, int num_ctas, void* stream) {
   const int w = ctx->num_ranks;
-  TDIST_REQUIRE(ntokens % w == 0 && N % 8 == 0, "ntokens must divide by world size and N by 8");
+  TDIST_REQUIRE(ntokens % w == 0 && N % 8 == 0 && ld % 8 == 0 && ld >= N,
+                "ntokens must divide by world size, N and the row stride by 8");
+  TDIST_REQUIRE((((uintptr_t)gemm_out | (uintptr_t)scatter | (uintptr_t)out) & 15) == 0, "buffers must be 16-byte aligned");
   TopkRsParams p;
   p.ctx = *ctx;
   p.gemm_out = (const uint16_t*)gemm_out;
@@ -520,6 +532,7 @@ TDIST_API int tdist_moe_topk_reduce_rs(const SymmCtx* ctx, const void* gemm_out,
   p.ntokens = ntokens;
   p.topk = topk;
   p.N = N;
+  p.ld = ld;
   p.tpr = ntokens / w;
   p.epoch = epoch;
   TDIST_HIP_TRY(hipMemsetAsync(counters, 0, (size_t)(TDIST_MAX_RANKS + 4) * sizeof(int), (hipStream_t)stream));

@@ -159,8 +159,7 @@ class TP_MoE:
         full_w, full_ids = self._gather_meta(wts, ids)
         h = self.ag_group_gemm(x2, self.gate_up_proj, ctx=self.ag_ctx, full_topk_ids=full_ids.contiguous())
         h = self._act(h)
-        out = self.run_moe_reduce_rs(h, self.down_proj, full_ids.contiguous(), full_w.contiguous(), ctx=self.rs_ctx,
-                                     n_chunks=4)
+        out = self.run_moe_reduce_rs(h, self.down_proj, full_ids.contiguous(), full_w.contiguous(), ctx=self.rs_ctx)
         return out.view(shape)
 
     def fwd(self, x: torch.Tensor):

@@ -13,6 +13,15 @@ the inter-node stage of the reference disappears:
             owner that all rows of that source have landed.
   combine : pull-based - for each token, the topk expert outputs are read from their owners'
             symmetric buffers at the recorded rows, weighted and summed.
+
+Buffer reuse.  The counts exchange at the head of every dispatch is a full handshake: a rank leaves it only
+after every peer's stream has reached the same dispatch, i.e. after the peer has finished (in stream order)
+everything it launched for the previous dispatch / combine.  On top of that the receive buffer and the
+expert-output buffer are double-buffered by call parity, so the rows handed out by dispatch n stay intact
+while dispatch n + 1 is in flight - a consumer of dispatch n on another stream, or a peer still pulling
+expert outputs of combine n, never sees rows of the next call.  What no buffering can make meaningful is a
+second combine for the same dispatch (its flags already carry the epoch, nothing would be waited for):
+``combine`` refuses it.
 """
 from __future__ import annotations
 
@@ -55,8 +64,8 @@ class EPAll2AllLayer(torch.nn.Module):
         self.epr = num_tot_experts // world_size
         self.cap_rows = int(max_tokens * topk * capacity_factor)
         heap = self.env.heap
-        self.recv_buf = heap.create_tensor_list([self.cap_rows, hidden], dtype, zero=False)
-        self.expert_out = heap.create_tensor_list([self.cap_rows, hidden], dtype, zero=False)
+        self.recv_buf = heap.create_tensor_list([2, self.cap_rows, hidden], dtype, zero=False)     # [parity]
+        self.expert_out = heap.create_tensor_list([2, self.cap_rows, hidden], dtype, zero=False)   # [parity]
         self.table = heap.create_tensor_list([world_size, num_tot_experts], torch.int32)
         self.flags = heap.create_tensor_list([3 * world_size], torch.int32, arena="sig")
         dev = self.env.device
@@ -70,6 +79,7 @@ class EPAll2AllLayer(torch.nn.Module):
         self.exp_indices = None
         self.recv_per_expert = None
         self.num_recv = 0
+        self._combined = True      # the latest dispatch has been combined (or there has been none yet)
 
     def check_error(self):
         if int(self.scratch[self.E + 8]) != 0:
@@ -99,27 +109,33 @@ class EPAll2AllLayer(torch.nn.Module):
             raise RuntimeError(f"EP dispatch: {self.num_recv} rows exceed the receive capacity {self.cap_rows}")
         self.scatter_idx = torch.empty((T, self.topk), dtype=torch.int32, device=input.device)
         self.exp_indices = idx
+        self._combined = False
+        recv = self.recv_buf[self.rank][self.epoch & 1]
         lib, cs = _lib.hip(), self.env.heap.ctx_struct()
         w = self.w
         _lib.check(
             lib.tdist_ep_dispatch(ctypes.byref(cs), _lib.ptr(input.contiguous()), _lib.ptr(idx), _lib.ptr(dst_base),
-                                  _lib.ptr(self.scratch), _lib.ptr(self.recv_buf[self.rank]), _lib.ptr(self.scatter_idx),
+                                  _lib.ptr(self.scratch), _lib.ptr(recv), _lib.ptr(self.scatter_idx),
                                   _lib.ptr(self.flags[self.rank][w:]), _lib.ptr(self.scratch[self.E:]),
                                   _lib.ptr(self.scratch[self.E + 8:]),
                                   ctypes.c_longlong(self.hidden * input.element_size()), T, self.topk, self.E, self.epr,
                                   self.epoch, self.num_sm * 2, _lib.stream_handle()), "ep_dispatch")
-        return self.recv_buf[self.rank][: self.num_recv]
+        return recv[: self.num_recv]
 
     def combine(self, input: torch.Tensor, weights: Optional[torch.Tensor] = None) -> torch.Tensor:
         """input [num_recv, hidden] = expert outputs in dispatch order -> [T, hidden]."""
+        if self._combined:
+            raise RuntimeError("EPAll2AllLayer.combine: no dispatch since the last combine (one combine per dispatch)")
         assert input.shape[0] == self.num_recv
+        self._combined = True
         T = self.exp_indices.shape[0]
-        self.expert_out[self.rank][: self.num_recv].copy_(input)
+        expert_out = self.expert_out[self.rank][self.epoch & 1]
+        expert_out[: self.num_recv].copy_(input)
         out = torch.empty((T, self.hidden), dtype=self.dtype, device=input.device)
         wts = weights.to(torch.float32).contiguous() if weights is not None else None
         lib, cs = _lib.hip(), self.env.heap.ctx_struct()
         _lib.check(
-            lib.tdist_ep_combine(ctypes.byref(cs), _lib.ptr(self.expert_out[self.rank]), _lib.ptr(self.exp_indices),
+            lib.tdist_ep_combine(ctypes.byref(cs), _lib.ptr(expert_out), _lib.ptr(self.exp_indices),
                                  _lib.ptr(self.scatter_idx), _lib.ptr(wts), _lib.ptr(out),
                                  _lib.ptr(self.flags[self.rank][2 * self.w:]), _lib.ptr(self.scratch[self.E + 8:]), T,
                                  self.topk, self.epr, self.hidden, self.epoch, self.num_sm * 4, _lib.stream_handle()),

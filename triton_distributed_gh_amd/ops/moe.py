@@ -303,6 +303,8 @@ class MoEReduceRSContext:
     env: Any = None
     num_ctas: int = 0
     call_count: int = 0
+    n_chunks_max: int = 8
+    side_stream: Any = None      # the reduce of chunk c runs here, next to the grouped GEMM of chunk c + 1
 
     def check_error(self):
         if self.scratch is not None and int(self.scratch[40]) != 0:
@@ -310,28 +312,48 @@ class MoEReduceRSContext:
 
 
 def create_moe_rs_context(rank, world_size, local_world_size, max_token_num, hidden_dim, num_experts, topk,
-                          input_dtype, n_chunks_max=8, num_ctas=0, env=None) -> MoEReduceRSContext:
+                          input_dtype, n_chunks_max=8, num_ctas=0, env=None, rs_stream=None) -> MoEReduceRSContext:
+    """``rs_stream``: the stream the chunked form (``n_chunks`` > 1) runs its reduces on; created on first
+    use when not given.  Ranks that share one GPU should pass streams that do not share a hardware queue with
+    another rank's (a reduce spins on its peers: two of them in one queue would wait for each other)."""
     env = env or get_env()
     num_ctas = default_num_ctas(env, world_size, num_ctas)
     heap = env.heap
     scatter, flags = [], []
     for _ in range(2):
         scatter.append(heap.create_tensor_list([max_token_num, hidden_dim], input_dtype, zero=False))
-        flags.append(heap.create_tensor_list([world_size], torch.int32, arena="sig"))
-    scratch = torch.zeros(64, dtype=torch.int32, device=env.device) if env.backend == "hip" else None
+        flags.append(heap.create_tensor_list([n_chunks_max * world_size], torch.int32, arena="sig"))   # [chunk][src]
+    # scratch: [40] sticky error word; per chunk c a block of 64 ints at 64 + 64 c: reduce counters [0, 32),
+    # grouped-GEMM tickets [32, 64)
+    scratch = (torch.zeros(64 + 64 * n_chunks_max, dtype=torch.int32, device=env.device)
+               if env.backend == "hip" else None)
     if env.backend == "hip":
         torch.cuda.synchronize()
     if env.cpu_group is not None:
         torch.distributed.barrier(group=env.cpu_group)
     return MoEReduceRSContext(rank, world_size, max_token_num, hidden_dim, num_experts, topk, input_dtype, scatter,
-                              flags, scratch, env, num_ctas)
+                              flags, scratch, env, num_ctas, 0, n_chunks_max, rs_stream)
+
+
+def _column_chunks(N: int, n_chunks: int):
+    """Cut N columns into at most n_chunks bands of whole 256-column GEMM tiles: [(first column, width)]."""
+    tiles = (N + 255) // 256
+    n = max(1, min(n_chunks, tiles))
+    per = (tiles + n - 1) // n * 256
+    return [(c0, min(per, N - c0)) for c0 in range(0, N, per)]
 
 
 def run_moe_reduce_rs(x: torch.Tensor, weights: torch.Tensor, chosen_experts: torch.Tensor,
-                      expert_weight: torch.Tensor, ctx: MoEReduceRSContext, n_chunks: int = 2, config=None):
+                      expert_weight: torch.Tensor, ctx: MoEReduceRSContext, n_chunks: Optional[int] = None, config=None):
     """x [ntokens*topk, K/w] (row token*topk+k), weights = expert weights ([E, hidden, K/w] or
     [E, K/w, hidden]), chosen_experts [ntokens, topk], expert_weight [ntokens, topk] routing
-    weights.  Returns [ntokens/w, hidden] = ReduceScatter_tokens(sum_k w_k * x_k @ W[e_k])."""
+    weights.  Returns [ntokens/w, hidden] = ReduceScatter_tokens(sum_k w_k * x_k @ W[e_k]).
+
+    ``n_chunks`` > 1 cuts the hidden dimension into bands of whole GEMM tiles and pipelines them as the
+    reference does (kernels/nvidia/moe_reduce_rs.py:238-244, :569-656): the topk reduce + scatter of band c runs
+    on a second stream next to the grouped GEMM of band c + 1, which leaves ``moe_rs.RS_CUS`` compute units
+    to it (a grouped-GEMM workgroup fills the register file of its CU, so the two kernels cannot share one).
+    Default: the ``moe_rs.N_CHUNKS`` tuning knob (1 = one GEMM launch, one reduce launch, back to back)."""
     env = ctx.env
     w, rank = ctx.world_size, ctx.rank
     forbid_graph_capture("run_moe_reduce_rs", w)
@@ -347,15 +369,29 @@ def run_moe_reduce_rs(x: torch.Tensor, weights: torch.Tensor, chosen_experts: to
     gemm_out = torch.empty((ntokens * topk, N), dtype=x.dtype, device=x.device)
     scale = expert_weight.reshape(-1).to(torch.float32).contiguous()
     lib = _lib.hip()
-    _lib.check(
-        lib.tdist_moe_group_gemm(_lib.ptr(x), _lib.ptr(b), _lib.ptr(gemm_out), _lib.ptr(idx.sorted_ids),
-                                 _lib.ptr(idx.expert_of_block), None, None, _lib.ptr(idx.meta), _lib.ptr(scale), None,
-                                 _lib.ptr(ctx.scratch[48:]), _lib.ptr(ctx.scratch[40:]), ctypes.c_longlong(x.stride(0)),
-                                 ctypes.c_longlong(b.stride(1)), ctypes.c_longlong(gemm_out.stride(0)),
-                                 ctypes.c_longlong(b.stride(0)), N, K, topk, 1, 1, 0, ctx.num_ctas, _DT[x.dtype],
-                                 _lib.stream_handle(), None, None, ctypes.c_longlong(0), None, 0, 0, 0),
-        "tdist_moe_group_gemm")
+    nck = int(n_chunks) if n_chunks is not None else int(tuning.get("moe_rs.N_CHUNKS", 1))
+    chunks = _column_chunks(N, min(nck, ctx.n_chunks_max)) if w > 1 else [(0, N)]
+    esz = x.element_size()
+    # with a reduce running next to it the grouped GEMM leaves some compute units free
+    gemm_ctas = ctx.num_ctas
+    if len(chunks) > 1:
+        budget = ctx.num_ctas or torch.cuda.get_device_properties(x.device).multi_processor_count
+        gemm_ctas = max(8, budget - min(int(tuning.get("moe_rs.RS_CUS", 32)), budget // 4))
+
+    def group_gemm(c, c0, nc):
+        blk = ctx.scratch[64 + 64 * c:]
+        _lib.check(
+            lib.tdist_moe_group_gemm(_lib.ptr(x), ctypes.c_void_p(b.data_ptr() + c0 * b.stride(1) * esz),
+                                     ctypes.c_void_p(gemm_out.data_ptr() + c0 * esz), _lib.ptr(idx.sorted_ids),
+                                     _lib.ptr(idx.expert_of_block), None, None, _lib.ptr(idx.meta), _lib.ptr(scale), None,
+                                     _lib.ptr(blk[32:]), _lib.ptr(ctx.scratch[40:]), ctypes.c_longlong(x.stride(0)),
+                                     ctypes.c_longlong(b.stride(1)), ctypes.c_longlong(gemm_out.stride(0)),
+                                     ctypes.c_longlong(b.stride(0)), nc, K, topk, 1, 1, 0, gemm_ctas, _DT[x.dtype],
+                                     _lib.stream_handle(), None, None, ctypes.c_longlong(0), None, 0, 0, 0),
+            "tdist_moe_group_gemm")
+
     if w == 1:
+        group_gemm(0, 0, N)
         from .moe import reduce_topk as _rt
 
         return _rt(gemm_out, topk)
@@ -364,10 +400,32 @@ def run_moe_reduce_rs(x: torch.Tensor, weights: torch.Tensor, chosen_experts: to
     ctx.call_count += 1
     out = torch.empty((ntokens // w, N), dtype=x.dtype, device=x.device)
     cs = env.heap.ctx_struct()
-    _lib.check(
-        lib.tdist_moe_topk_reduce_rs(ctypes.byref(cs), _lib.ptr(gemm_out), _lib.ptr(ctx.scatter[parity][rank]),
-                                     _lib.ptr(ctx.flags[parity][rank]), _lib.ptr(ctx.scratch), _lib.ptr(ctx.scratch[40:]),
-                                     _lib.ptr(out), ntokens, topk, N, epoch,
-                                     int(os.environ.get("TDIST_MOE_RS_CTAS", "0")) or ctx.num_ctas, _lib.stream_handle()),
-        "tdist_moe_topk_reduce_rs")
+    rs_ctas = int(os.environ.get("TDIST_MOE_RS_CTAS", "0")) or ctx.num_ctas
+
+    def reduce_rs(c, c0, nc):
+        blk = ctx.scratch[64 + 64 * c:]
+        _lib.check(
+            lib.tdist_moe_topk_reduce_rs(ctypes.byref(cs), ctypes.c_void_p(gemm_out.data_ptr() + c0 * esz),
+                                         ctypes.c_void_p(ctx.scatter[parity][rank].data_ptr() + c0 * esz),
+                                         _lib.ptr(ctx.flags[parity][rank][c * w:]), _lib.ptr(blk), _lib.ptr(ctx.scratch[40:]),
+                                         ctypes.c_void_p(out.data_ptr() + c0 * esz), ntokens, topk, nc,
+                                         ctypes.c_longlong(N), epoch, rs_ctas, _lib.stream_handle()),
+            "tdist_moe_topk_reduce_rs")
+
+    if len(chunks) == 1:
+        group_gemm(0, 0, N)
+        reduce_rs(0, 0, N)
+        return out
+    main = torch.cuda.current_stream()
+    if ctx.side_stream is None:
+        ctx.side_stream = getattr(env, "side_stream", None) or torch.cuda.Stream(device=x.device)
+    side = ctx.side_stream
+    for c, (c0, nc) in enumerate(chunks):
+        group_gemm(c, c0, nc)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            reduce_rs(c, c0, nc)
+    main.wait_stream(side)
     return out

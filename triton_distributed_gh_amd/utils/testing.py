@@ -22,7 +22,7 @@ from __future__ import annotations
 import ctypes
 import sys
 import threading
-from typing import Callable, List
+from typing import Callable, List, Optional
 
 import torch
 
@@ -130,3 +130,22 @@ class VirtualCluster:
                 return  # the device is in an error state: freeing arenas now could fault again
         for env in self.envs:
             env.heap.close()
+
+
+def assert_close_elementwise(got: torch.Tensor, ref: torch.Tensor, rtol: float = 1e-2, atol: float = 1e-2,
+                             what: str = "", magnitude: Optional[torch.Tensor] = None) -> None:
+    """Every element within ``atol + rtol * |ref|`` (the reference's ``assert_allclose(atol=rtol=1e-2)``
+    convention, e.g. python/triton_dist/test/amd/test_ag_gemm_intra_node.py:170-190).  A metric relative to
+    the largest reference element would let a wrong small-magnitude row through; this one does not.  The
+    message names the worst element.  ``magnitude`` (same shape) replaces ``|ref|`` in the bound where the
+    result is a sum of separately rounded 16-bit partials: their rounding errors scale with the sum of the
+    partials' magnitudes, not with the (possibly cancelling) total."""
+    g, r = got.float(), ref.float()
+    assert g.shape == r.shape, f"{what}: shape {tuple(g.shape)} vs {tuple(r.shape)}"
+    excess = (g - r).abs() - (atol + rtol * (r.abs() if magnitude is None else magnitude.float()))
+    bad = excess > 0
+    if bool(bad.any()):
+        flat = int(excess.argmax())
+        idx = tuple(int(i) for i in torch.unravel_index(torch.tensor(flat), g.shape))
+        raise AssertionError(f"{what}: {int(bad.sum())} of {g.numel()} elements outside atol={atol} rtol={rtol}; worst at "
+                             f"{idx}: got {g[idx].item():.6g}, expected {r[idx].item():.6g}")
