@@ -20,8 +20,8 @@ struct DecodeArgs {
   const uint16_t* v_cache;
   const int* block_table;    // [batch, max_pages]
   const int* kv_len;         // [batch]
-  float* partial;            // [batch, q_heads, splits, D + 1]
-  void* out;                 // fused: [batch, q_heads, D] (16-bit) or [batch, q_heads, D + 1] (fp32, LSE last)
+  void* partial;             // [batch, q_heads, splits, D + 1], fp32 or (p16) the 16-bit type of q
+  void* out;                 // fused: [batch, q_heads, D] (16-bit) / [batch, q_heads, D + 1] (fp32 or 16-bit, LSE last)
   int* tickets;              // fused: [batch * gridDim.y], zero before the first launch (self-resetting)
   long long q_stride_b, q_stride_h;
   long long k_stride_slot, k_stride_h;
@@ -31,7 +31,9 @@ struct DecodeArgs {
   int table_stride;
   int page_size, page_shift;  // page_shift >= 0 when page_size is a power of two
   int q_heads, kv_heads, splits;
-  int fused;                  // 0: partials only, 1: merged 16-bit out, 2: merged fp32 out + LSE column
+  int fused;                  // 0: partials only, 1: merged 16-bit out, 2: merged fp32 out + LSE column,
+                              // 3: merged 16-bit out + LSE column
+  int p16;                    // 1: partial rows in the 16-bit type of q (the reference's *_fp16_fp16_fp16 kernels)
   int deep;                   // 1: two register sets (loads one block ahead): throughput launches, many workgroups per CU
   float sm_scale, soft_cap;
 };
@@ -76,8 +78,33 @@ __device__ __forceinline__ uint16_t to16(float f) {
 // so the loads of one pass overlap instead of queueing behind each other.  `lens` (optional)
 // skips empty items, whose rows may never have been written.
 template <bool IS_BF16>
-__device__ __forceinline__ void merge_rows(const float* part, long long stride, int n, int D, const int* lens,
+__device__ __forceinline__ float from16(uint16_t v) {
+  if constexpr (IS_BF16) {
+    return __builtin_bit_cast(float, (uint32_t)v << 16);
+  } else {
+    return (float)__builtin_bit_cast(_Float16, v);
+  }
+}
+
+// out_mode: 1 = 16-bit row, 2 = fp32 row + LSE at column D, 3 = 16-bit row + LSE at column D.
+// P16: the partial rows are in the 16-bit type instead of fp32.
+template <bool IS_BF16, bool P16 = false>
+__device__ __forceinline__ void merge_rows(const void* part_, long long stride, int n, int D, const int* lens,
                                            int lens_stride, void* out, int out_mode, int tid, int nthreads) {
+  struct Rows {
+    const void* base;
+    __device__ __forceinline__ float operator[](long long i) const {
+      if constexpr (P16) {
+        return from16<IS_BF16>(((const uint16_t*)base)[i]);
+      } else {
+        return ((const float*)base)[i];
+      }
+    }
+    __device__ __forceinline__ Rows operator+(long long off) const {
+      return Rows{(const char*)base + off * (P16 ? 2 : 4)};
+    }
+  };
+  const Rows part{part_};
   float mx = -INFINITY;
   for (int s = tid; s < n; s += nthreads) {
     if (lens && lens[(long long)s * lens_stride] <= 0) continue;
@@ -97,7 +124,7 @@ __device__ __forceinline__ void merge_rows(const float* part, long long stride, 
 #pragma unroll 2
     for (int s = 0; s < n; ++s) {
       const bool skip = lens && lens[(long long)s * lens_stride] <= 0;
-      const float* row = part + s * stride;
+      const Rows row = part + s * stride;
       const float l = skip ? -INFINITY : row[D];
       const float wgt = (l == -INFINITY) ? 0.f : __expf(l - mx);
       float v[4];
@@ -121,7 +148,14 @@ __device__ __forceinline__ void merge_rows(const float* part, long long stride, 
       }
     }
   }
-  if (out_mode == 2 && tid == 0) ((float*)out)[D] = den > 0.f ? mx + __logf(den) : -INFINITY;
+  if (out_mode >= 2 && tid == 0) {
+    const float lse = den > 0.f ? mx + __logf(den) : -INFINITY;
+    if (out_mode == 2) {
+      ((float*)out)[D] = lse;
+    } else {
+      ((uint16_t*)out)[D] = to16<IS_BF16>(lse);
+    }
+  }
 }
 
 // Split-KV body for work item (batch b, head block by, split z); writes the normalised partial row
@@ -309,7 +343,7 @@ __device__ __forceinline__ void decode_split_body(const DecodeArgs& a, const int
     for (int i = 0; i < 4; ++i) s_acc[(wave * 16 + li) * D + NDV * (4 * lg + i) + j] = acc[j][i];
   __syncthreads();
 
-  float* prow = a.partial + b * a.p_stride_b + z * a.p_stride_s;
+  const long long prow = b * a.p_stride_b + z * a.p_stride_s;     // element offset of this split's rows
   for (int idx = threadIdx.x; idx < 16 * D; idx += 256) {
     const int h = idx / D, c = idx - h * D;
     if (h >= valid_h) continue;
@@ -324,12 +358,18 @@ __device__ __forceinline__ void decode_split_body(const DecodeArgs& a, const int
       L += s_l[w * 16 + h] * f;
       o += s_acc[(w * 16 + h) * D + c] * f;
     }
-    float* dst = prow + (long long)(h0 + h) * a.p_stride_h;
+    const long long doff = prow + (long long)(h0 + h) * a.p_stride_h;
+    float* dst = (float*)a.partial + doff;
     const float val = L > 0.f ? o / L : 0.f;
     const float lse = L > 0.f ? (M + __log2f(L)) * 0.6931471805599453f : -INFINITY;
     if (a.fused == 1 && a.splits == 1) {
       // a single split is the final result: no partial row, no ticket, no second pass
       ((uint16_t*)a.out)[b * a.o_stride_b + (long long)(h0 + h) * a.o_stride_h + c] = to16<IS_BF16>(val);
+    } else if (a.p16) {
+      // 16-bit partial rows (plain stores; a fused launch publishes them with a release fence before its ticket)
+      uint16_t* d16 = (uint16_t*)a.partial + doff;
+      d16[c] = to16<IS_BF16>(val);
+      if (c == 0) d16[D] = to16<IS_BF16>(lse);
     } else if (a.fused) {
       // read by another workgroup of this launch: write-through stores (they leave this XCD's L2
       // at once), so the hand-off needs no release fence, only a drain before the ticket

@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void decode_split_kernel(DecodeArgs a) {
   decode_split_body<IS_BF16, D>(a, b, (int)blockIdx.y, (int)blockIdx.z, smem);
 
   if (!a.fused || (a.fused == 1 && a.splits == 1)) return;
+  if (a.p16) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // 16-bit rows went out as plain stores
   // ---- last workgroup of this (batch, head block) merges the splits.  The partial rows were
   // stored write-through: every wave drains its stores, the workgroup barriers, one lane takes a
   // ticket; the workgroup that draws the last ticket drops its stale L1 lines with ONE acquire
@@ -66,25 +67,28 @@ __global__ __launch_bounds__(256) void decode_split_kernel(DecodeArgs a) {
   {
     const int h = threadIdx.x >> 4, sub = threadIdx.x & 15;
     if (h < valid_h) {
-      const float* part = a.partial + b * a.p_stride_b + (long long)(h0 + h) * a.p_stride_h;
+      const long long poff = b * a.p_stride_b + (long long)(h0 + h) * a.p_stride_h;
       char* o = (char*)a.out + (b * a.o_stride_b + (long long)(h0 + h) * a.o_stride_h) * (a.fused == 2 ? 4 : 2);
-      merge_rows<IS_BF16>(part, a.p_stride_s, a.splits, D, nullptr, 0, o, a.fused, sub, 16);
+      if (a.p16)
+        merge_rows<IS_BF16, true>((const uint16_t*)a.partial + poff, a.p_stride_s, a.splits, D, nullptr, 0, o, a.fused, sub, 16);
+      else
+        merge_rows<IS_BF16, false>((const float*)a.partial + poff, a.p_stride_s, a.splits, D, nullptr, 0, o, a.fused, sub, 16);
     }
   }
 }
 
 // Generic LSE-weighted merge: partial rows [n, batch, heads, D + 1] (given by strides) ->
 // out [batch, heads, D] (16-bit) or [batch, heads, D + 1] (fp32 with LSE).  With `lens`
-// ([n, batch] int32) items of length 0 are skipped (ranks without KV for a sequence).
-template <bool IS_BF16>
-__global__ __launch_bounds__(64) void decode_combine_kernel(const float* part, long long p_stride_n, long long p_stride_b,
+// ([n, batch] int32) items of length 0 are skipped (ranks without KV for a sequence).  P16: 16-bit partials.
+template <bool IS_BF16, bool P16>
+__global__ __launch_bounds__(64) void decode_combine_kernel(const void* part, long long p_stride_n, long long p_stride_b,
                                                             long long p_stride_h, int n, int D, const int* lens,
                                                             int lens_stride, void* out, long long o_stride_b,
                                                             long long o_stride_h, int out_mode) {
   const int b = blockIdx.x, h = blockIdx.y;
-  const float* p = part + b * p_stride_b + h * p_stride_h;
+  const char* p = (const char*)part + (b * p_stride_b + h * p_stride_h) * (P16 ? 2 : 4);
   char* o = (char*)out + (b * o_stride_b + h * o_stride_h) * (out_mode == 2 ? 4 : 2);
-  merge_rows<IS_BF16>(p, p_stride_n, n, D, lens ? lens + b : nullptr, lens_stride, o, out_mode, threadIdx.x, 64);
+  merge_rows<IS_BF16, P16>(p, p_stride_n, n, D, lens ? lens + b : nullptr, lens_stride, o, out_mode, threadIdx.x, 64);
 }
 
 template <bool IS_BF16, int D>
@@ -106,9 +110,10 @@ hipError_t launch_split(const DecodeArgs& a, int batch, hipStream_t st) {
 
 }  // namespace
 
-// dtype: 0 = bf16, 1 = fp16.  fused: 0 partials only / 1 merged 16-bit / 2 merged fp32 + LSE.
+// dtype: 0 = bf16, 1 = fp16; + 16: the partial rows are stored in that 16-bit type instead of fp32.
+// fused: 0 partials only / 1 merged 16-bit / 2 merged fp32 + LSE / 3 merged 16-bit + LSE.
 TDIST_API int tdist_flash_decode_split(const void* q, const void* k_cache, const void* v_cache, const int* block_table,
-                                       const int* kv_len, float* partial, void* out, int* tickets, int batch,
+                                       const int* kv_len, void* partial, void* out, int* tickets, int batch,
                                        int q_heads, int kv_heads, int head_dim, int splits, int page_size,
                                        int table_stride, long long q_stride_b, long long q_stride_h,
                                        long long k_stride_slot, long long k_stride_h, long long v_stride_slot,
@@ -133,6 +138,10 @@ TDIST_API int tdist_flash_decode_split(const void* q, const void* k_cache, const
   a.table_stride = table_stride, a.page_size = page_size;
   a.page_shift = (page_size & (page_size - 1)) == 0 ? __builtin_ctz(page_size) : -1;
   a.q_heads = q_heads, a.kv_heads = kv_heads, a.splits = splits, a.fused = fused;
+  a.p16 = (dtype & 16) ? 1 : 0;
+  dtype &= 15;
+  TDIST_REQUIRE(dtype == 0 || dtype == 1, "dtype must be 0 (bf16) or 1 (fp16), + 16 for 16-bit partial rows");
+  TDIST_REQUIRE(fused >= 0 && fused <= 3, "fused must be 0..3");
   a.sm_scale = sm_scale, a.soft_cap = soft_cap;
   {
     static int num_cus = 0;
@@ -154,19 +163,26 @@ TDIST_API int tdist_flash_decode_split(const void* q, const void* k_cache, const
   return 0;
 }
 
-TDIST_API int tdist_flash_decode_combine(const float* partial, long long p_stride_n, long long p_stride_b,
+// dtype as for tdist_flash_decode_split (+ 16: 16-bit partial rows); out_mode 1 / 2 / 3 as `fused` there.
+TDIST_API int tdist_flash_decode_combine(const void* partial, long long p_stride_n, long long p_stride_b,
                                          long long p_stride_h, int n, int batch, int heads, int head_dim,
                                          const int* lens, int lens_stride, void* out, long long o_stride_b,
                                          long long o_stride_h, int out_mode, int dtype, void* stream) {
   TDIST_REQUIRE(n >= 1 && batch > 0 && heads > 0 && head_dim > 0, "bad combine shape");
-  TDIST_REQUIRE(out_mode == 1 || out_mode == 2, "out_mode must be 1 (16-bit) or 2 (fp32 + LSE)");
+  TDIST_REQUIRE(out_mode >= 1 && out_mode <= 3, "out_mode must be 1 (16-bit), 2 (fp32 + LSE) or 3 (16-bit + LSE)");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == 0)
-    hipLaunchKernelGGL(decode_combine_kernel<true>, dim3(batch, heads), dim3(64), 0, st, partial, p_stride_n, p_stride_b,
-                       p_stride_h, n, head_dim, lens, lens_stride, out, o_stride_b, o_stride_h, out_mode);
-  else
-    hipLaunchKernelGGL(decode_combine_kernel<false>, dim3(batch, heads), dim3(64), 0, st, partial, p_stride_n,
-                       p_stride_b, p_stride_h, n, head_dim, lens, lens_stride, out, o_stride_b, o_stride_h, out_mode);
+  const bool p16 = (dtype & 16) != 0;
+  dtype &= 15;
+  TDIST_REQUIRE(dtype == 0 || dtype == 1, "dtype must be 0 (bf16) or 1 (fp16), + 16 for 16-bit partial rows");
+  auto launch = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3(batch, heads), dim3(64), 0, st, partial, p_stride_n, p_stride_b, p_stride_h, n,
+                       head_dim, lens, lens_stride, out, o_stride_b, o_stride_h, out_mode);
+  };
+  if (dtype == 0) {
+    if (p16) launch(decode_combine_kernel<true, true>); else launch(decode_combine_kernel<true, false>);
+  } else {
+    if (p16) launch(decode_combine_kernel<false, true>); else launch(decode_combine_kernel<false, false>);
+  }
   TDIST_HIP_TRY(hipGetLastError());
   return 0;
 }

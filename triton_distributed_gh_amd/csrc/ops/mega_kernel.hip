@@ -375,6 +375,7 @@ __device__ __forceinline__ void fill_decode_args(const MegaOp& op, fdec::DecodeA
   a.page_shift = (a.page_size & (a.page_size - 1)) == 0 ? __builtin_ctz(a.page_size) : -1;
   a.fused = 0;
   a.deep = 0;
+  a.p16 = 0;
   a.sm_scale = op.f[0], a.soft_cap = op.f[1];
 }
 
