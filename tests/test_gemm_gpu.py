@@ -135,3 +135,29 @@ def test_decode_gemm_with_silu_mul_epilogue(M, I, K):
     assert got.shape == (M, I)
     assert (got.float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item() + 1e-3
     assert (got.float() - two.float()).abs().max().item() <= 1e-2 * ref.abs().max().item() + 1e-3
+
+
+def test_measured_gemm_times_sit_between_the_speed_of_light_and_the_model():
+    """The perf model's MI355X tables against this GPU: a measured GEMM can never beat the speed-of-light
+    estimate, and stays within 2x of what the model expects of the tile engine / the streaming kernel."""
+    from triton_distributed_gh_amd.utils import perf_model as pm
+
+    def timed_ms(fn, iters=10):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    for M, N, K in [(4096, 8192, 8192), (1, 32768, 4096)]:
+        a = (torch.rand(M, K, device="cuda") - 0.5).bfloat16()
+        b = (torch.rand(N, K, device="cuda") - 0.5).bfloat16()
+        out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        t = timed_ms(lambda: gemm_nt(a, b, out=out, force_native=True))
+        sol, exp = pm.estimate_gemm_sol_time_ms(M, N, K), pm.estimate_gemm_time_ms(M, N, K)
+        assert sol <= t <= 2.0 * exp, f"{M}x{N}x{K}: measured {t:.4f} ms, speed of light {sol:.4f}, model {exp:.4f}"

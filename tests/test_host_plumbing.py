@@ -202,3 +202,36 @@ def test_symmetric_heap_grows_by_segments():
             vc.collective(lambda r, env: env.heap.create_tensor([2 << 20], torch.uint8))     # larger than a segment
     finally:
         vc.close()
+
+
+def test_perf_model_tables_and_estimates():
+    """MI355X tables (dense MFMA peaks, HBM3E, xGMI links) and what the estimates built on them must obey
+    (reference: kernels/nvidia/gemm_perf_model.py:232-236, comm_perf_model.py:94-116)."""
+    import torch
+
+    from triton_distributed_gh_amd.utils import perf_model as pm
+
+    assert pm.get_max_tensorcore_tflops(torch.bfloat16) == 2500.0 and pm.get_max_tensorcore_tflops(torch.float8_e4m3fn) == 5000.0
+    assert pm.get_dram_gbps() == 8000.0 and pm.XGMI_LINKS_PER_GPU == 7
+    # headline shape: compute-bound, and the expected time of the tile engine sits above the speed of light
+    sol = pm.estimate_gemm_sol_time_ms(4096, 8192, 8192)
+    exp = pm.estimate_gemm_time_ms(4096, 8192, 8192)
+    assert abs(sol - 2 * 4096 * 8192 * 8192 / 2.5e15 * 1e3) < 1e-6 and sol < exp < 2 * sol
+    # decode shape: memory-bound
+    assert pm.estimate_gemm_sol_time_ms(1, 4096, 12288) == pytest.approx(4096 * 12288 * 2 / 8e12 * 1e3, rel=1e-2)
+    # a full-mesh all-gather is bound by ONE link per shard: twice the ranks, half the shard, half the time
+    ag = [pm.estimate_all_gather_time_ms(4096 // w * 8192 * 2, w) for w in (2, 4, 8)]
+    assert ag[0] == pytest.approx(2 * ag[1]) and ag[1] == pytest.approx(2 * ag[2])
+    for w in (2, 4, 8):
+        est = pm.estimate_ag_gemm_time_ms(4096, 8192 // w, 8192, w, push_wgs=pm.suggest_push_workgroups(4096, 8192 // w, 8192, w))
+        assert est["total_ms"] >= max(est["gemm_ms"], est["all_gather_ms"])
+        rs = pm.estimate_gemm_rs_time_ms(4096, 8192, 8192 // w, w)
+        assert rs["total_ms"] >= max(rs["gemm_ms"], rs["reduce_scatter_ms"])
+        n = pm.suggest_push_workgroups(4096, 8192 // w, 8192, w)
+        assert n % (w - 1) == 0 and w - 1 <= n <= 64
+    assert pm.suggest_push_workgroups(4096, 8192, 8192, 1) == 0
+    # a tiny GEMM next to a large shard cannot be fed by a quarter of the CUs: the copy engines take over
+    assert pm.prefer_copy_engine_producer(8192, 256, 8192, 8) and not pm.prefer_copy_engine_producer(4096, 8192, 8192, 2)
+    # Qwen3-8B decode step: 15.1 GB of weights, ~290 launches -> between the streaming bound and twice it
+    step = pm.estimate_decode_step_ms(int(15.1e9), 36 * 2 * 512 * 8 * 128 * 2, 290)
+    assert 15.1e9 / 8e12 * 1e3 < step < 2 * 15.1e9 / 5.5e12 * 1e3
