@@ -203,3 +203,37 @@ def test_qkv_prep_matches_separate_kernels(B, S, Hq, Hkv, D, norm):
     assert (q.view(B * S, Hq, D).float() - qr.float()).abs().max().item() <= 2e-2
     assert (kc.float() - kc_ref.float()).abs().max().item() <= 2e-2
     assert torch.equal(kc == 0, kc_ref == 0) or (kc != 0).sum() == (kc_ref != 0).sum()
+
+
+def test_attention_running_max_covers_every_lane_group():
+    """One key far above the rest, placed at every position of a 32-token block in turn: the running maximum
+    must be the maximum over ALL lane groups of the wave.  With a maximum taken from one group only, a
+    logit 400 above it overflows exp2 and the row turns to inf / nan (decode and prefill kernels share the
+    cross-lane max helper)."""
+    D, Hq, Hkv, page, L = 128, 8, 1, 32, 96
+    dtype = torch.bfloat16
+    scale = 1.0
+    for pos in range(32, 64, 3):
+        k = (torch.randn(4, page, Hkv, D, device="cuda") * 0.05).to(dtype)
+        v = torch.randn(4, page, Hkv, D, device="cuda").to(dtype)
+        q = (torch.randn(1, 1, D, device="cuda") * 0.05).to(dtype).expand(1, Hq, D).contiguous()
+        table = torch.arange(4, device="cuda", dtype=torch.int32).view(1, 4)
+        lens = torch.tensor([L], dtype=torch.int32, device="cuda")
+        # key `pos` is parallel to the query vector (the same for every head): its logit is 400, the others ~0
+        qd = q[0, 0].float()
+        k.view(-1, Hkv, D)[pos, 0] = (qd / (qd ** 2).sum() * 400).to(dtype)
+        ref = fd.decode_reference(q, k, v, lens, table, scale)
+        out = fd.gqa_fwd_batch_decode(q, k, v, None, None, lens, table, scale, kv_split=1)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out.float()).all(), f"dominant key at {pos}: non-finite output"
+        assert (out.float() - ref).abs().max().item() < 5e-2, f"dominant key at {pos}"
+        # the same keys through the prefill kernel (one query row per head, no mask)
+        cu_q = torch.tensor([0, 1], dtype=torch.int32, device="cuda")
+        cu_k = torch.tensor([0, L], dtype=torch.int32, device="cuda")
+        kk = k.view(-1, Hkv, D)[:L].contiguous()
+        vv = v.view(-1, Hkv, D)[:L].contiguous()
+        o2 = flash_attn_varlen_fwd(q[0].unsqueeze(0).contiguous().view(1, Hq, D), kk, vv, cu_q, cu_k, 1, causal=False,
+                                   softmax_scale=scale)
+        torch.cuda.synchronize()
+        assert torch.isfinite(o2.float()).all(), f"prefill, dominant key at {pos}: non-finite output"
+        assert (o2.float().view(1, Hq, D) - ref).abs().max().item() < 5e-2, f"prefill, dominant key at {pos}"

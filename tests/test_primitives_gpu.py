@@ -126,3 +126,33 @@ def test_grid_barrier(blocks):
     from triton_distributed_gh_amd.ops.common_ops import barrier_on_this_grid_smoke
     stale, timeouts = barrier_on_this_grid_smoke(blocks, rounds=16)
     assert (stale, timeouts) == (0, 0)
+
+
+@pytest.mark.parametrize("w", [1, 4])
+def test_language_extra_helpers(w):
+    """tdist/language_extra.hpp (the gfx950 forms of the reference's language_extra.py:109-929): packed moves,
+    vector ld / st, 64-lane shuffles and ballot, one-atomic-per-wave, multimem stores to every rank, arrive_inc /
+    wait_eq across ranks, scoped ld / st / CAS / red - one kernel per rank checks itself; then the load-reduce
+    over the ranks against a PyTorch sum."""
+    vc = VirtualCluster(w, heap_bytes=1 << 24)
+    try:
+        bufs = vc.collective(lambda r, env: env.heap.create_tensor([(2 * w + 2) * 512], torch.int32))
+        syncs = vc.collective(lambda r, env: env.heap.create_tensor([4], torch.int32, arena="sig"))
+        outs = [torch.zeros(4, dtype=torch.int32, device="cuda") for _ in range(w)]
+        torch.cuda.synchronize()
+        vc.run(lambda r, env: primitives.language_extra_smoke(bufs[r], syncs[r], outs[r], env=env))
+        for r in range(w):
+            assert outs[r].tolist() == [1, 1, 1, 0], f"rank {r}: wave 0 / wave 1 self-checks, arrival, failed-check bits = {outs[r].tolist()}"
+            assert int(syncs[r][0]) == w
+        srcs = vc.collective(lambda r, env: env.heap.create_tensor([128 * 8], torch.bfloat16))
+        vals = [torch.randn(128 * 8, device="cuda").bfloat16() for _ in range(w)]
+        for r in range(w):
+            srcs[r].copy_(vals[r])
+        dsts = [torch.empty(128 * 8, device="cuda", dtype=torch.bfloat16) for _ in range(w)]
+        torch.cuda.synchronize()
+        vc.run(lambda r, env: primitives.ld_reduce_smoke(srcs[r], dsts[r], env=env))
+        ref = sum(v.float() for v in vals).bfloat16()
+        for r in range(w):
+            assert torch.equal(dsts[r], ref)
+    finally:
+        vc.close()

@@ -29,6 +29,12 @@ def main():
         "atom_add / red_add are global_atomic_add": "global_atomic_add" in body or "flat_atomic_add" in body,
         "atom_cas is global_atomic_cmpswap": "atomic_cmpswap" in body,
     }
+    ext = isa.kernel_isa("primitives_test.hip", "language_extra_kernel")
+    facts["multimem_st_v4 is a write-through 16-byte store per rank (global_store_dwordx4 ... sc0 sc1)"] = \
+        "global_store_dwordx4" in ext and "sc0 sc1" in ext
+    facts["xor_max<32> is v_permlane32_swap (no LDS round trip)"] = "v_permlane32_swap" in ext
+    facts["ballot / one-atomic-per-wave use the 64-bit exec mask (s_ff1_i32_b64 / v_readlane)"] = \
+        "s_ff1_i32_b64" in ext or "v_readfirstlane" in ext or "v_readlane" in ext
     ring = isa.kernel_isa("primitives_test.hip", "ring_queue_kernel")
     facts["__syncthreads is s_barrier"] = "s_barrier" in ring
     for fact, ok in facts.items():
@@ -41,6 +47,19 @@ def main():
         torch.cuda.synchronize()
         assert out[:6].tolist() == [5, 5, 8, 11, 12, 20] and int(word) == 20
         print("  ok   atomics kernel: release / acquire / add / cas sequence returns the expected values")
+        from triton_distributed_gh_amd.utils.testing import VirtualCluster
+
+        vc = VirtualCluster(2, heap_bytes=1 << 24)
+        try:
+            bufs = vc.collective(lambda r, env: env.heap.create_tensor([6 * 512], torch.int32))
+            syncs = vc.collective(lambda r, env: env.heap.create_tensor([4], torch.int32, arena="sig"))
+            outs = [torch.zeros(4, dtype=torch.int32, device="cuda") for _ in range(2)]
+            torch.cuda.synchronize()
+            vc.run(lambda r, env: primitives.language_extra_smoke(bufs[r], syncs[r], outs[r], env=env))
+            assert all(o[:3].tolist() == [1, 1, 1] for o in outs)
+        finally:
+            vc.close()
+        print("  ok   language_extra kernel on two ranks: vector ld / st, shuffles, multimem stores, arrive / wait")
     print("✅ scoped load / store / atomic / barrier helpers lower to the expected gfx950 instructions")
 
 

@@ -105,12 +105,16 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & (64 - 1); }
 
 // max(x, x of lane ^ 16) / max(x, x of lane ^ 32) with the gfx950 row-swap instructions (register file only;
 // a cross-lane shuffle would take a round trip through the LDS pipeline on the softmax's critical path)
+// The two results are copied into scalars before the bit casts: a bit cast applied directly to an element of
+// the builtin's vector result (`__builtin_bit_cast(float, r[1])`) reads element 0 with this compiler, and the
+// max silently degenerates to "the partner's value on half of the lanes".
 template <int XOR>
 __device__ __forceinline__ float xor_max(float x) {
   const unsigned u = __builtin_bit_cast(unsigned, x);
   const auto r = XOR == 16 ? __builtin_amdgcn_permlane16_swap(u, u, false, false)
                            : __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+  const unsigned a = r[0], b = r[1];
+  return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
 }
 
 // Constant 100 MHz wall clock, independent of the shader clock.

@@ -6,6 +6,7 @@
 //  test_wait_and_notify.py, test_barrier_all.py, test_libdevice.py, test_rocshmem_api.py).
 #include "tdist/common.hpp"
 #include "tdist/grid_barrier.hpp"
+#include "tdist/language_extra.hpp"
 #include "tdist/primitives.hpp"
 #include "tdist/shmem_device.hpp"
 
@@ -94,6 +95,63 @@ __global__ void atomics_kernel(int* word, int* out) {
   }
 }
 
+// language_extra helpers, one workgroup of 128 threads (two waves) per rank.  `buf` is a symmetric
+// [num_ranks + 2][128] uint4 area: slot r holds rank r's vector, slot num_ranks the "multimem" broadcast target
+// and slot num_ranks + 1 bf16 values for the load-reduce.  `sync` is a symmetric int[4]; out[0] / out[1]: all
+// checks of wave 0 / wave 1 passed, out[2]: the arrivals came in, out[3]: one bit per failed check.
+__global__ void language_extra_kernel(SymmCtx ctx, uint4* buf, int* sync, int* out) {
+  using namespace tdist::ext;
+  const int t = tid(0), w = ctx.num_ranks, me = ctx.rank;
+  // packed move, vector store / load round trip
+  const uint32_t packed = pack_b32_v2((uint16_t)t, (uint16_t)(t + 1));
+  st_v4_u32(buf + me * 128 + t, packed, (uint32_t)t, (uint32_t)me, 7u);
+  const uint4 back = load_v4_u32(buf + me * 128 + t);
+  bool ok = true; { const bool c_ = (back.x == ((uint32_t)t | ((uint32_t)(t + 1) << 16)) && back.y == (uint32_t)t && back.z == (uint32_t)me && back.w == 7u); if (!c_) atomicOr(out + 3, 1); ok &= c_; }
+  // shuffles and ballot over the 64-lane wave
+  const int l = laneid();
+  { const bool c_ = (__shfl_sync_i32(~0ull, l, 5) == 5 && __shfl_xor_sync_i32(~0ull, l, 32) == (l ^ 32)); if (!c_) atomicOr(out + 3, 1 << 1); ok &= c_; }
+  { const bool c_ = (__shfl_down_sync_i32(~0ull, l, 3) == (l + 3 < 64 ? l + 3 : l) && __shfl_up_sync_i32(~0ull, l, 3) == (l >= 3 ? l - 3 : l)); if (!c_) atomicOr(out + 3, 1 << 2); ok &= c_; }
+  { const bool c_ = (__ballot_sync(~0ull, (l & 1) != 0) == 0xaaaaaaaaaaaaaaaaull); if (!c_) atomicOr(out + 3, 1 << 3); ok &= c_; }
+  { const bool c_ = (ntid(0) == 128 && xor_max<32>((float)l) == (float)(l | 32) && xor_max<16>((float)l) == (float)(l | 16)); if (!c_) atomicOr(out + 3, 1 << 4); ok &= c_; }
+  // one atomic per wave: two waves -> the counter ends at 2, every lane of a wave sees the same old value
+  __shared__ int s_cnt;
+  if (t == 0) s_cnt = 0;
+  __syncthreads_();
+  const int old = atomic_add_per_warp(&s_cnt, 1, WORKGROUP, RELAXED);
+  { const bool c_ = (old == __shfl_sync_i32(~0ull, old, 0)); if (!c_) atomicOr(out + 3, 1 << 5); ok &= c_; }
+  __syncthreads_();
+  { const bool c_ = (s_cnt == 2); if (!c_) atomicOr(out + 3, 1 << 6); ok &= c_; }
+  // multimem store: the same slot on every rank gets this rank's lane values (rank-tagged), then everybody
+  // arrives at every rank's counter and waits for all arrivals
+  multimem_st_v4(ctx, buf + (w + 2 + me) * 128 + t, (uint32_t)(me + 1), (uint32_t)t, 0u, 0u);
+  drain_stores();
+  for (int r = 0; r < w; ++r) arrive_inc(symm_at(ctx, sync, r), 0, 1, SYS);
+  const bool arrived = wait_eq(sync, 0, w, SYS);
+  // every rank's tagged vector must be here now
+  for (int r = 0; r < w; ++r) {
+    const uint4 v = load_v4_b32(buf + (w + 2 + r) * 128 + t);
+    { const bool c_ = (v.x == (uint32_t)(r + 1) && v.y == (uint32_t)t); if (!c_) atomicOr(out + 3, 1 << 7); ok &= c_; }
+  }
+  // CAS / scoped ld / st / red_release on a private word
+  if (t == 0) {
+    int* word = sync + 1;
+    st(word, 5, GPU, RELEASE);
+    { const bool c_ = (ld_acquire(word, GPU) == 5 && atomic_cas(word, 5, 9, SYS, ACQ_REL) == 5 && atomic_cas(word, 5, 1, GPU, RELAXED) == 9); if (!c_) atomicOr(out + 3, 1 << 8); ok &= c_; }
+    red_release(word, 3, GPU);
+    { const bool c_ = (atomic_add(word, 0, GPU, ACQUIRE) == 12); if (!c_) atomicOr(out + 3, 1 << 9); ok &= c_; }
+    st_b32(word, 77u);
+    { const bool c_ = (ld_b32(word) == 77u); if (!c_) atomicOr(out + 3, 1 << 10); ok &= c_; }
+  }
+  const unsigned long long good = __ballot_sync(~0ull, ok);
+  if (l == 0) out[t >> 6] = good == ~0ull ? 1 : 0;
+  if (t == 0) out[2] = arrived ? 1 : 0;
+}
+
+// Load-reduce on its own (after a host-side barrier: every rank's slot is final): sums eight bf16 per lane over ranks.
+__global__ void language_extra_ld_reduce_kernel(SymmCtx ctx, const uint4* src, uint4* dst) {
+  dst[threadIdx.x] = tdist::ext::multimem_ld_reduce_v4_bf16(ctx, src + threadIdx.x);
+}
+
 // Grid barrier check: in round r every workgroup publishes r+1 in its own word, crosses the
 // barrier, and must then read r+1 from EVERY workgroup's word; a second barrier keeps round r+1's
 // stores behind round r's reads.  bad[0] counts stale reads, bad[1] timeouts.
@@ -156,6 +214,19 @@ TDIST_API int tdist_test_shmem_api(const SymmCtx* ctx, int* buf, uint64_t* sig, 
 }
 TDIST_API int tdist_test_atomics(int* word, int* out, void* stream) {
   hipLaunchKernelGGL(atomics_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, word, out);
+  TDIST_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// buf: symmetric uint4 [(2 * num_ranks + 2) * 128]; sync: symmetric int[4], zero; out: int[4].
+TDIST_API int tdist_test_language_extra(const SymmCtx* ctx, void* buf, int* sync, int* out, void* stream) {
+  hipLaunchKernelGGL(language_extra_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, *ctx, (uint4*)buf, sync, out);
+  TDIST_HIP_TRY(hipGetLastError());
+  return 0;
+}
+TDIST_API int tdist_test_ld_reduce(const SymmCtx* ctx, const void* src, void* dst, void* stream) {
+  hipLaunchKernelGGL(language_extra_ld_reduce_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, *ctx, (const uint4*)src,
+                     (uint4*)dst);
   TDIST_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -47,3 +47,18 @@ def atomics_smoke(stream=None):
     out = torch.zeros(8, dtype=torch.int32, device="cuda")
     _lib.check(_lib.hip().tdist_test_atomics(_lib.ptr(word), _lib.ptr(out), _lib.stream_handle(stream)), "atomics")
     return word, out
+
+
+def language_extra_smoke(buf, sync, out, env=None, stream=None):
+    """Run the language_extra test kernel (csrc/ops/primitives_test.hip) on this rank: ``buf`` symmetric uint4
+    area of (2 w + 2) x 128 vectors (int32 [(2 w + 2) * 512]), ``sync`` symmetric int32 [4] (zero), ``out`` int32 [4]."""
+    cs = (env or get_env()).heap.ctx_struct()
+    _lib.check(_lib.hip().tdist_test_language_extra(ctypes.byref(cs), _lib.ptr(buf), _lib.ptr(sync), _lib.ptr(out),
+                                                    _lib.stream_handle(stream)), "language_extra")
+
+
+def ld_reduce_smoke(src, dst, env=None, stream=None):
+    """dst[128 x 8 bf16] = sum over ranks of the symmetric ``src`` (multimem_ld_reduce_v4_bf16)."""
+    cs = (env or get_env()).heap.ctx_struct()
+    _lib.check(_lib.hip().tdist_test_ld_reduce(ctypes.byref(cs), _lib.ptr(src), _lib.ptr(dst), _lib.stream_handle(stream)),
+               "ld_reduce")
