@@ -14,6 +14,7 @@
   do {                                                                           \
     hipError_t _e = (expr);                                                      \
     if (_e != hipSuccess) {                                                      \
+      (void)hipGetLastError(); /* reported through the return code, not left for the next caller */ \
       tdist_set_last_error(#expr, (int)_e, __FILE__, __LINE__);                  \
       return (int)_e;                                                            \
     }                                                                            \
@@ -47,6 +48,10 @@ struct SymmCtx {
   int num_extra;
   int pad_;
   uint64_t extra_base[TDIST_MAX_EXTRA_SEGMENTS][TDIST_MAX_RANKS];
+  // Virtual-memory-management arena (runtime_hip.cc: tdist_vmm_*): one contiguous range of vmm_bytes
+  // per rank, any size, holds the tensors that do not fit a hipIpc segment.  0 = not created.
+  uint64_t vmm_bytes;
+  uint64_t vmm_base[TDIST_MAX_RANKS];
 };
 
 // Spin budget: every device-side wait gives up after this many 100 MHz ticks

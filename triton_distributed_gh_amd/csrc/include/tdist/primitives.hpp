@@ -26,8 +26,8 @@ enum MemSemantic : int { SEM_RELAXED = 0, SEM_ACQUIRE = 1 };
 __device__ __forceinline__ int rank(const SymmCtx& ctx) { return ctx.rank; }
 __device__ __forceinline__ int num_ranks(const SymmCtx& ctx) { return ctx.num_ranks; }
 
-// Translate a pointer into this rank's symmetric arena (data segment or signal arena) to the
-// same object inside `peer`'s arena.  Pointers outside both arenas are returned unchanged
+// Translate a pointer into this rank's symmetric arena (data segment, signal arena or the
+// virtual-memory-management arena) to the same object inside `peer`'s arena.  Pointers outside both arenas are returned unchanged
 // when peer == rank and are otherwise invalid.
 template <typename T>
 __device__ __forceinline__ T* symm_at(const SymmCtx& ctx, T* ptr, int peer) {
@@ -40,6 +40,8 @@ __device__ __forceinline__ T* symm_at(const SymmCtx& ctx, T* ptr, int peer) {
     const uint64_t eb = ctx.extra_base[k][ctx.rank];
     if (p - eb < ctx.heap_bytes) return reinterpret_cast<T*>(ctx.extra_base[k][peer] + (p - eb));
   }
+  const uint64_t vb = ctx.vmm_base[ctx.rank];
+  if (p - vb < ctx.vmm_bytes) return reinterpret_cast<T*>(ctx.vmm_base[peer] + (p - vb));
   return ptr;
 }
 

@@ -213,3 +213,94 @@ TDIST_API int tdist_ag_push_full_mesh(int rank, int num_ranks, const void* local
   }
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Virtual-memory-management arena: a symmetric heap of any size.
+//
+// One hipIpc mapping stays below 2 GiB on this stack, so a heap sized for a 288 GB device cannot be
+// ONE hipMalloc shared through hipIpc.  Here each rank reserves a contiguous virtual range per rank
+// of the node (its own and one per peer), commits physical memory in chunks on demand
+// (hipMemCreate), maps its own chunks at the next offset of its own range, exports each chunk as a
+// dmabuf file descriptor, and maps the descriptors received from a peer at the SAME offset of that
+// peer's range.  Addresses inside a range are contiguous, so a symmetric tensor may span any number
+// of chunks and peer translation stays `base[peer] + offset`.  The descriptors travel between the
+// processes over a Unix-domain socket (utils/vmm.py); this file only wraps the driver calls.
+// Role in the reference: rocshmem_malloc on the rocSHMEM symmetric heap
+// (shmem/rocshmem_bind/pyrocshmem/src/pyrocshmem.cc:101-113).
+// ---------------------------------------------------------------------------------------------
+static hipMemAllocationProp vmm_prop(int dev, int uncached) {
+  hipMemAllocationProp prop;
+  memset(&prop, 0, sizeof(prop));
+  prop.type = uncached ? hipMemAllocationTypeUncached : hipMemAllocationTypePinned;
+  prop.requestedHandleType = hipMemHandleTypePosixFileDescriptor;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = dev;
+  return prop;
+}
+
+TDIST_API int tdist_vmm_granularity(int dev, int uncached, unsigned long long* out) {
+  hipMemAllocationProp prop = vmm_prop(dev, uncached);
+  size_t g = 0;
+  TDIST_HIP_TRY(hipMemGetAllocationGranularity(&g, &prop, hipMemAllocationGranularityRecommended));
+  *out = g;
+  return 0;
+}
+
+TDIST_API int tdist_vmm_reserve(void** out, unsigned long long bytes, unsigned long long align) {
+  TDIST_HIP_TRY(hipMemAddressReserve(out, bytes, align, nullptr, 0));
+  return 0;
+}
+
+TDIST_API int tdist_vmm_unreserve(void* va, unsigned long long bytes) {
+  TDIST_HIP_TRY(hipMemAddressFree(va, bytes));
+  return 0;
+}
+
+// Physical chunk on device `dev`; *handle_out is the driver's generic allocation handle.
+TDIST_API int tdist_vmm_create(int dev, int uncached, unsigned long long bytes, unsigned long long* handle_out) {
+  hipMemAllocationProp prop = vmm_prop(dev, uncached);
+  hipMemGenericAllocationHandle_t h;
+  TDIST_HIP_TRY(hipMemCreate(&h, bytes, &prop, 0));
+  *handle_out = (unsigned long long)(uintptr_t)h;
+  return 0;
+}
+
+TDIST_API int tdist_vmm_export_fd(unsigned long long handle, int* fd_out) {
+  int fd = -1;
+  TDIST_HIP_TRY(hipMemExportToShareableHandle(&fd, (hipMemGenericAllocationHandle_t)(uintptr_t)handle,
+                                              hipMemHandleTypePosixFileDescriptor, 0));
+  *fd_out = fd;
+  return 0;
+}
+
+TDIST_API int tdist_vmm_import_fd(int fd, unsigned long long* handle_out) {
+  hipMemGenericAllocationHandle_t h;
+  // (this runtime reads the descriptor THROUGH the pointer; passing the descriptor's value cast to a
+  // pointer, as the CUDA driver API takes it, crashes inside the call)
+  int os_handle = fd;
+  TDIST_HIP_TRY(hipMemImportFromShareableHandle(&h, (void*)&os_handle, hipMemHandleTypePosixFileDescriptor));
+  *handle_out = (unsigned long long)(uintptr_t)h;
+  return 0;
+}
+
+// Map a chunk at `va` and give device `dev` (the caller's device) read / write access to it.
+TDIST_API int tdist_vmm_map(void* va, unsigned long long bytes, unsigned long long handle, int dev) {
+  TDIST_HIP_TRY(hipMemMap(va, bytes, 0, (hipMemGenericAllocationHandle_t)(uintptr_t)handle, 0));
+  hipMemAccessDesc desc;
+  memset(&desc, 0, sizeof(desc));
+  desc.location.type = hipMemLocationTypeDevice;
+  desc.location.id = dev;
+  desc.flags = hipMemAccessFlagsProtReadWrite;
+  TDIST_HIP_TRY(hipMemSetAccess(va, bytes, &desc, 1));
+  return 0;
+}
+
+TDIST_API int tdist_vmm_unmap(void* va, unsigned long long bytes) {
+  TDIST_HIP_TRY(hipMemUnmap(va, bytes));
+  return 0;
+}
+
+TDIST_API int tdist_vmm_release(unsigned long long handle) {
+  TDIST_HIP_TRY(hipMemRelease((hipMemGenericAllocationHandle_t)(uintptr_t)handle));
+  return 0;
+}

@@ -10,8 +10,13 @@ arena and ONE small signal arena at start-up, the handles are exchanged once ove
 One hipIpc mapping cannot reach 2 GiB on this stack (``MAX_IPC_BYTES``), so the data arena GROWS
 in equal segments of at most that size, on demand and collectively: when a symmetric tensor does
 not fit the segments that exist, every rank allocates one more, the handles are exchanged, and the
-tensor is carved from it.  A tensor lives inside ONE segment (so it must be smaller than a
-segment); the device-side translation checks the segments in turn.
+tensor is carved from it.  A tensor of these arenas lives inside ONE segment; the device-side
+translation checks the segments in turn.
+
+A tensor that is larger than a segment (or arrives when all segments are full) goes to a third kind
+of arena, created on first need: ``utils/vmm.py`` - one contiguous virtual range per rank, physical
+chunks committed on demand and shared as dmabuf file descriptors - whose capacity defaults to 7/8 of
+the device memory (``TDIST_SYMM_VMM_BYTES``).  ``TDIST_HEAP_KIND=vmm`` sends every data tensor there.
 
 Two backends share this file:
 * ``hip``  - ``hipMalloc`` / ``hipExtMallocWithFlags`` + ``hipIpcGet/OpenMemHandle``;
@@ -52,6 +57,8 @@ class SymmCtxStruct(ctypes.Structure):
         ("num_extra", ctypes.c_int),
         ("_pad", ctypes.c_int),
         ("extra_base", (ctypes.c_uint64 * MAX_RANKS) * MAX_EXTRA_SEGMENTS),
+        ("vmm_bytes", ctypes.c_uint64),
+        ("vmm_base", ctypes.c_uint64 * MAX_RANKS),
     ]
 
 
@@ -161,6 +168,8 @@ class SymmetricHeap:
         self._owned = []
         self._shm_names: List[str] = []
         self._closed = False
+        self._vmm, self._vmm_failed = None, ""
+        self.heap_kind = os.environ.get("TDIST_HEAP_KIND", "ipc")   # "ipc" | "vmm" (every data tensor on the VMM arena)
         if backend == "hip":
             self._init_hip()
         else:
@@ -206,6 +215,7 @@ class SymmetricHeap:
             h._owned = [bases[a][r] for a in bases] if backend == "hip" else []
             h._opened, h._shm_names, h._closed, h._tensor_info = [], [], False, {}
             h._virtual = True
+            h._vmm, h._vmm_failed, h.heap_kind = None, "", "ipc"
             h.data_mode = 0
             heaps.append(h)
         return heaps
@@ -279,7 +289,15 @@ class SymmetricHeap:
 
     # ------------------------------------------------------------------ allocation
     def _data_arenas(self) -> List[str]:
+        """The hipIpc data segments ("data", "data1", ...), in creation order."""
         return [a for a in self._alloc if a.startswith("data")]
+
+    def _arena_size(self, arena: str) -> int:
+        if arena == "sig":
+            return self.sig_bytes
+        if arena == "vmm":
+            return self._vmm.capacity
+        return self.heap_bytes
 
     def _carve(self, arena: str, shape: Sequence[int], dtype: torch.dtype, align: int):
         """Returns (arena name actually used, offset, nbytes)."""
@@ -287,6 +305,9 @@ class SymmetricHeap:
         nbytes = numel * torch.empty((), dtype=dtype).element_size()
         if arena != "data":
             return arena, self._alloc[arena].alloc(nbytes, align), nbytes
+        can_vmm = self.backend == "hip" and not getattr(self, "_virtual", False)
+        if can_vmm and self.heap_kind == "vmm":
+            return self._carve_vmm(nbytes, align)
         for name in self._data_arenas():
             try:
                 return name, self._alloc[name].alloc(nbytes, align), nbytes
@@ -294,12 +315,41 @@ class SymmetricHeap:
                 continue
         n_seg = len(self._data_arenas())
         if nbytes > self.heap_bytes or n_seg > MAX_EXTRA_SEGMENTS or (n_seg + 1) * self.heap_bytes > self.max_heap_bytes:
+            if can_vmm:
+                return self._carve_vmm(nbytes, align)
             raise MemoryError(
                 f"symmetric heap exhausted: need {nbytes} bytes, {n_seg} segment(s) of {self.heap_bytes} bytes in use "
                 f"(a tensor must fit one segment; capacity {self.max_heap_bytes}: raise TDIST_SYMM_HEAP_BYTES / "
                 "TDIST_SYMM_HEAP_MAX_BYTES)")
         name = self._grow()
         return name, self._alloc[name].alloc(nbytes, align), nbytes
+
+    def _carve_vmm(self, nbytes: int, align: int):
+        """Collective: carve from the VMM arena (created on first use), committing chunks as needed."""
+        from .vmm import VmmArena, VmmUnsupported, default_capacity
+
+        if self._vmm_failed:
+            raise MemoryError(f"symmetric tensor of {nbytes} bytes does not fit a hipIpc segment ({self.heap_bytes} bytes) "
+                              f"and the VMM arena is unavailable here: {self._vmm_failed}")
+        if self._vmm is None:
+            chunk = int(os.environ.get("TDIST_SYMM_VMM_CHUNK_BYTES", 1 << 30))
+            self._vmm = VmmArena(self.rank, self.world_size, self.group, default_capacity(), chunk,
+                                 uncached=self.data_mode != 0)
+            self._alloc["vmm"] = _FreeList(self._vmm.capacity)
+            self._bases["vmm"] = list(self._vmm.bases)
+            self._flat["vmm"] = [_wrap_device(b, self._vmm.capacity, self) for b in self._vmm.bases]
+        off = self._alloc["vmm"].alloc(nbytes, max(align, 256))
+        try:
+            self._vmm.commit(off + nbytes)
+        except VmmUnsupported as exc:                 # raised on every rank together
+            self._alloc["vmm"].release(off)
+            self._vmm_failed = str(exc)
+            if self.heap_kind == "vmm":               # everything was asked to live there: fall back to the segments
+                self.heap_kind = "ipc"
+                return self._carve("data", [nbytes], torch.uint8, align)
+            raise MemoryError(f"symmetric tensor of {nbytes} bytes does not fit a hipIpc segment ({self.heap_bytes} "
+                              f"bytes) and the VMM arena is unavailable here: {exc}") from exc
+        return "vmm", off, nbytes
 
     def _grow(self) -> str:
         """Collective: add one data segment on every rank (same order everywhere, because symmetric
@@ -395,7 +445,7 @@ class SymmetricHeap:
         base = t.data_ptr()
         for arena in self._alloc:
             b = self._bases[arena][self.rank]
-            size = self.sig_bytes if arena == "sig" else self.heap_bytes
+            size = self._arena_size(arena)
             if b <= base < b + size:
                 return SymmTensorInfo(arena, base - b, t.numel() * t.element_size())
         raise ValueError("tensor is not inside this rank's symmetric heap")
@@ -437,13 +487,17 @@ class SymmetricHeap:
         for k, name in enumerate(extra):
             for r in range(self.world_size):
                 c.extra_base[k][r] = self._bases[name][r]
+        if self._vmm is not None:
+            c.vmm_bytes = self._vmm.capacity
+            for r in range(self.world_size):
+                c.vmm_base[r] = self._vmm.bases[r]
         return c
 
     def translate(self, ptr: int, peer: int) -> int:
         """Host-side twin of the device ``symm_at``: the address of the same symmetric byte on ``peer``."""
         for arena in self._alloc:
             b = self._bases[arena][self.rank]
-            size = self.sig_bytes if arena == "sig" else self.heap_bytes
+            size = self._arena_size(arena)
             if b <= ptr < b + size:
                 return self._bases[arena][peer] + (ptr - b)
         raise ValueError("pointer is not inside this rank's symmetric heap")
@@ -460,6 +514,8 @@ class SymmetricHeap:
             return
         self._closed = True
         self._flat = {"data": [], "sig": []}
+        if self._vmm is not None:
+            self._vmm.close(sync_group)
         if getattr(self, "_virtual", False) and self.backend == "host":
             return
         if self.backend == "hip":
