@@ -303,11 +303,18 @@ def test_model_modes_match_single_rank(name, mode, w):
         vc.close()
 
 
-@pytest.mark.parametrize("mode", ["triton_dist_AR", "triton_dist_gemm_ar", "triton_dist"])
-def test_fused_backend_decode_replays_from_graph(mode):
+@pytest.mark.parametrize("mode", ["triton_dist_AR", "triton_dist_gemm_ar", "triton_dist", "triton_dist-256tile"])
+def test_fused_backend_decode_replays_from_graph(mode, monkeypatch):
     """World size 2: each rank captures ONE decode step and replays it; the all-reduce kernels and the
     low-latency forms of GEMM + all-reduce / AG + GEMM / GEMM + RS advance their call number on the device,
-    so every replay matches the single-rank model."""
+    so every replay matches the single-rank model.  ``triton_dist-256tile`` switches the low-latency forms
+    off, so the two-row shards reach the 256x256-tile AG + GEMM / GEMM + RS kernels as tiles that straddle
+    ranks (the configuration whose replay faulted while a memset node preceded every launch)."""
+    if mode.endswith("-256tile"):
+        from triton_distributed_gh_amd.ops import tp_ll
+
+        monkeypatch.setattr(tp_ll, "LL_MAX_M", 0)
+        mode = "triton_dist"
     name, w, bsz, prompt, L, steps = "tdist/tiny-dense", 2, 4, 16, 128, 4
     sharded = mode == "triton_dist"
     per = bsz // w

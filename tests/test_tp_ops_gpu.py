@@ -158,10 +158,13 @@ def test_fused_ops_on_a_grown_heap():
         vc.close()
 
 
-@pytest.mark.parametrize("w,M,N,K", [(2, 1024, 1024, 512), (4, 1024, 2048, 1024)])
+@pytest.mark.parametrize("w,M,N,K", [(2, 1024, 1024, 512), (4, 1024, 2048, 1024), (2, 640, 1024, 512),
+                                     (4, 1152, 1024, 512)])
 def test_ag_gemm_gemm_rs_pair_replays_from_graph(w, M, N, K):
     """The TP MLP pair captured once per rank and replayed: both kernels number their calls on the
-    device, so every replay (and an eager call in between) uses a fresh epoch and buffer parity."""
+    device, so every replay (and an eager call in between) uses a fresh epoch and buffer parity.  The last
+    two shapes give every rank 320 / 288 rows: 256-row tiles that straddle ranks (more rows than the
+    low-latency forms take, so the 256x256-tile kernels run)."""
     vc = VirtualCluster(w, heap_bytes=1 << 27)
     try:
         ag = vc.collective(lambda r, env: create_ag_gemm_intra_node_context(

@@ -5,11 +5,11 @@ Reference: python/triton_dist/models/engine.py:36-189.  Back-ends: ``torch`` (RC
 all-reduce kernels) and ``triton_dist_gemm_ar`` (GEMM fused with the all-reduce).
 
 Graph replay is used where the whole step is replay-safe: the torch back-end, any back-end at
-world size 1, and at any world size ``triton_dist_AR`` and - for decode batches up to 256 rows
-(``ops.gemm_ar.LL_MAX_M`` / ``ops.tp_ll.LL_MAX_M``) - ``triton_dist_gemm_ar`` and ``triton_dist``: the
-all-reduce kernels and the low-latency forms of GEMM + all-reduce, AG + GEMM and GEMM + RS keep their call
-number on the device, so a replayed launch picks a fresh epoch and buffer parity by itself
-(csrc/include/tdist/call_state.hpp).  Larger decode batches of the fused back-ends, and MoE models in
+world size 1, and at any world size ``triton_dist_AR``, ``triton_dist`` (dense models, any decode batch)
+and - for decode batches up to 256 rows (``ops.gemm_ar.LL_MAX_M``) - ``triton_dist_gemm_ar``: the
+all-reduce kernels, AG + GEMM, GEMM + RS (both tile forms) and the low-latency GEMM + all-reduce keep their
+call number on the device, so a replayed launch picks a fresh epoch and buffer parity by itself
+(csrc/include/tdist/call_state.hpp).  Larger decode batches of ``triton_dist_gemm_ar``, and MoE models in
 ``triton_dist`` mode (the MoE ops number their calls on the host), run the decode loop eagerly at world
 size > 1 - the ops refuse capture rather than race (utils/distributed.py: forbid_graph_capture).
 """
@@ -134,11 +134,10 @@ class Engine:
         if self.backend == "triton_dist":
             next_token = next_token.split(bsz // m.world_size, dim=0)[m.rank].contiguous()
         from ..ops.gemm_ar import LL_MAX_M
-        from ..ops.tp_ll import LL_MAX_M as TP_LL_MAX_M
         use_graph = not self.no_graph and m.device.type == "cuda" and (
             self.backend in ("torch", "triton_dist_AR") or m.world_size == 1
             or (self.backend == "triton_dist_gemm_ar" and bsz <= LL_MAX_M)
-            or (self.backend == "triton_dist" and bsz <= TP_LL_MAX_M and not self._is_moe()))
+            or (self.backend == "triton_dist" and not self._is_moe()))
         if use_graph:
             self.model_launch = self._init_cuda_graph(bsz)
         else:

@@ -205,9 +205,9 @@ def ag_gemm_intra_node_op(a, b, c, ctx: AllGatherGEMMTensorParallelContext):
     # The in-kernel producer numbers its calls on the device (ctx.state); every other producer takes
     # parity and epoch from the host and must not be captured in a graph.
     device_calls = ctx.backend == "hip" and ctx.producer == "kernel" and ctx.state is not None
-    # Capture is accepted for the configuration covered by the replay tests: whole 256-row tiles per
-    # rank.  (Shapes whose tiles straddle ranks run the same kernels eagerly.)
-    if not device_calls or (M_per_rank % _BM != 0 and os.environ.get("TDIST_ALLOW_STRADDLE_CAPTURE") != "1"):
+    # With device-side numbering the launch is one kernel node (no memset node: see ops/gemm_rs.py for what
+    # a captured memset did) and records into a HIP graph at any shape, tiles straddling ranks included.
+    if not device_calls:
         forbid_graph_capture("ag_gemm", w)
     parity = ctx.call_count & 1
     epoch = ctx.call_count % EPOCH_MOD + 1

@@ -127,9 +127,13 @@ def gemm_rs_intra_node_op(a, b, ctx: GEMMReduceScatterTensorParallelContext, out
             and out.stride(0) % 8 == 0 and out.data_ptr() % 16 == 0:
         # decode-sized call: mid-M tile body, device-side call numbering, capturable (ops/tp_ll.py)
         return tp_ll.gemm_rs_ll(ctx.ll, env, rank, w, a, b, out, ctx.num_ctas)
-    # Capture is accepted for the configuration covered by the replay tests (whole 256-row tiles
-    # per rank); the kernels number their calls on the device either way.
-    if ctx.backend != "hip" or (M_per_rank % 256 != 0 and os.environ.get("TDIST_ALLOW_STRADDLE_CAPTURE") != "1"):
+    # The kernel numbers its calls on the device and re-arms its own counters, so a launch is ONE kernel
+    # node and records into a HIP graph at any shape.  (It used to be preceded by a hipMemsetAsync of the
+    # counters: that memset NODE - not the kernel - faulted with an illegal address when the graphs of two
+    # ranks replayed decode-sized launches side by side; putting only the functionally redundant memset back
+    # in front of the unchanged kernel brings the fault back.  No op of this package that can be captured
+    # issues a memset any more.)
+    if ctx.backend != "hip":
         forbid_graph_capture("gemm_rs", w)
     parity = ctx.call_count & 1
     epoch = ctx.call_count % EPOCH_MOD + 1
