@@ -88,3 +88,38 @@ def test_user_ring_queue_on_four_virtual_ranks():
                 assert torch.equal(outs[r], ins[(r - 1) % w]), f"launch {it}, rank {r}: wrong items"
     finally:
         vc.close()
+
+
+def test_extern_device_library_links_into_the_user_kernel(tmp_path):
+    """The device-side form of extern_call: a kernel file that only DECLARES two device functions, built
+    together with the library that defines them (cross-compiles without a GPU)."""
+    if rt.hipcc_path() is None:
+        pytest.skip("no hipcc")
+    k = ROOT / "tutorials/kernels/extern_call_user.hip"
+    lib = ROOT / "tutorials/kernels/extern_lib_user.hip"
+    with pytest.raises(RuntimeError):                       # without the library the symbols stay undefined
+        rt.compile_hip(k, tmp_path / "alone.hsaco")
+    co = rt.compile_hip(k, tmp_path / "with_lib.hsaco", extern_libs=[lib])
+    assert co.exists() and co.stat().st_size > 1000 and co.read_bytes()[:4] == b"\x7fELF"
+    assert rt.compile_hip(k, tmp_path / "with_lib.hsaco", extern_libs=[lib]) == co      # digest hit, no rebuild
+
+
+@pytest.mark.gpu
+def test_extern_device_library_kernel_runs(tmp_path):
+    from triton_distributed_gh_amd.utils.symm import SymmetricHeap
+
+    co = rt.compile_hip(ROOT / "tutorials/kernels/extern_call_user.hip", tmp_path / "ext.hsaco",
+                        extern_libs=[ROOT / "tutorials/kernels/extern_lib_user.hip"])
+    kern = rt.load_module(co).get("silu_and_tag")
+    heap = SymmetricHeap(0, 1, None, "hip", heap_bytes=1 << 22)
+    try:
+        n = 1000
+        x = torch.randn(n, device="cuda")
+        out = torch.empty(n, device="cuda")
+        tags = torch.empty(n, dtype=torch.int32, device="cuda")
+        kern((n + 255) // 256, 256, None, heap, x, out, tags, n)
+        torch.cuda.synchronize()
+        torch.testing.assert_close(out, torch.nn.functional.silu(x), atol=1e-5, rtol=1e-5)
+        assert tags.tolist() == [i * 31 for i in range(n)]
+    finally:
+        heap.close()

@@ -83,26 +83,40 @@ __device__ __forceinline__ uint4 pack8(const float* v) {
   return r;
 }
 
+// Operand pointers come out of the op table in memory, so the compiler sees generic pointers and would
+// emit FLAT loads / stores: those also count on the LDS counter, return out of order (a counted
+// s_waitcnt vmcnt(N) means nothing for them) and cost an aperture check each.  Every hot access goes
+// through these casts to the global address space instead.
+#define TDIST_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ const TDIST_GLOBAL T* as_global(const void* p) {
+  return (const TDIST_GLOBAL T*)(uintptr_t)p;
+}
+template <class T>
+__device__ __forceinline__ TDIST_GLOBAL T* as_global_mut(void* p) {
+  return (TDIST_GLOBAL T*)(uintptr_t)p;
+}
+
 // Write-through (sc1) stores: the bytes leave this XCD's L2 at once, so a hand-off needs no release
 // fence - only a drain (s_waitcnt vmcnt(0)) in every storing wave before the flag.  4 / 8 bytes per
 // store (agent-scope relaxed atomic stores lower to global_store ... sc1).
 __device__ __forceinline__ void st_wt32(void* p, uint32_t v) {
-  __hip_atomic_store((uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(as_global_mut<uint32_t>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void st_wt128(void* p, const uint4& v) {
-  __hip_atomic_store((uint64_t*)p, ((uint64_t)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store((uint64_t*)p + 1, ((uint64_t)v.w << 32) | v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(as_global_mut<uint64_t>(p), ((uint64_t)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(as_global_mut<uint64_t>(p) + 1, ((uint64_t)v.w << 32) | v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // L1-bypassing (sc1) 16-byte load of handed-off bytes: with write-through producer stores and every
 // consumer load of this form, a hand-off needs no acquire fence (no L1 invalidate) either.
 __device__ __forceinline__ uint4 ld_sc1_128(const void* p) {
-  const uint64_t lo = __hip_atomic_load((const uint64_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const uint64_t hi = __hip_atomic_load((const uint64_t*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint64_t lo = __hip_atomic_load(as_global<uint64_t>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint64_t hi = __hip_atomic_load(as_global<uint64_t>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return uint4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
 }
 __device__ __forceinline__ float ld_sc1_bf16(const uint16_t* p) {
   // 4-byte aligned container load, then pick the half
-  const uint32_t w = __hip_atomic_load((const uint32_t*)((uintptr_t)p & ~(uintptr_t)3), __ATOMIC_RELAXED,
+  const uint32_t w = __hip_atomic_load(as_global<uint32_t>((const void*)((uintptr_t)p & ~(uintptr_t)3)), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
   return bf2f((uint16_t)(((uintptr_t)p & 2) ? (w >> 16) : (w & 0xffffu)));
 }
@@ -110,7 +124,16 @@ __device__ __forceinline__ float ld_sc1_bf16(const uint16_t* p) {
 // Streamed-once weights: non-temporal loads keep them from evicting the activations in L2.
 __device__ __forceinline__ uint4 ld_nt128(const void* p) {
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-  const u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
+  const u32x4 v = __builtin_nontemporal_load(as_global<u32x4>(p));
+  return uint4{v[0], v[1], v[2], v[3]};
+}
+
+// Activation fragment through a bounds-checked buffer descriptor, L1-bypassing (sc1, aux bit 4): an offset
+// past the descriptor's size reads as zero, so rows beyond the batch and a window that starts before the
+// row need no branch.  `off` = byte offset of the lane, `imm` a compile-time addend (instruction offset).
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4_t;
+__device__ __forceinline__ uint4 ld_x_frag(__amdgpu_buffer_rsrc_t rsrc, int off, int imm) {
+  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + imm, 0, 16);
   return uint4{v[0], v[1], v[2], v[3]};
 }
 
@@ -124,30 +147,124 @@ __device__ __forceinline__ float wave_sum(float v) {
 // p0 x, p1 W, p2 out, p3 residual (or null); i0 M, i1 N, i2 K, i3 ldx, i4 ldo, i5 ldr, i6 BN (16/32/64),
 // i7 mode: 0 plain, 1 gate/up pair (W rows [0,N) = gate, [N,2N) = up; out = silu(gate) * up).
 // Tile t covers columns [t*BN, (t+1)*BN).  Waves: WN = BN/16 column groups x WK = 4/WN K-slices.
-__device__ __forceinline__ void task_linear(const MegaOp& op, int tile, float* smem) {
-  using VT = tdist::gemm::bf16x8;
-  const int M = op.i[0], N = op.i[1], K = op.i[2];
-  const long long ldx = op.i[3], ldo = op.i[4], ldr = op.i[5];
-  const int BN = op.i[6], mode = op.i[7];
-  const int WN = BN >> 4, WK = 4 / WN;
+//
+// A task runs in two steps.  linear_issue() - called BEFORE the task's dependencies are waited for -
+// puts the first PF weight loads of every wave in flight (weights depend on nobody), so the memory
+// round trip of a task's first bytes, and with 16-column tiles of a 4096-deep layer ALL its bytes, overlaps
+// the wait for the producer and the write-out of the previous task.  It issues exactly PF loads per wave
+// whatever the shape (addresses past the wave's K range are clamped and their products multiplied by a
+// zero activation), because the deferred publish of the previous task counts them (s_waitcnt vmcnt(PF)).
+// task_linear() then loads the activations, consumes the prefetched fragments and streams the rest.
+constexpr int LIN_PF = 8;
+struct LinearPrefetch {
+  uint4 w[LIN_PF];
+};
+
+struct LinearGeom {
+  int WN, WK, wn, wk, li, lg, n0, ks0, ks1, ksteps;
+  int kb;                     // K-step held by prefetched fragment 0 (fragment u holds K-step kb + u)
+  const uint16_t *wr, *ur;    // this lane's gate / plain row and up row, at its 16-byte column of K-step 0
+};
+
+// The prefetch window of a wave is LIN_PF (mode 1: LIN_PF / 2 per matrix half) consecutive K-steps read
+// at constant offsets from ONE base address per lane (32 per-load addresses would cost 64 registers).  It
+// starts at the wave's first K-step; where fewer K-steps than the window are left before the END OF THE
+// WEIGHT MATRIX (last rows of a short-K layer) it starts earlier, by the same amount in every lane.  K-steps
+// of the window outside [ks0, ks1) - the neighbouring wave's, the next row's - are loaded and discarded.
+__device__ __forceinline__ LinearGeom linear_geom(const MegaOp& op, int tile) {
+  LinearGeom g;
+  const int N = op.i[1], K = op.i[2], BN = op.i[6], mode = op.i[7];
+  g.WN = BN >> 4;
+  g.WK = 4 / g.WN;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wn = wave % WN, wk = wave / WN;
-  const int li = lane & 15, lg = lane >> 4;
-  const uint16_t* x = (const uint16_t*)op.p[0];
+  g.wn = wave % g.WN;
+  g.wk = wave / g.WN;
+  g.li = lane & 15;
+  g.lg = lane >> 4;
+  g.n0 = tile * BN + g.wn * 16;
+  const int ncol = min(g.n0 + g.li, N - 1);
+  g.ksteps = K / 32;
+  const int per = (g.ksteps + g.WK - 1) / g.WK;
+  g.ks0 = min(g.wk * per, g.ksteps);
+  g.ks1 = min(g.ks0 + per, g.ksteps);
   const uint16_t* W = (const uint16_t*)op.p[1];
-  const int n0 = tile * BN + wn * 16;
-  const int ncol = min(n0 + li, N - 1);
-  // K range of this wave (multiples of 32)
-  const int ksteps = K / 32;
-  const int per = (ksteps + WK - 1) / WK;
-  const int ks0 = wk * per, ks1 = min(ks0 + per, ksteps);
-  const uint16_t* xr = x + (long long)min(li, M - 1) * ldx + lg * 8;
-  const uint16_t* wr = W + (long long)ncol * K + lg * 8;
-  const uint16_t* ur = W + (long long)(ncol + N) * K + lg * 8;
-  const bool xvalid = li < M;
+  g.wr = W + (long long)ncol * K + g.lg * 8;
+  g.ur = W + (long long)(ncol + N) * K + g.lg * 8;
+  // K-steps from (last row any lane of this wave reads, ks0) to the end of the matrix; the gate half of a
+  // gate/up matrix is followed by the N up rows, so only the second half can come up short
+  const int rows = mode == 1 ? 2 * N : N;
+  const int last_row = min(g.n0 + 15, N - 1) + (mode == 1 ? N : 0);
+  const long long left = (long long)(rows - 1 - last_row) * g.ksteps + (g.ksteps - g.ks0);
+  const int PFm = mode == 1 ? LIN_PF / 2 : LIN_PF;
+  g.kb = g.ks0 - (left < PFm ? PFm - (int)left : 0);
+  return g;
+}
+
+__device__ __forceinline__ void linear_issue(const MegaOp& op, int tile, LinearPrefetch& pre) {
+  const LinearGeom g = linear_geom(op, tile);
+  constexpr int H = LIN_PF / 2;
+  // two bases, constant offsets: fragments [0, H) are K-steps kb .. kb + H of the (gate) row, fragments
+  // [H, 2H) the same K-steps of the up row (mode 1) or K-steps kb + H .. kb + 2H of the same row (mode 0)
+  const uint16_t* a = g.wr + (long long)g.kb * 32;
+  const uint16_t* b = op.i[7] == 1 ? g.ur + (long long)g.kb * 32 : a + H * 32;
+#pragma unroll
+  for (int u = 0; u < H; ++u) pre.w[u] = ld_nt128(a + u * 32);
+#pragma unroll
+  for (int u = 0; u < H; ++u) pre.w[H + u] = ld_nt128(b + u * 32);
+}
+
+__device__ __forceinline__ void task_linear(const MegaOp& op, int tile, float* smem, const LinearPrefetch& pre) {
+  using VT = tdist::gemm::bf16x8;
+  const int M = op.i[0], N = op.i[1];
+  const long long ldx = op.i[3], ldo = op.i[4], ldr = op.i[5];
+  const int mode = op.i[7];
+  const LinearGeom g = linear_geom(op, tile);
+  const int WN = g.WN, WK = g.WK, wn = g.wn, wk = g.wk, li = g.li, lg = g.lg, n0 = g.n0, ks1 = g.ks1;
+  const int lane = threadIdx.x & 63;
+  // activations [M, K] behind a descriptor of exactly their bytes; lanes of rows >= M point past its end
+  const int K = op.i[2];
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)op.p[0], 0, (int)(((M - 1) * ldx + K) * 2), 0x00020000);
+  const int xoff = li < M ? (int)((li * ldx + lg * 8) * 2) : (int)0x40000000;
+  const uint16_t* wr = g.wr;
+  const uint16_t* ur = g.ur;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
   constexpr int U = 8;
-  int ks = ks0;
+  // ---- the prefetched fragments: K-steps kb .. kb + PFm, of which [ks0, ks1) are this wave's ----
+  const int PFm = mode == 1 ? LIN_PF / 2 : LIN_PF;
+  const int xw = xoff + g.kb * 64;                          // (kb < 0: far past the end as an unsigned offset)
+  const int v0 = g.ks0 - g.kb, v1 = g.ks1 - g.kb;          // valid fragments: v0 <= u < v1
+  const uint4 zero4 = {0, 0, 0, 0};
+  constexpr int H = LIN_PF / 2;
+  constexpr int UB = H < U ? H : U;        // activation fragments loaded per batch
+#pragma unroll
+  for (int b = 0; b < H; b += UB) {
+    uint4 xv[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) xv[u] = ld_x_frag(xrs, xw, (b + u) * 64);
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const VT a = __builtin_bit_cast(VT, (b + u >= v0 && b + u < v1) ? xv[u] : zero4);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(VT, pre.w[b + u]), acc, 0, 0, 0);
+      if (mode == 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(VT, pre.w[H + b + u]), acc2, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // one batch of activation loads at a time (registers)
+  }
+  if (mode != 1) {
+#pragma unroll
+    for (int b = H; b < LIN_PF; b += UB) {
+      uint4 xv[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) xv[u] = ld_x_frag(xrs, xw, (b + u) * 64);
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const VT a = __builtin_bit_cast(VT, (b + u >= v0 && b + u < v1) ? xv[u] : zero4);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(VT, pre.w[b + u]), acc, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- the rest of the K range, streamed in batches of U ----
+  int ks = g.kb + PFm;                 // (>= ks1 whenever the window was moved back)
   for (; ks + U <= ks1; ks += U) {
     uint4 wv[U], xv[U], uv[U];
 #pragma unroll
@@ -156,8 +273,9 @@ __device__ __forceinline__ void task_linear(const MegaOp& op, int tile, float* s
 #pragma unroll
       for (int u = 0; u < U; ++u) uv[u] = ld_nt128(ur + (ks + u) * 32);
     }
+    const int xk = xoff + ks * 64;
 #pragma unroll
-    for (int u = 0; u < U; ++u) xv[u] = xvalid ? ld_sc1_128(xr + (ks + u) * 32) : uint4{0, 0, 0, 0};
+    for (int u = 0; u < U; ++u) xv[u] = ld_x_frag(xrs, xk, u * 64);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const VT a = __builtin_bit_cast(VT, xv[u]);
@@ -167,7 +285,7 @@ __device__ __forceinline__ void task_linear(const MegaOp& op, int tile, float* s
   }
   for (; ks < ks1; ++ks) {
     const uint4 wv = ld_nt128(wr + ks * 32);
-    const uint4 xv = xvalid ? ld_sc1_128(xr + ks * 32) : uint4{0, 0, 0, 0};
+    const uint4 xv = ld_x_frag(xrs, xoff + ks * 64, 0);
     const VT a = __builtin_bit_cast(VT, xv);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(VT, wv), acc, 0, 0, 0);
     if (mode == 1) {
@@ -447,28 +565,77 @@ __device__ __forceinline__ void task_prefetch(const MegaOp& op, int tile, int* s
   if (acc == 0x9e3779b9u && b1 < 0) *sink = (int)acc;
 }
 
+// The interpreter pipelines three things across task boundaries of a queue:
+//   * the record of task t+1 is fetched while task t runs (two LDS slots);
+//   * a linear task's first weight loads go out before its dependencies are waited for (linear_issue);
+//   * task t is PUBLISHED after task t+1's weight loads were issued: the wait that covers t's stores is a
+//     counted one (everything but the LIN_PF youngest memory operations of each wave), so the write-out
+//     of one task drains under the loads of the next instead of idling the queue.
 __global__ __launch_bounds__(256, 2) void mega_kernel(MegaParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int* s_task = (int*)smem;                  // [TASK_WORDS]
-  int* s_lens = s_task + TASK_WORDS;         // [16] effective kv lengths
+  int* s_task = (int*)smem;                  // [2][TASK_WORDS], then [16] effective kv lengths (task_attn_split)
+  int* s_lens = s_task + 2 * TASK_WORDS;     // [16] effective kv lengths
   char* work = smem + 256;                   // task scratch
   const int q = blockIdx.x;
   const int ntask = P.queue_len[q];
   const int* myq = P.queues + (long long)q * P.max_tasks * TASK_WORDS;
   int seen_op[MAX_DEPS] = {-1, -1, -1}, seen_lo[MAX_DEPS] = {0, 0, 0}, seen_hi[MAX_DEPS] = {0, 0, 0};
   int seen_next = 0;
+  if (ntask > 0 && threadIdx.x < TASK_WORDS) s_task[threadIdx.x] = myq[threadIdx.x];
+  __syncthreads();
+  int pend_type = 0, pend_op = 0, pend_tile = 0;      // task whose tile is computed but not yet published
+  auto publish = [&](bool loads_behind) {
+    // Tasks whose outputs are all write-through stores need only the drain + barrier; the attention
+    // and rope/kv-cache tasks store plain and pay one agent-scope release (L2 write-back).
+    if (loads_behind) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LIN_PF) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (threadIdx.x == 0) {
+      if (pend_type == TASK_ATTN_SPLIT || pend_type == TASK_ATTN_COMBINE || pend_type == TASK_QK_NORM_ROPE_KV) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      store_relaxed_agent(P.scoreboard + (long long)pend_op * P.max_tiles + pend_tile, P.epoch);
+    }
+  };
   for (int t = 0; t < ntask; ++t) {
-    __syncthreads();
-    if (threadIdx.x < TASK_WORDS) s_task[threadIdx.x] = myq[t * TASK_WORDS + threadIdx.x];
-    __syncthreads();
-    const int type = s_task[0], opi = s_task[1], tile = s_task[2], ndeps = s_task[3];
+    const int* rec = s_task + (t & 1) * TASK_WORDS;
+    // (workgroup-uniform words: kept in scalar registers, the vector file is needed for the weight prefetch)
+    const int type = __builtin_amdgcn_readfirstlane(rec[0]), opi = __builtin_amdgcn_readfirstlane(rec[1]);
+    const int tile = __builtin_amdgcn_readfirstlane(rec[2]), ndeps = __builtin_amdgcn_readfirstlane(rec[3]);
+    // The op table is read-only for the kernel: read it through the constant address space, so that the
+    // descriptor (pointers, dims) arrives by scalar loads and lives in scalar registers.  Through a generic
+    // pointer the compiler must assume the kernel's own stores may change it and uses vector loads - two
+    // vector registers per pointer, per lane, in every task body.
+    MegaOp op;
+    {
+      typedef const __attribute__((address_space(4))) MegaOp ConstOp;
+      ConstOp* cop = (ConstOp*)(uintptr_t)(P.ops + opi);
+#pragma unroll
+      for (int k = 0; k < 10; ++k) op.p[k] = cop->p[k];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) op.i[k] = cop->i[k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) op.f[k] = cop->f[k];
+    }
+    // record of the next task (lands while this one runs; stored to the other slot at the bottom)
+    int next_word = 0;
+    if (t + 1 < ntask && threadIdx.x < TASK_WORDS) next_word = myq[(t + 1) * TASK_WORDS + threadIdx.x];
+    LinearPrefetch pre;
+    const bool linear = type == TASK_LINEAR;
+    if (linear) linear_issue(op, tile, pre);
+    if (t > 0) publish(linear);
     // ---- wait for the dependencies (contiguous tile ranges of producer ops) ----
     // A range this workgroup has already waited for (typical: consecutive column tiles of one
     // linear op) is complete for good and its data was acquired then: skip the poll and the fence.
     // Tasks that read handed-off bytes only through sc1 loads skip the L1 invalidate.
     const bool acquire = !(type == TASK_LINEAR || type == TASK_RMS_NORM || type == TASK_ADD || type == TASK_SILU_MUL);
     for (int d = 0; d < ndeps && d < MAX_DEPS; ++d) {
-      const int dop = s_task[4 + 3 * d], lo = s_task[5 + 3 * d], hi = s_task[6 + 3 * d];
+      const int dop = __builtin_amdgcn_readfirstlane(rec[4 + 3 * d]), lo = __builtin_amdgcn_readfirstlane(rec[5 + 3 * d]);
+      const int hi = __builtin_amdgcn_readfirstlane(rec[6 + 3 * d]);
       bool seen = false;
 #pragma unroll
       for (int k = 0; k < MAX_DEPS; ++k) seen |= (dop == seen_op[k] && lo >= seen_lo[k] && hi <= seen_hi[k]);
@@ -478,9 +645,8 @@ __global__ __launch_bounds__(256, 2) void mega_kernel(MegaParams P) {
       seen_op[seen_next] = dop, seen_lo[seen_next] = lo, seen_hi[seen_next] = hi;
       seen_next = (seen_next + 1) % MAX_DEPS;
     }
-    const MegaOp& op = P.ops[opi];
     switch (type) {
-      case TASK_LINEAR: task_linear(op, tile, (float*)work); break;
+      case TASK_LINEAR: task_linear(op, tile, (float*)work, pre); break;
       case TASK_RMS_NORM: task_rms_norm(op, tile, (float*)work); break;
       case TASK_ADD: task_add(op, tile); break;
       case TASK_SILU_MUL: task_silu_mul(op, tile); break;
@@ -494,19 +660,14 @@ __global__ __launch_bounds__(256, 2) void mega_kernel(MegaParams P) {
       case TASK_PREFETCH: task_prefetch(op, tile, P.err + 1); break;
       default: atomicOr(P.err, 4); break;
     }
-    // ---- publish the tile ----
-    // Tasks whose outputs are all write-through stores need only the drain + barrier; the attention
-    // and rope/kv-cache tasks store plain and pay one agent-scope release (L2 write-back).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      if (type == TASK_ATTN_SPLIT || type == TASK_ATTN_COMBINE || type == TASK_QK_NORM_ROPE_KV) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      store_relaxed_agent(P.scoreboard + (long long)opi * P.max_tiles + tile, P.epoch);
-    }
+    pend_type = type, pend_op = opi, pend_tile = tile;
+    // hand the next record over: every wave has read this task's record long ago, the other slot is free
+    if (threadIdx.x < TASK_WORDS) s_task[((t + 1) & 1) * TASK_WORDS + threadIdx.x] = next_word;
+    // (a bare barrier: this task's global stores stay in flight - publish() counts them down later)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   }
+  if (ntask > 0) publish(false);
 }
 
 }  // namespace

@@ -1,6 +1,11 @@
-"""``extern_call``: call an exported native entry point by symbol name
-(reference: python/triton_dist/language/core.py:85-117 emits a call to an external device symbol;
-the native library here exposes host launchers with a C ABI, which is what can be called by name)."""
+"""``extern_call``: call an exported native entry point by symbol name.
+
+The reference's ``extern_call`` (python/triton_dist/language/core.py:85-117) makes a Triton kernel call a
+symbol of an external DEVICE library.  Kernels here are HIP source, so the device-side form is the language
+itself: the kernel file declares ``extern "C" __device__ T sym(...)`` and ``triton_dist.tools.compile_hip(...,
+extern_libs=[lib.hip])`` links the library's relocatable device code into the kernel's code object
+(tools/runtime.py; tests/test_user_kernels.py builds and runs one).  The function below is the HOST-side
+counterpart: any launcher the native libraries export with a C ABI, called by name."""
 from __future__ import annotations
 
 import ctypes

@@ -62,17 +62,31 @@ def hipcc_path() -> Optional[str]:
                                      if (Path(os.environ.get("ROCM_PATH", "/opt/rocm")) / "bin" / "hipcc").exists() else None)
 
 
+def _llvm_tool(name: str) -> Optional[str]:
+    p = Path(os.environ.get("ROCM_PATH", "/opt/rocm")) / "lib" / "llvm" / "bin" / name
+    return str(p) if p.exists() else shutil.which(name)
+
+
 def compile_hip(source: Union[str, Path], out: Union[str, Path, None] = None, arch: str = "gfx950",
-                extra_flags: Sequence[str] = (), force: bool = False) -> Path:
+                extra_flags: Sequence[str] = (), force: bool = False,
+                extern_libs: Sequence[Union[str, Path]] = ()) -> Path:
     """``hipcc --genco`` of one source file with the device headers on the include path.  The code
     object is rebuilt only when the source, the headers or the flags changed (a digest is kept next to
-    it), so calling this at every start-up is cheap."""
+    it), so calling this at every start-up is cheap.
+
+    ``extern_libs``: more ``.hip`` sources that DEFINE device functions the kernel file only declares
+    (``extern "C" __device__ float user_act(float);``).  Every file is compiled to relocatable device bitcode
+    (``-fgpu-rdc``), the bitcode is linked and one code object is produced - the device-side form of the
+    reference's ``extern_call`` / ``extern_libs`` (python/triton_dist/language/core.py:85-117: a Triton kernel
+    calling a symbol of an external device library)."""
     src = Path(source).resolve()
+    libs = [Path(p).resolve() for p in extern_libs]
     out = Path(out) if out is not None else src.with_suffix(".hsaco")
-    flags = ["--genco", f"--offload-arch={arch}", "-O3", "-std=c++17", "-fno-gpu-sanitize", f"-I{INCLUDE_DIR}",
-             *extra_flags]
+    common = [f"--offload-arch={arch}", "-O3", "-std=c++17", "-fno-gpu-sanitize", f"-I{INCLUDE_DIR}", *extra_flags]
+    flags = (["--genco"] if not libs else ["-fgpu-rdc", "--cuda-device-only", "-c"]) + common
     h = hashlib.sha1(" ".join(flags).encode())
-    h.update(src.read_bytes())
+    for f in [src, *libs]:
+        h.update(f.read_bytes())
     for hdr in sorted(INCLUDE_DIR.rglob("*.h*")):
         h.update(hdr.read_bytes())
     digest = h.hexdigest()
@@ -85,9 +99,28 @@ def compile_hip(source: Union[str, Path], out: Union[str, Path, None] = None, ar
             return out                      # no compiler on this machine: use the code object that shipped
         raise RuntimeError("hipcc not found and no prebuilt code object at " + str(out))
     out.parent.mkdir(parents=True, exist_ok=True)
-    res = subprocess.run([cc, *flags, str(src), "-o", str(out)], capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError(f"hipcc failed for {src}:\n{res.stdout}{res.stderr}")
+
+    def run(cmd, what):
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"{what} failed for {src}:\n{res.stdout}{res.stderr}")
+
+    if not libs:
+        run([cc, *flags, str(src), "-o", str(out)], "hipcc")
+    else:
+        link, clang = _llvm_tool("llvm-link"), _llvm_tool("clang")
+        if link is None or clang is None:
+            raise RuntimeError("extern_libs needs llvm-link and clang of the ROCm toolchain")
+        bcs = []
+        for k, f in enumerate([src, *libs]):
+            bc = out.with_suffix(f".{k}.bc")
+            run([cc, *flags, str(f), "-o", str(bc)], "hipcc (device bitcode)")
+            bcs.append(str(bc))
+        merged = out.with_suffix(".linked.bc")
+        run([link, *bcs, "-o", str(merged)], "llvm-link")
+        run([clang, "-target", "amdgcn-amd-amdhsa", f"-mcpu={arch}", "-O3", str(merged), "-o", str(out)], "device link")
+        for f in [*bcs, str(merged)]:
+            os.unlink(f)
     stamp.write_text(digest)
     return out
 
