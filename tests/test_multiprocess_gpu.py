@@ -38,6 +38,16 @@ def test_bench_two_processes_run_the_fused_path():
     assert "torch_ag_gemm_us" in out and "torch_gemm_rs_us" in out and out["producer"] == "kernel", out
 
 
+def test_bench_four_processes_run_the_fused_path():
+    """N=4 (four processes sharing the GPU): every rank maps three peers, the kernels split the CUs four ways."""
+    res = _torchrun(4, ROOT / "bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1", "--no-baseline", port=29575,
+                    timeout=400)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    out = _bench_line(res)
+    assert out["n_gpus"] == 4 and out["timed_path"].startswith("fused HIP kernels") and out["note"] == "", out
+    assert out["config"]["parallelism"] == "tp4" and out["checks_passed_before_timing"] == 3 and out["value"] > 0, out
+
+
 def test_heap_selftest_falls_back_to_the_next_memory_mode():
     """A failed probe of the coarse-grained arena (injected) moves the heap to fine-grained memory on
     every rank, and the fused ops still pass their checks there."""

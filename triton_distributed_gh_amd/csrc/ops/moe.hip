@@ -47,10 +47,21 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(AlignParams p) {
   for (int i = threadIdx.x; i < EW; i += blockDim.x) hist[i] = 0;
   for (int i = threadIdx.x; i < p.cap; i += blockDim.x) p.sorted_ids[i] = -1;
   __syncthreads();
-  for (int i = threadIdx.x; i < p.n; i += blockDim.x) {
-    const int e = p.topk_ids[i];
-    const int s = min((i / p.topk) / p.tokens_per_rank, p.w - 1);
-    atomicAdd(&hist[e * p.w + s], 1);
+  // (eight independent loads per thread in flight: one load -> one atomic per iteration is a chain of
+  // dependent L2 round trips, 32 of them per pass at 32k pairs)
+  constexpr int UA = 8;
+  for (int i0 = threadIdx.x; i0 < p.n; i0 += UA * blockDim.x) {
+    int ev[UA];
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+      const int i = i0 + u * blockDim.x;
+      ev[u] = i < p.n ? p.topk_ids[i] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+      const int i = i0 + u * blockDim.x;
+      if (ev[u] >= 0) atomicAdd(&hist[ev[u] * p.w + min((i / p.topk) / p.tokens_per_rank, p.w - 1)], 1);
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -91,11 +102,21 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(AlignParams p) {
   __syncthreads();
   for (int i = threadIdx.x; i < EW; i += blockDim.x) hist[i] = 0;   // now cursors
   __syncthreads();
-  for (int i = threadIdx.x; i < p.n; i += blockDim.x) {
-    const int e = p.topk_ids[i];
-    const int s = min((i / p.topk) / p.tokens_per_rank, p.w - 1);
-    const int slot = base[e * p.w + s] + atomicAdd(&hist[e * p.w + s], 1);
-    p.sorted_ids[slot] = i;
+  for (int i0 = threadIdx.x; i0 < p.n; i0 += UA * blockDim.x) {
+    int ev[UA];
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+      const int i = i0 + u * blockDim.x;
+      ev[u] = i < p.n ? p.topk_ids[i] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+      const int i = i0 + u * blockDim.x;
+      if (ev[u] >= 0) {
+        const int bin = ev[u] * p.w + min((i / p.topk) / p.tokens_per_rank, p.w - 1);
+        p.sorted_ids[base[bin] + atomicAdd(&hist[bin], 1)] = i;
+      }
+    }
   }
   // arrival order: a block is ready once its LAST needed source (in push-arrival order: own rank
   // first, then rank+1, rank+2, ... as pushed by the producers) has landed.  Stable counting sort
