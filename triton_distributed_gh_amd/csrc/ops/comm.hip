@@ -12,6 +12,7 @@
 // kernels/nvidia/p2p.py:30-85.  NUMA / multi-node / multimem variants have nothing to map to inside
 // one full-mesh xGMI node and are served by the same kernels.
 #include "tdist/cache_policy.hpp"
+#include "tdist/call_state.hpp"
 #include "tdist/common.hpp"
 #include "tdist/primitives.hpp"
 #include "tdist/shmem_device.hpp"
@@ -93,11 +94,23 @@ struct AgLLParams {
   int* err;
   long long words;
   unsigned flag;              // != 0, changes every call
+  // Device-side call numbering (tdist/call_state.hpp): with `state` set, `stage` is the base of BOTH halves
+  // (half h at stage + h * half_stride words) and half / flag come from the call number on the device, so
+  // the launch is the same every time and replays from a HIP graph.
+  int* state;
+  long long half_stride;
 };
 
 __global__ __launch_bounds__(512) void allgather_ll_kernel(AgLLParams p) {
+  __shared__ int s_call;
   const int w = p.ctx.num_ranks, rank = p.ctx.rank;
   const int b = blockIdx.x;
+  int call = 0;
+  if (p.state) {
+    call = call_begin(p.state, &s_call);
+    p.stage += (long long)call_parity(call) * p.half_stride;
+    p.flag = (unsigned)call_epoch(call);
+  }
   if (b < w - 1) {
     const int peer = (rank + 1 + b) % w;
     const unsigned* src = (const unsigned*)(p.buf + (long long)rank * p.words * 4);
@@ -123,6 +136,7 @@ __global__ __launch_bounds__(512) void allgather_ll_kernel(AgLLParams p) {
       dst[i] = (unsigned)v;
     }
   }
+  if (p.state) call_end(p.state, call);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -366,11 +380,13 @@ TDIST_API int tdist_allgather(const SymmCtx* ctx, void* buf, int* flags, int* lo
   return 0;
 }
 
+// `state` != null: int32 [2] = {call number, finished workgroups}, zero when created; `stage` is then the base of
+// both halves, `half_stride` their distance in 8-byte words, and `flag` is ignored.
 TDIST_API int tdist_allgather_ll(const SymmCtx* ctx, void* buf, void* stage, int* err, long long bytes_per_rank,
-                                 unsigned flag, void* stream) {
+                                 unsigned flag, void* stream, int* state, long long half_stride) {
   const int w = ctx->num_ranks;
   if (w <= 1) return 0;
-  TDIST_REQUIRE(bytes_per_rank % 4 == 0 && flag != 0, "LL all-gather needs 4-byte multiples and a non-zero flag");
+  TDIST_REQUIRE(bytes_per_rank % 4 == 0 && (flag != 0 || state), "LL all-gather needs 4-byte multiples and a non-zero flag");
   AgLLParams p;
   p.ctx = *ctx;
   p.buf = (char*)buf;
@@ -378,6 +394,8 @@ TDIST_API int tdist_allgather_ll(const SymmCtx* ctx, void* buf, void* stage, int
   p.err = err;
   p.words = bytes_per_rank / 4;
   p.flag = flag;
+  p.state = state;
+  p.half_stride = half_stride;
   hipLaunchKernelGGL(allgather_ll_kernel, dim3(2 * (w - 1)), dim3(512), 0, (hipStream_t)stream, p);
   TDIST_HIP_TRY(hipGetLastError());
   return 0;

@@ -15,6 +15,7 @@
 // order, on the device side of `moe_align`).
 #include "tdist/ag_push.hpp"
 #include "tdist/cache_policy.hpp"
+#include "tdist/call_state.hpp"
 #include "tdist/common.hpp"
 #include "tdist/gemm_gfx950.hpp"
 #include "tdist/primitives.hpp"
@@ -171,6 +172,15 @@ struct GroupGemmParams {
   int* push_done;
   int M_per_rank, rows_per_chunk, rank, world, push_wgs, straddle, race_debug;
   WgTrace trace;              // tdist/wg_trace.hpp (off unless the host armed a sink)
+  // Device-side call numbering (tdist/call_state.hpp).  With `state` set, A / ws / flags / epoch above are
+  // ignored: parity and flag value come from the call number on the device (ws, flags = parity 0; ws1, flags1 =
+  // parity 1), so the launch is the same every time and replays from a HIP graph.  The last workgroup of every
+  // launch zeroes the n_counters ints from `ticket` on (with or without `state`): no memset in front.
+  int* state;
+  uint16_t* ws1;
+  int* flags1;
+  int* fin;
+  int n_counters;
 };
 
 struct GroupCall {
@@ -199,8 +209,21 @@ __global__ __launch_bounds__(THREADS, 2) void moe_group_gemm_kernel(GroupGemmPar
   bool have;
   WgTraceCursor tr = wg_trace_begin(p.trace);
   wg_trace(tr, 1, 0);
+  int call = 0;
+  GroupCall cv{p.ws, p.push_flags, p.epoch};
+  const uint16_t* A = p.A;
+  const int* flags = p.flags;
+  if (p.state) {
+    call = call_begin(p.state, s_ticket + 2);       // (mailbox ints 1 and 2 are not used by the work queues)
+    if (call_parity(call)) {
+      cv.ws = p.ws1;
+      cv.flags = p.flags1;
+    }
+    cv.epoch = call_epoch(call);
+    A = cv.ws;
+    flags = cv.flags;
+  }
   if ((int)blockIdx.x < p.push_wgs) {
-    const GroupCall cv{p.ws, p.push_flags, p.epoch};
     push_item(p, cv, (int)blockIdx.x);
     wg_trace(tr, 6, 0);
     have = wq.next(local);
@@ -243,15 +266,15 @@ __global__ __launch_bounds__(THREADS, 2) void moe_group_gemm_kernel(GroupGemmPar
     }
     wg_trace(tr, 2, b);
     wq.prefetch();
-    if (p.flags && p.seg_range) {
+    if (flags && p.seg_range) {
       const int f0 = p.seg_range[2 * b] * p.cpr, f1 = (p.seg_range[2 * b + 1] + 1) * p.cpr;
-      wait(p.flags + f0, f1 - f0, SCOPE_SYS, SEM_ACQUIRE, p.epoch, p.err);
+      wait(flags + f0, f1 - f0, SCOPE_SYS, SEM_ACQUIRE, cv.epoch, p.err);
     } else {
       __syncthreads();
     }
     wg_trace(tr, 3, b);
     TileArgs t;
-    t.A = p.A;
+    t.A = A;
     t.B = p.B + (long long)e * p.b_expert_stride + (long long)pid_n * BN * p.ldb;
     t.lda = p.lda;
     t.ldb = p.ldb;
@@ -291,6 +314,7 @@ __global__ __launch_bounds__(THREADS, 2) void moe_group_gemm_kernel(GroupGemmPar
     local = next_local;
   }
   wg_trace(tr, 7, 0);
+  call_end(p.state, call, p.fin, p.ticket, p.n_counters);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -312,11 +336,16 @@ struct TopkRsParams {
   const uint16_t* gemm_out;
   uint16_t* scatter;     // symmetric [w][tpr][ld]
   int* flags;            // symmetric [w]
-  int* counters;         // local [w] + ticket at [w]; zeroed before launch
+  int* counters;         // local [w] + ticket at [w]; zero at launch, re-armed by the last workgroup;
+                         // [TDIST_MAX_RANKS + 1] = finished-workgroup counter
   int* err;
   uint16_t* out;         // [tpr, ld]
   long long ld;          // row stride of gemm_out / scatter / out in elements (N of the whole problem)
   int ntokens, topk, N, tpr, epoch;
+  // device-side call numbering (tdist/call_state.hpp): scatter / flags = parity 0, scatter1 / flags1 = parity 1
+  int* state;
+  uint16_t* scatter1;
+  int* flags1;
 };
 
 constexpr int RS_TG = 8;
@@ -341,7 +370,20 @@ __device__ __forceinline__ uint4 pack_bf16x8(const float (&acc)[8]) {
 
 __global__ __launch_bounds__(256) void moe_topk_reduce_rs_kernel(TopkRsParams p) {
   __shared__ int s_item;
+  __shared__ int s_call;
   const int w = p.ctx.num_ranks, rank = p.ctx.rank;
+  int call = 0;
+  uint16_t* scatter = p.scatter;
+  int* flags = p.flags;
+  int epoch = p.epoch;
+  if (p.state) {
+    call = call_begin(p.state, &s_call);
+    if (call_parity(call)) {
+      scatter = p.scatter1;
+      flags = p.flags1;
+    }
+    epoch = call_epoch(call);
+  }
   const int gpo = (p.tpr + RS_TG - 1) / RS_TG;
   const int n_push = w * gpo;
   const int total = n_push + gpo;
@@ -358,7 +400,7 @@ __global__ __launch_bounds__(256) void moe_topk_reduce_rs_kernel(TopkRsParams p)
       const int tl0 = (item / w) * RS_TG;
       const int ntl = min(RS_TG, p.tpr - tl0);  // >= 1
       const uint16_t* src = p.gemm_out + ((long long)d * p.tpr + tl0) * p.topk * p.ld;
-      uint16_t* dst = ((d == rank) ? p.scatter : symm_at(p.ctx, p.scatter, d)) + ((long long)rank * p.tpr + tl0) * p.ld;
+      uint16_t* dst = ((d == rank) ? scatter : symm_at(p.ctx, scatter, d)) + ((long long)rank * p.tpr + tl0) * p.ld;
       const int units = ntl * cpr;              // one unit = one 16-byte output piece
       for (int u0 = threadIdx.x; u0 < units; u0 += 4 * blockDim.x) {
         float acc[4][8];
@@ -389,13 +431,13 @@ __global__ __launch_bounds__(256) void moe_topk_reduce_rs_kernel(TopkRsParams p)
       if (threadIdx.x == 0) {
         const int prev = atom_add_relaxed_agent(p.counters + d, 1);
         if (prev == gpo - 1) {
-          store_relaxed_system(((d == rank) ? p.flags : symm_at(p.ctx, p.flags, d)) + rank, p.epoch);
+          store_relaxed_system(((d == rank) ? flags : symm_at(p.ctx, flags, d)) + rank, epoch);
         }
       }
     } else {
       const int tl0 = (item - n_push) * RS_TG;
       const int ntl = min(RS_TG, p.tpr - tl0);
-      wait(p.flags, w, SCOPE_SYS, SEM_ACQUIRE, p.epoch, p.err);
+      wait(flags, w, SCOPE_SYS, SEM_ACQUIRE, epoch, p.err);
       const int units = ntl * cpr;
       for (int u0 = threadIdx.x; u0 < units; u0 += 2 * blockDim.x) {
         float acc[2][8];
@@ -407,7 +449,7 @@ __global__ __launch_bounds__(256) void moe_topk_reduce_rs_kernel(TopkRsParams p)
           if (u < units) {
             const int tl = u / cpr, c = (u - tl * cpr) << 3;
             for (int s = 0; s < w; ++s)
-              acc_bf16x8(acc[j], *(const uint4*)(p.scatter + ((long long)s * p.tpr + tl0 + tl) * p.ld + c));
+              acc_bf16x8(acc[j], *(const uint4*)(scatter + ((long long)s * p.tpr + tl0 + tl) * p.ld + c));
           }
         }
 #pragma unroll
@@ -421,6 +463,7 @@ __global__ __launch_bounds__(256) void moe_topk_reduce_rs_kernel(TopkRsParams p)
       }
     }
   }
+  call_end(p.state, call, p.counters + TDIST_MAX_RANKS + 1, p.counters, w + 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -441,7 +484,9 @@ TDIST_API int tdist_moe_align(const int* topk_ids, int* sorted_ids, int* expert_
   return 0;
 }
 
-// `ticket`: 8 + cpr zero-initialisable ints (queue tickets, then the producer's per-chunk counters).
+// `ticket`: 8 + cpr + 1 ints, zero at the first launch (queue tickets, the producer's per-chunk counters, the
+// finished-workgroup counter); every launch leaves them zero again.  `state` != null: device-side call
+// numbering - `ws` / `flags` are then parity 0, `ws1` / `flags1` parity 1, `A` and `epoch` are ignored.
 // Producer (AG + MoE): ctx / a_local / ws / M_per_rank / rows_per_chunk / push_wgs describe the in-kernel
 // all-gather (push_wgs == 0 or ctx == null: no producer); `flags` is then also the symmetric flag array the
 // producers raise on every rank.
@@ -451,7 +496,8 @@ TDIST_API int tdist_moe_group_gemm(const void* A, const void* B, void* out, cons
                                    long long ldb, long long ldo, long long b_expert_stride, int N, int K, int topk,
                                    int a_mode, int cpr, int epoch, int num_ctas, int dtype, void* stream,
                                    const tdist::SymmCtx* ctx, const void* a_local, long long lda_local, void* ws,
-                                   int M_per_rank, int rows_per_chunk, int push_wgs) {
+                                   int M_per_rank, int rows_per_chunk, int push_wgs, int* state, void* ws1,
+                                   int* flags1) {
   TDIST_REQUIRE(K >= 128 && K % 64 == 0, "K must be a multiple of 64 and >= 128");
   TDIST_REQUIRE(N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldo % 8 == 0, "N/lda/ldb/ldo must be multiples of 8");
   GroupGemmParams p;
@@ -526,7 +572,13 @@ TDIST_API int tdist_moe_group_gemm(const void* A, const void* B, void* out, cons
     TDIST_HIP_TRY(hipFuncSetAttribute((const void*)moe_group_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  TDIST_HIP_TRY(hipMemsetAsync(ticket, 0, counter_ints * sizeof(int), (hipStream_t)stream));
+  TDIST_REQUIRE(!state || (p.push_wgs > 0 && ws1 && flags1 && (((uintptr_t)ws1) & 15) == 0),
+                "device-side call numbering is for the in-kernel all-gather and needs both parities");
+  p.state = state;
+  p.ws1 = (uint16_t*)ws1;
+  p.flags1 = flags1;
+  p.n_counters = (int)counter_ints;
+  p.fin = ticket + counter_ints;
   if (dtype == 0)
     hipLaunchKernelGGL(moe_group_gemm_kernel<true>, dim3(grid), dim3(THREADS), lds, (hipStream_t)stream, p);
   else
@@ -537,7 +589,7 @@ TDIST_API int tdist_moe_group_gemm(const void* A, const void* B, void* out, cons
 
 TDIST_API int tdist_moe_topk_reduce_rs(const SymmCtx* ctx, const void* gemm_out, void* scatter, int* flags,
                                        int* counters, int* err, void* out, int ntokens, int topk, int N, long long ld,
-                                       int epoch, int num_ctas, void* stream) {
+                                       int epoch, int num_ctas, void* stream, int* state, void* scatter1, int* flags1) {
   const int w = ctx->num_ranks;
   TDIST_REQUIRE(ntokens % w == 0 && N % 8 == 0 && ld % 8 == 0 && ld >= N,
                 "ntokens must divide by world size, N and the row stride by 8");
@@ -556,7 +608,12 @@ TDIST_API int tdist_moe_topk_reduce_rs(const SymmCtx* ctx, const void* gemm_out,
   p.ld = ld;
   p.tpr = ntokens / w;
   p.epoch = epoch;
-  TDIST_HIP_TRY(hipMemsetAsync(counters, 0, (size_t)(TDIST_MAX_RANKS + 4) * sizeof(int), (hipStream_t)stream));
+  TDIST_REQUIRE(!state || (scatter1 && flags1 && (((uintptr_t)scatter1) & 15) == 0),
+                "device-side call numbering needs both parities");
+  p.state = state;
+  p.scatter1 = (uint16_t*)scatter1;
+  p.flags1 = flags1;
+  // (`counters`: TDIST_MAX_RANKS + 4 ints, zero at the first launch; the kernel re-arms them)
   // memory-bound streaming work: four workgroups per CU unless the caller budgets fewer
   hipLaunchKernelGGL(moe_topk_reduce_rs_kernel, dim3(num_ctas > 0 ? num_ctas : 1024), dim3(256), 0, (hipStream_t)stream, p);
   TDIST_HIP_TRY(hipGetLastError());

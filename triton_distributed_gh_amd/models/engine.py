@@ -5,13 +5,14 @@ Reference: python/triton_dist/models/engine.py:36-189.  Back-ends: ``torch`` (RC
 all-reduce kernels) and ``triton_dist_gemm_ar`` (GEMM fused with the all-reduce).
 
 Graph replay is used where the whole step is replay-safe: the torch back-end, any back-end at
-world size 1, and at any world size ``triton_dist_AR``, ``triton_dist`` (dense models, any decode batch)
-and - for decode batches up to 256 rows (``ops.gemm_ar.LL_MAX_M``) - ``triton_dist_gemm_ar``: the
-all-reduce kernels, AG + GEMM, GEMM + RS (both tile forms) and the low-latency GEMM + all-reduce keep their
-call number on the device, so a replayed launch picks a fresh epoch and buffer parity by itself
-(csrc/include/tdist/call_state.hpp).  Larger decode batches of ``triton_dist_gemm_ar``, and MoE models in
-``triton_dist`` mode (the MoE ops number their calls on the host), run the decode loop eagerly at world
-size > 1 - the ops refuse capture rather than race (utils/distributed.py: forbid_graph_capture).
+world size 1, and at any world size ``triton_dist_AR``, ``triton_dist`` (dense and MoE models, any decode
+batch) and - for decode batches up to 256 rows (``ops.gemm_ar.LL_MAX_M``) - ``triton_dist_gemm_ar``: the
+all-reduce kernels, AG + GEMM, GEMM + RS (both tile forms), the MoE pair (AG + grouped GEMM, grouped GEMM +
+top-k reduce + RS, with the low-latency all-gather of the routing data) and the low-latency GEMM + all-reduce
+keep their call number on the device, so a replayed launch picks a fresh epoch and buffer parity by itself
+(csrc/include/tdist/call_state.hpp).  Larger decode batches of ``triton_dist_gemm_ar`` run the decode loop
+eagerly at world size > 1 - that op refuses capture rather than race (utils/distributed.py:
+forbid_graph_capture).
 """
 from __future__ import annotations
 
@@ -137,7 +138,7 @@ class Engine:
         use_graph = not self.no_graph and m.device.type == "cuda" and (
             self.backend in ("torch", "triton_dist_AR") or m.world_size == 1
             or (self.backend == "triton_dist_gemm_ar" and bsz <= LL_MAX_M)
-            or (self.backend == "triton_dist" and not self._is_moe()))
+            or self.backend == "triton_dist")
         if use_graph:
             self.model_launch = self._init_cuda_graph(bsz)
         else:

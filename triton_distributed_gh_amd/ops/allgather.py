@@ -55,6 +55,7 @@ class FastAllGatherContext:
     scratch: Optional[torch.Tensor]
     env: Any = None
     signal_target: int = 0
+    ll_state: Optional[torch.Tensor] = None    # LL mode: {call number, finished workgroups} on the device
 
     def check_error(self) -> None:
         if self.scratch is not None and int(self.scratch[16]) != 0:
@@ -71,11 +72,12 @@ def create_fast_allgather_context(rank: int, node: int = 0, num_ranks: int = 1, 
     flags = heap.create_tensor_list([4 * w], torch.int32, arena="sig")
     stage = heap.create_tensor_list([2 * w * words], torch.int64, zero=True)
     scratch = torch.zeros(32, dtype=torch.int32, device=env.device) if env.backend == "hip" else None
+    ll_state = torch.zeros(4, dtype=torch.int32, device=env.device) if env.backend == "hip" else None
     if env.backend == "hip":
         torch.cuda.synchronize()
     if env.cpu_group is not None:
         torch.distributed.barrier(group=env.cpu_group)
-    return FastAllGatherContext(env.rank, w, max_buffer_size, flags, stage, scratch, env)
+    return FastAllGatherContext(env.rank, w, max_buffer_size, flags, stage, scratch, env, 0, ll_state)
 
 
 def fast_allgather(symm_buffer: torch.Tensor, ctx: FastAllGatherContext, rank: Optional[int] = None,
@@ -88,6 +90,18 @@ def fast_allgather(symm_buffer: torch.Tensor, ctx: FastAllGatherContext, rank: O
     if w == 1:
         return symm_buffer
     bytes_per_rank = symm_buffer[0].numel() * symm_buffer.element_size()
+    if env.backend == "hip" and mode in _LL:
+        # The LL form numbers its calls on the device (staging half and flag value come from a counter the
+        # kernel advances): one kernel node, the same every time - it records into a HIP graph.
+        assert bytes_per_rank <= ctx.max_bytes_per_rank, "shard larger than the LL staging buffer"
+        words = (ctx.max_bytes_per_rank + 3) // 4
+        cs = env.heap.ctx_struct()
+        # staging slots are strided by the ACTUAL word count of this call
+        _lib.check(_lib.hip().tdist_allgather_ll(ctypes.byref(cs), _lib.ptr(symm_buffer), _lib.ptr(ctx.stage[ctx.rank]),
+                                                 _lib.ptr(ctx.scratch[16:]), ctypes.c_longlong(bytes_per_rank),
+                                                 ctypes.c_uint(0), _lib.stream_handle(), _lib.ptr(ctx.ll_state),
+                                                 ctypes.c_longlong(w * words)), "tdist_allgather_ll")
+        return symm_buffer
     forbid_graph_capture("fast_allgather", w)
     ctx.signal_target += 1
     epoch = ctx.signal_target
@@ -95,17 +109,6 @@ def fast_allgather(symm_buffer: torch.Tensor, ctx: FastAllGatherContext, rank: O
         return _allgather_host(symm_buffer, ctx, epoch)
     cs = env.heap.ctx_struct()
     lib = _lib.hip()
-    if mode in _LL:
-        assert bytes_per_rank <= ctx.max_bytes_per_rank, "shard larger than the LL staging buffer"
-        half = epoch & 1
-        words = (ctx.max_bytes_per_rank + 3) // 4
-        stage = ctx.stage[ctx.rank][half * w * words:]
-        # staging slots are strided by the ACTUAL word count of this call
-        _lib.check(lib.tdist_allgather_ll(ctypes.byref(cs), _lib.ptr(symm_buffer), _lib.ptr(stage),
-                                          _lib.ptr(ctx.scratch[16:]), ctypes.c_longlong(bytes_per_rank),
-                                          ctypes.c_uint(epoch & 0x7FFFFFFF or 1), _lib.stream_handle()),
-                   "tdist_allgather_ll")
-        return symm_buffer
     kmode = 1 if mode == "pull" else 0
     if mode != "pull" and mode not in _PUSH:
         raise ValueError(f"unknown all-gather mode {mode}")

@@ -181,7 +181,8 @@ def create_ag_group_gemm_context(max_ntokens, N_per_rank, K, num_experts, topk, 
                                            producer="kernel", num_ctas=num_ctas, ag_streams=ag_streams, env=env)
     # eight work-queue tickets, then the in-kernel producer's per-chunk counters (csrc/ops/moe.hip)
     max_chunks = max(1, (max_ntokens // num_ranks + 15) // 16)
-    tickets = torch.zeros(8 + max_chunks, dtype=torch.int32, device=env.device) if env.backend == "hip" else None
+    # (+ the finished-workgroup counter behind them; the kernel leaves all of them zero after every launch)
+    tickets = torch.zeros(8 + max_chunks + 4, dtype=torch.int32, device=env.device) if env.backend == "hip" else None
     return MoEAllGatherGroupGEMMTensorParallelContext(ag, num_experts, topk, N_per_rank, K, rank, num_ranks, env, num_ctas,
                                                       tickets)
 
@@ -193,7 +194,8 @@ def ag_group_gemm(a: torch.Tensor, b: torch.Tensor, ctx: MoEAllGatherGroupGEMMTe
     token's activation through expert full_topk_ids[token, k]."""
     ag, env = ctx.ag, ctx.env
     w, rank = ctx.num_ranks, ctx.rank
-    forbid_graph_capture("ag_group_gemm", w)
+    if env.backend != "hip":
+        forbid_graph_capture("ag_group_gemm", w)
     M_per_rank, K = a.shape
     ntokens, topk = full_topk_ids.shape
     assert ntokens == M_per_rank * w and K == ctx.K
@@ -204,8 +206,10 @@ def ag_group_gemm(a: torch.Tensor, b: torch.Tensor, ctx: MoEAllGatherGroupGEMMTe
     a = a.contiguous()
     idx = moe_align_block_size(full_topk_ids, ctx.num_experts, w, rank, M_per_rank)
     out = torch.empty((ntokens * topk, N), dtype=a.dtype, device=a.device)
-    parity = ag.call_count & 1
-    epoch = ag.call_count % EPOCH_MOD + 1
+    # The call number lives on the device (ag.state, csrc/include/tdist/call_state.hpp): the kernel picks the
+    # workspace / flag parity and the flag value itself, so the launch is the same every time and records into
+    # a HIP graph; the host count is kept for the names the context exposes (workspace_tensors).
+    parity, epoch = 0, 0
     ag.call_count += 1
     rpc = _rows_per_chunk(M_per_rank, ag.M_PER_CHUNK)
     cur = torch.cuda.current_stream()
@@ -231,7 +235,9 @@ def ag_group_gemm(a: torch.Tensor, b: torch.Tensor, ctx: MoEAllGatherGroupGEMMTe
                                         M_per_rank // rpc, epoch, ctx.num_ctas, _DT[a.dtype], _lib.stream_handle(cur),
                                         ctypes.byref(cs) if cs is not None else None, _lib.ptr(a),
                                         ctypes.c_longlong(a.stride(0)), _lib.ptr(A) if w > 1 else None, M_per_rank, rpc,
-                                        push_wgs), "tdist_moe_group_gemm")
+                                        push_wgs, _lib.ptr(ag.state) if w > 1 else None,
+                                        _lib.ptr(ag.workspaces[1][rank]) if w > 1 else None,
+                                        _lib.ptr(ag.flags[1][rank]) if w > 1 else None), "tdist_moe_group_gemm")
     return out
 
 
@@ -305,6 +311,8 @@ class MoEReduceRSContext:
     call_count: int = 0
     n_chunks_max: int = 8
     side_stream: Any = None      # the reduce of chunk c runs here, next to the grouped GEMM of chunk c + 1
+    state: Optional[torch.Tensor] = None     # device-side call number of the unchunked form (call_state.hpp)
+    numbering: str = ""          # "device" (unchunked, capturable) or "host" (chunked): one per context
 
     def check_error(self):
         if self.scratch is not None and int(self.scratch[40]) != 0:
@@ -331,8 +339,11 @@ def create_moe_rs_context(rank, world_size, local_world_size, max_token_num, hid
         torch.cuda.synchronize()
     if env.cpu_group is not None:
         torch.distributed.barrier(group=env.cpu_group)
+    state = torch.zeros(4, dtype=torch.int32, device=env.device) if env.backend == "hip" else None
+    if env.backend == "hip":
+        torch.cuda.synchronize()
     return MoEReduceRSContext(rank, world_size, max_token_num, hidden_dim, num_experts, topk, input_dtype, scatter,
-                              flags, scratch, env, num_ctas, 0, n_chunks_max, rs_stream)
+                              flags, scratch, env, num_ctas, 0, n_chunks_max, rs_stream, state)
 
 
 def _column_chunks(N: int, n_chunks: int):
@@ -356,7 +367,6 @@ def run_moe_reduce_rs(x: torch.Tensor, weights: torch.Tensor, chosen_experts: to
     Default: the ``moe_rs.N_CHUNKS`` tuning knob (1 = one GEMM launch, one reduce launch, back to back)."""
     env = ctx.env
     w, rank = ctx.world_size, ctx.rank
-    forbid_graph_capture("run_moe_reduce_rs", w)
     ntokens, topk = chosen_experts.shape
     K = x.shape[1]
     N = ctx.hidden_dim
@@ -387,7 +397,8 @@ def run_moe_reduce_rs(x: torch.Tensor, weights: torch.Tensor, chosen_experts: to
                                      _lib.ptr(blk[32:]), _lib.ptr(ctx.scratch[40:]), ctypes.c_longlong(x.stride(0)),
                                      ctypes.c_longlong(b.stride(1)), ctypes.c_longlong(gemm_out.stride(0)),
                                      ctypes.c_longlong(b.stride(0)), nc, K, topk, 1, 1, 0, gemm_ctas, _DT[x.dtype],
-                                     _lib.stream_handle(), None, None, ctypes.c_longlong(0), None, 0, 0, 0),
+                                     _lib.stream_handle(), None, None, ctypes.c_longlong(0), None, 0, 0, 0, None, None,
+                                     None),
             "tdist_moe_group_gemm")
 
     if w == 1:
@@ -395,7 +406,18 @@ def run_moe_reduce_rs(x: torch.Tensor, weights: torch.Tensor, chosen_experts: to
         from .moe import reduce_topk as _rt
 
         return _rt(gemm_out, topk)
-    parity = ctx.call_count & 1
+    # The unchunked form numbers its calls on the device (one kernel node per launch, no memset: it records
+    # into a HIP graph); the chunked form runs several launches per call on two streams and takes parity and
+    # epoch from the host.  The two counts know nothing of each other, so a context serves one form only.
+    numbering = "device" if len(chunks) == 1 else "host"
+    if ctx.numbering and ctx.numbering != numbering:
+        raise RuntimeError("run_moe_reduce_rs: this context was used with n_chunks "
+                           f"{'== 1' if ctx.numbering == 'device' else '> 1'} before; the chunked and the unchunked "
+                           "form number their calls differently - create one context per form")
+    ctx.numbering = numbering
+    if numbering == "host":
+        forbid_graph_capture("run_moe_reduce_rs (n_chunks > 1)", w)
+    parity = ctx.call_count & 1 if numbering == "host" else 0
     epoch = ctx.call_count % EPOCH_MOD + 1
     ctx.call_count += 1
     out = torch.empty((ntokens // w, N), dtype=x.dtype, device=x.device)
@@ -404,12 +426,16 @@ def run_moe_reduce_rs(x: torch.Tensor, weights: torch.Tensor, chosen_experts: to
 
     def reduce_rs(c, c0, nc):
         blk = ctx.scratch[64 + 64 * c:]
+        dev = numbering == "device"
         _lib.check(
             lib.tdist_moe_topk_reduce_rs(ctypes.byref(cs), ctypes.c_void_p(gemm_out.data_ptr() + c0 * esz),
                                          ctypes.c_void_p(ctx.scatter[parity][rank].data_ptr() + c0 * esz),
                                          _lib.ptr(ctx.flags[parity][rank][c * w:]), _lib.ptr(blk), _lib.ptr(ctx.scratch[40:]),
                                          ctypes.c_void_p(out.data_ptr() + c0 * esz), ntokens, topk, nc,
-                                         ctypes.c_longlong(N), epoch, rs_ctas, _lib.stream_handle()),
+                                         ctypes.c_longlong(N), epoch, rs_ctas, _lib.stream_handle(),
+                                         _lib.ptr(ctx.state) if dev else None,
+                                         _lib.ptr(ctx.scatter[1][rank]) if dev else None,
+                                         _lib.ptr(ctx.flags[1][rank]) if dev else None),
             "tdist_moe_topk_reduce_rs")
 
     if len(chunks) == 1:
