@@ -26,7 +26,16 @@ using namespace tdist;
 using namespace tdist::gemm;
 
 // ------------------------------------------------------------------------------------------------
-// align: ONE workgroup of 1024 threads.  LDS: hist[E*w], base[E*w], pad_off[E+1], stage_of[cap/256]
+// align, two launches over G workgroups of 1024 threads (G = ceil(n / ALIGN_PER_WG)):
+//   count   - workgroup g histograms its slice of the (token, k) pairs by (expert, source rank) in LDS, writes
+//             the E*w counts to part[g][.] and fills its share of sorted_ids with -1 (padding rows);
+//   scatter - every workgroup sums the G partial histograms (its own start inside each bin = the counts of the
+//             workgroups before it), thread 0 walks the E*w bins once for the padded expert offsets, and the
+//             workgroup scatters its pairs through LDS cursors; workgroup 0 also emits the per-block tables
+//             (expert, source-rank range, arrival order) and the meta words.
+// One workgroup did all of this in 32-40 us at 32k pairs (every pass is a chain of LDS atomics with results on
+// ONE compute unit); spread over 16 compute units the two launches take a few microseconds each.
+// LDS per workgroup: hist[E*w], base[E*w], pad_off[E+1], stage_of[cap/256].
 // ------------------------------------------------------------------------------------------------
 struct AlignParams {
   const int* topk_ids;    // [n] expert of flat pair i = token*topk + k
@@ -35,34 +44,56 @@ struct AlignParams {
   int* seg_range;         // [cap/256][2] first / last source rank present in the block
   int* order;             // [cap/256] block ids sorted by arrival (rotated last source rank)
   int* meta;              // [0] num_blocks, [1] padded rows, [2..2+E) tokens per expert
+  int* part;              // [G][E*w] per-workgroup histograms (written by count, read by scatter)
   int n, E, w, topk, tokens_per_rank, rank, cap;
 };
 
-__global__ __launch_bounds__(1024) void moe_align_kernel(AlignParams p) {
+constexpr int ALIGN_PER_WG = 2048;     // pairs per workgroup (two per thread)
+
+__device__ __forceinline__ int align_bin(const AlignParams& p, int i, int e) {
+  return e * p.w + min((i / p.topk) / p.tokens_per_rank, p.w - 1);
+}
+
+__global__ __launch_bounds__(1024) void moe_align_count_kernel(AlignParams p) {
   extern __shared__ int lds[];
-  int* hist = lds;                       // [E*w] counts, later cursors
+  int* hist = lds;
+  const int EW = p.E * p.w;
+  const int G = gridDim.x, g = blockIdx.x;
+  for (int i = threadIdx.x; i < EW; i += blockDim.x) hist[i] = 0;
+  // this workgroup's share of the padding fill
+  const int per = (p.cap + G - 1) / G;
+  for (int i = g * per + threadIdx.x; i < min(p.cap, (g + 1) * per); i += blockDim.x) p.sorted_ids[i] = -1;
+  __syncthreads();
+  const int i0 = g * ALIGN_PER_WG + threadIdx.x, i1 = i0 + blockDim.x;
+  const int e0 = i0 < p.n ? p.topk_ids[i0] : -1;
+  const int e1 = i1 < p.n ? p.topk_ids[i1] : -1;
+  if (e0 >= 0) atomicAdd(&hist[align_bin(p, i0, e0)], 1);
+  if (e1 >= 0) atomicAdd(&hist[align_bin(p, i1, e1)], 1);
+  __syncthreads();
+  for (int i = threadIdx.x; i < EW; i += blockDim.x) p.part[g * EW + i] = hist[i];
+}
+
+__global__ __launch_bounds__(1024) void moe_align_scatter_kernel(AlignParams p) {
+  extern __shared__ int lds[];
+  int* hist = lds;                       // [E*w] totals, later this workgroup's cursors
   int* base = lds + p.E * p.w;           // [E*w] start row of (e, s)
   int* pad_off = base + p.E * p.w;       // [E+1]
-  int* stage_of = pad_off + p.E + 1;     // [cap / 256] arrival stage of every block
+  int* stage_of = pad_off + p.E + 1;     // [cap / 256] arrival stage of every block (workgroup 0)
   const int EW = p.E * p.w;
-  for (int i = threadIdx.x; i < EW; i += blockDim.x) hist[i] = 0;
-  for (int i = threadIdx.x; i < p.cap; i += blockDim.x) p.sorted_ids[i] = -1;
-  __syncthreads();
-  // (eight independent loads per thread in flight: one load -> one atomic per iteration is a chain of
-  // dependent L2 round trips, 32 of them per pass at 32k pairs)
-  constexpr int UA = 8;
-  for (int i0 = threadIdx.x; i0 < p.n; i0 += UA * blockDim.x) {
-    int ev[UA];
-#pragma unroll
-    for (int u = 0; u < UA; ++u) {
-      const int i = i0 + u * blockDim.x;
-      ev[u] = i < p.n ? p.topk_ids[i] : -1;
+  const int G = gridDim.x, g = blockIdx.x;
+  // the pairs of this workgroup (loads in flight while the histograms are summed)
+  const int i0 = g * ALIGN_PER_WG + threadIdx.x, i1 = i0 + blockDim.x;
+  const int e0 = i0 < p.n ? p.topk_ids[i0] : -1;
+  const int e1 = i1 < p.n ? p.topk_ids[i1] : -1;
+  for (int b = threadIdx.x; b < EW; b += blockDim.x) {
+    int tot = 0, before = 0;
+    for (int k = 0; k < G; ++k) {
+      const int c = p.part[k * EW + b];
+      tot += c;
+      before += k < g ? c : 0;
     }
-#pragma unroll
-    for (int u = 0; u < UA; ++u) {
-      const int i = i0 + u * blockDim.x;
-      if (ev[u] >= 0) atomicAdd(&hist[ev[u] * p.w + min((i / p.topk) / p.tokens_per_rank, p.w - 1)], 1);
-    }
+    hist[b] = tot;
+    base[b] = before;                    // (start inside the bin; the bin's own start is added below)
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -71,64 +102,55 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(AlignParams p) {
       pad_off[e] = off;
       int tot = 0;
       for (int s = 0; s < p.w; ++s) {
-        base[e * p.w + s] = off + tot;
-        tot += hist[e * p.w + s];
+        const int c = hist[e * p.w + s];
+        const int mine = base[e * p.w + s];
+        base[e * p.w + s] = off + tot;   // global start row of (e, s)
+        hist[e * p.w + s] = off + tot + mine;      // this workgroup's cursor
+        tot += c;
+        // keep the count for the per-block tables below (workgroup 0 needs start + count of every bin)
+        lds[2 * EW + p.E + 1 + (p.cap / BM) + e * p.w + s] = c;
       }
-      p.meta[2 + e] = tot;
+      if (g == 0) p.meta[2 + e] = tot;
       off += (tot + BM - 1) / BM * BM;
     }
     pad_off[p.E] = off;
-    p.meta[0] = off / BM;
-    p.meta[1] = off;
+    if (g == 0) {
+      p.meta[0] = off / BM;
+      p.meta[1] = off;
+    }
   }
   __syncthreads();
+  if (e0 >= 0) p.sorted_ids[atomicAdd(&hist[align_bin(p, i0, e0)], 1)] = i0;
+  if (e1 >= 0) p.sorted_ids[atomicAdd(&hist[align_bin(p, i1, e1)], 1)] = i1;
+  if (g != 0) return;
+  // ---- workgroup 0: per-block expert id, source-rank range, arrival order ----
+  const int* count = lds + 2 * EW + p.E + 1 + (p.cap / BM);
   const int nblocks = pad_off[p.E] / BM;
-  // per-block expert id + source-rank range (computed before the cursors are consumed)
   for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
     const int r0 = b * BM, r1 = r0 + BM;
     int e = 0;
     while (pad_off[e + 1] <= r0) ++e;
     int smin = p.w, smax = -1;
     for (int s = 0; s < p.w; ++s) {
-      const int a = base[e * p.w + s], c = a + hist[e * p.w + s];
+      const int a = base[e * p.w + s], c = a + count[e * p.w + s];
       if (c > a && a < r1 && c > r0) {
         smin = min(smin, s);
         smax = max(smax, s);
       }
     }
+    const int lo = smin > smax ? 0 : smin, hi = smin > smax ? 0 : smax;
     p.expert_of_block[b] = e;
-    p.seg_range[2 * b] = smin > smax ? 0 : smin;
-    p.seg_range[2 * b + 1] = smin > smax ? 0 : smax;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < EW; i += blockDim.x) hist[i] = 0;   // now cursors
-  __syncthreads();
-  for (int i0 = threadIdx.x; i0 < p.n; i0 += UA * blockDim.x) {
-    int ev[UA];
-#pragma unroll
-    for (int u = 0; u < UA; ++u) {
-      const int i = i0 + u * blockDim.x;
-      ev[u] = i < p.n ? p.topk_ids[i] : -1;
-    }
-#pragma unroll
-    for (int u = 0; u < UA; ++u) {
-      const int i = i0 + u * blockDim.x;
-      if (ev[u] >= 0) {
-        const int bin = ev[u] * p.w + min((i / p.topk) / p.tokens_per_rank, p.w - 1);
-        p.sorted_ids[base[bin] + atomicAdd(&hist[bin], 1)] = i;
-      }
-    }
-  }
-  // arrival order: a block is ready once its LAST needed source (in push-arrival order: own rank
-  // first, then rank+1, rank+2, ... as pushed by the producers) has landed.  Stable counting sort
-  // on stage = max over [smin, smax] of ((s - rank + w) % w), one thread per block: its position is
-  // the number of blocks of an earlier stage plus the number of lower-numbered blocks of its own.
-  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+    p.seg_range[2 * b] = lo;
+    p.seg_range[2 * b + 1] = hi;
+    // arrival order: a block is ready once its LAST needed source (in push-arrival order: own rank first,
+    // then rank+1, rank+2, ... as pushed by the producers) has landed
     int stage = 0;
-    for (int s = p.seg_range[2 * b]; s <= p.seg_range[2 * b + 1]; ++s) stage = max(stage, (s - p.rank + p.w) % p.w);
-    stage_of[b] = stage;     // seg_range[b] was written by this same thread above
+    for (int s = lo; s <= hi; ++s) stage = max(stage, (s - p.rank + p.w) % p.w);
+    stage_of[b] = stage;
   }
   __syncthreads();
+  // stable counting sort on the stage, one thread per block: position = blocks of an earlier stage + lower-
+  // numbered blocks of its own (a few hundred blocks at most)
   for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
     const int mine = stage_of[b];
     int pos = 0;
@@ -467,19 +489,25 @@ __global__ __launch_bounds__(256) void moe_topk_reduce_rs_kernel(TopkRsParams p)
 }
 
 // ------------------------------------------------------------------------------------------------
+// `part`: int32 scratch of at least tdist_moe_align_part_ints(n, E, w) words (any contents).
+TDIST_API int tdist_moe_align_part_ints(int n, int E, int w) { return ((n + ALIGN_PER_WG - 1) / ALIGN_PER_WG) * E * w; }
+
 TDIST_API int tdist_moe_align(const int* topk_ids, int* sorted_ids, int* expert_of_block, int* seg_range, int* order,
                               int* meta, int n, int E, int w, int topk, int tokens_per_rank, int rank, int cap,
-                              void* stream) {
-  TDIST_REQUIRE(E > 0 && w > 0 && cap % BM == 0 && cap >= n, "bad align arguments");
-  const size_t lds = (size_t)(2 * E * w + E + 1 + cap / BM) * sizeof(int);
+                              void* stream, int* part) {
+  TDIST_REQUIRE(E > 0 && w > 0 && cap % BM == 0 && cap >= n && n > 0 && part, "bad align arguments");
+  const size_t lds = (size_t)(3 * E * w + E + 1 + cap / BM) * sizeof(int);
   TDIST_REQUIRE(lds <= 160 * 1024, "too many experts x ranks for one workgroup");
-  AlignParams p{topk_ids, sorted_ids, expert_of_block, seg_range, order, meta, n, E, w, topk, tokens_per_rank, rank, cap};
+  AlignParams p{topk_ids, sorted_ids, expert_of_block, seg_range, order, meta, part, n, E, w, topk, tokens_per_rank, rank, cap};
   static bool attr_set = false;
   if (!attr_set) {
-    TDIST_HIP_TRY(hipFuncSetAttribute((const void*)moe_align_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    TDIST_HIP_TRY(hipFuncSetAttribute((const void*)moe_align_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    TDIST_HIP_TRY(hipFuncSetAttribute((const void*)moe_align_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(moe_align_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, p);
+  const int G = (n + ALIGN_PER_WG - 1) / ALIGN_PER_WG;
+  hipLaunchKernelGGL(moe_align_count_kernel, dim3(G), dim3(1024), (size_t)E * w * sizeof(int), (hipStream_t)stream, p);
+  hipLaunchKernelGGL(moe_align_scatter_kernel, dim3(G), dim3(1024), lds, (hipStream_t)stream, p);
   TDIST_HIP_TRY(hipGetLastError());
   return 0;
 }

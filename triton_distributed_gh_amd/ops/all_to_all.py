@@ -19,7 +19,7 @@ from typing import Any, List, Optional, Tuple
 import torch
 
 from .. import _lib
-from ..utils.distributed import get_env
+from ..utils.distributed import get_env, forbid_graph_capture
 
 FP8_MAX = 448.0  # OCP e4m3fn
 
@@ -89,6 +89,9 @@ def fast_all_to_all(ctx: AllToAllContext, send_tensor: torch.Tensor, send_split_
     n = send_tensor.shape[0]
     assert n <= ctx.max_m and send_tensor.shape[1] == ctx.hidden
     assert send_split_cumsum.numel() == ctx.num_tot_experts + 1
+    # parity and flag value of a call are host state, and the returned views name this call's half of the
+    # receive buffers: a replayed graph would reuse one half and one flag value forever
+    forbid_graph_capture("fast_all_to_all", w)
     half = ctx.call_count & 1
     with_scale = send_scale is not None
     if env.backend == "host":

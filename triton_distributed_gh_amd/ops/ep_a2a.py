@@ -31,7 +31,7 @@ from typing import Optional
 import torch
 
 from .. import _lib
-from ..utils.distributed import get_env
+from ..utils.distributed import forbid_graph_capture, get_env
 
 
 def bincount(x: torch.Tensor, length: int) -> torch.Tensor:
@@ -101,6 +101,8 @@ class EPAll2AllLayer(torch.nn.Module):
         assert self.env.backend == "hip", "EP dispatch runs on the GPU backend"
         T = input.shape[0]
         assert T <= self.max_tokens and input.shape[1] == self.hidden and input.dtype == self.dtype
+        # (the receive count crosses to the host to size the output, and epoch / buffer parity are host state)
+        forbid_graph_capture("EPAll2AllLayer.dispatch", self.w)
         self.epoch += 1
         idx = exp_indices.to(torch.int32).contiguous()
         dst_base, self.recv_per_expert, num_recv = self.preprocess(idx)

@@ -56,10 +56,12 @@ def moe_align_block_size(topk_ids: torch.Tensor, num_experts: int, world_size: i
     out = AlignedIndex(torch.empty(cap, dtype=torch.int32, device=dev), torch.zeros(nb, dtype=torch.int32, device=dev),
                        torch.zeros((nb, 2), dtype=torch.int32, device=dev), torch.zeros(nb, dtype=torch.int32, device=dev),
                        torch.zeros(2 + num_experts, dtype=torch.int32, device=dev))
+    lib = _lib.hip()
+    part = torch.empty(max(1, lib.tdist_moe_align_part_ints(n, num_experts, world_size)), dtype=torch.int32, device=dev)
     _lib.check(
-        _lib.hip().tdist_moe_align(_lib.ptr(ids), _lib.ptr(out.sorted_ids), _lib.ptr(out.expert_of_block),
-                                   _lib.ptr(out.seg_range), _lib.ptr(out.order), _lib.ptr(out.meta), n, num_experts,
-                                   world_size, topk, tokens_per_rank, rank, cap, _lib.stream_handle()),
+        lib.tdist_moe_align(_lib.ptr(ids), _lib.ptr(out.sorted_ids), _lib.ptr(out.expert_of_block),
+                            _lib.ptr(out.seg_range), _lib.ptr(out.order), _lib.ptr(out.meta), n, num_experts,
+                            world_size, topk, tokens_per_rank, rank, cap, _lib.stream_handle(), _lib.ptr(part)),
         "tdist_moe_align")
     return out
 
