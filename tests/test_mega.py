@@ -225,3 +225,56 @@ def test_qwen3_mega_forward_matches_torch_decode(w):
             tok = ref[:, -1].argmax(-1, keepdim=True)
     finally:
         vc.close()
+
+
+def test_task_kinds_configs_and_facade_cpu():
+    """Every registered op type has a config class and names the ModelBuilder method and interpreter body that
+    serve it; the reference's module paths for tasks / configs / layer builders resolve."""
+    import importlib
+
+    from triton_distributed_gh_amd.mega import tasks
+    from triton_distributed_gh_amd.mega.core import registered_task_types
+    from triton_distributed_gh_amd.mega.model_builder import ModelBuilder as MB
+
+    assert set(tasks.TASK_KINDS) == set(registered_task_types())
+    for name, kind in tasks.TASK_KINDS.items():
+        assert hasattr(MB, kind.builder_method) and issubclass(kind.config_cls, tasks.ConfigBase), name
+        assert isinstance(tasks.default_config(name).to_dict(), dict)
+    assert tasks.linear_block_n(tasks.LinearConfig(BLOCK_SIZE_N=32)) == 32 and tasks.linear_block_n(None) == 0
+    with pytest.raises(ValueError):
+        tasks.linear_block_n(tasks.LinearConfig(BLOCK_SIZE_N=48))
+    for mod, attr in [("triton_dist.mega_triton_kernel.tasks.linear", "LinearConfig"),
+                      ("triton_dist.mega_triton_kernel.core.config", "ConfigBase"),
+                      ("triton_dist.mega_triton_kernel.models.layers.tp_mlp", "TPMLPBuilder"),
+                      ("triton_dist.mega_triton_kernel.models.layers.tp_attn", "TPAttnBuilder"),
+                      ("triton_dist.mega_triton_kernel.models.utils", "prepare_cos_sin_cache"),
+                      ("triton_dist.mega_triton_kernel.kernels", "TASK_BODIES")]:
+        assert hasattr(importlib.import_module(mod), attr), (mod, attr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bn", [16, 32, 64])
+def test_linear_config_block_n_and_mlp_builder(bn):
+    """A LinearConfig fixes the columns per task; TPMLPBuilder shards a plain MLP module and records the block."""
+    from triton_distributed_gh_amd.mega import LinearConfig, TPMLPBuilder
+    from triton_distributed_gh_amd.mega.kernels import check_abi
+
+    check_abi()
+    torch.manual_seed(bn)
+    H, I, M = 512, 1024, 3
+    mlp = torch.nn.Module()
+    mlp.gate_proj, mlp.up_proj = torch.nn.Linear(H, I, bias=False), torch.nn.Linear(H, I, bias=False)
+    mlp.down_proj = torch.nn.Linear(I, H, bias=False)
+    mlp = mlp.to("cuda", BF)
+    x = (torch.rand(M, H, device="cuda") - 0.5).to(BF)
+    b = ModelBuilder(num_queues=64)
+    blk = TPMLPBuilder(b, rank=0, world_size=1)._init_parameters(mlp)
+    cfg = LinearConfig(BLOCK_SIZE_N=bn)
+    out = blk.build_fwd(x, fc1_config=cfg, fc2_config=cfg)
+    assert [op.num_tiles for op in b.ops] == [I // bn, H // bn]
+    b.run()
+    torch.cuda.synchronize()
+    b.check_error()
+    h = torch.nn.functional.silu(x.float() @ mlp.gate_proj.weight.float().t()) * (x.float() @ mlp.up_proj.weight.float().t())
+    ref = h.to(BF).float() @ mlp.down_proj.weight.float().t()
+    assert _rel(out, ref) < 2e-2

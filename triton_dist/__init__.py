@@ -86,6 +86,23 @@ ALIASES = {
     "mega_triton_kernel.core.scheduler": ["mega.core"],
     "mega_triton_kernel.core.registry": ["mega.core"],
     "mega_triton_kernel.core.builder": ["mega.core"],
+    "mega_triton_kernel.core.config": ["mega.tasks"],
+    "mega_triton_kernel.core.code_generator": ["mega.kernels"],
+    "mega_triton_kernel.tasks": ["mega.tasks"],
+    "mega_triton_kernel.tasks.linear": ["mega.tasks"],
+    "mega_triton_kernel.tasks.norm": ["mega.tasks"],
+    "mega_triton_kernel.tasks.attn": ["mega.tasks"],
+    "mega_triton_kernel.tasks.activation": ["mega.tasks"],
+    "mega_triton_kernel.tasks.elementwise": ["mega.tasks"],
+    "mega_triton_kernel.tasks.allreduce": ["mega.tasks"],
+    "mega_triton_kernel.tasks.barrier": ["mega.tasks"],
+    "mega_triton_kernel.tasks.prefetch": ["mega.tasks"],
+    "mega_triton_kernel.kernels": ["mega.kernels"],
+    "mega_triton_kernel.kernels.task_context": ["mega.kernels"],
+    "mega_triton_kernel.models.layers": ["mega.layers"],
+    "mega_triton_kernel.models.layers.tp_attn": ["mega.layers"],
+    "mega_triton_kernel.models.layers.tp_mlp": ["mega.layers"],
+    "mega_triton_kernel.models.utils": ["mega.layers"],
     "mega_triton_kernel.models": ["mega.model_builder", "mega.qwen3"],
     "mega_triton_kernel.models.model_builder": ["mega.model_builder"],
     "mega_triton_kernel.models.qwen3": ["mega.qwen3"],

@@ -4,3 +4,5 @@ from .core import (Task, TaskDependency, TaskType, check_schedule, register_task
                    round_robin_scheduler, zig_zag_scheduler)
 from .model_builder import ModelBuilder  # noqa: F401
 from .qwen3 import Qwen3Model  # noqa: F401
+from .layers import TPAttnBuilder, TPMLPBuilder, prepare_cos_sin_cache  # noqa: F401
+from .tasks import ConfigBase, FlashAttnConfig, LinearConfig, TASK_KINDS, get_config_factory  # noqa: F401

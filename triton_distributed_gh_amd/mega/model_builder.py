@@ -72,33 +72,36 @@ class ModelBuilder:
         return 0 if t is None else t.data_ptr()
 
     # ---- op constructors --------------------------------------------------------------------------
-    def make_linear(self, x, weight, out, residual=None, mode: int = 0, name="linear"):
+    def make_linear(self, x, weight, out, residual=None, mode: int = 0, name="linear", config=None):
         """out[M, N] (+ residual) = x[M, K] @ weight[N, K]^T.  ``mode=1``: weight is [2N, K]
-        (gate rows then up rows) and out = silu(gate) * up."""
+        (gate rows then up rows) and out = silu(gate) * up.  ``config``: a ``tasks.LinearConfig`` whose
+        ``BLOCK_SIZE_N`` (16 / 32 / 64) fixes the columns per task."""
         M, K = x.shape
         N = weight.shape[0] // (2 if mode == 1 else 1)
         assert M <= 16, "mega-kernel linear tasks are decode-shaped (at most 16 tokens)"
         assert K % 32 == 0 and weight.shape[1] == K and out.shape == (M, N)
         assert x.dtype == weight.dtype == out.dtype == torch.bfloat16
         assert x.stride(1) == 1 and weight.is_contiguous() and out.stride(1) == 1
-        bn = _linear_bn(N, self.num_queues)
+        from .tasks import linear_block_n
+
+        bn = linear_block_n(config) or _linear_bn(N, self.num_queues)
         op = self._add(TaskType.LINEAR, name, (N + bn - 1) // bn, [x.data_ptr(), weight.data_ptr(), out.data_ptr(), self._ptr(residual)],
                        [M, N, K, x.stride(0), out.stride(0), residual.stride(0) if residual is not None else 0, bn, mode],
                        [], [x, residual], [out], [x, weight, out, residual])
         self._commit(op)
         return op
 
-    def make_fc1(self, x, gate_up_weight, out, name="mlp_fc1"):
-        return self.make_linear(x, gate_up_weight, out, mode=1, name=name)
+    def make_fc1(self, x, gate_up_weight, out, name="mlp_fc1", config=None):
+        return self.make_linear(x, gate_up_weight, out, mode=1, name=name, config=config)
 
-    def make_fc2(self, x, weight, out, residual=None, name="mlp_fc2"):
-        return self.make_linear(x, weight, out, residual, name=name)
+    def make_fc2(self, x, weight, out, residual=None, name="mlp_fc2", config=None):
+        return self.make_linear(x, weight, out, residual, name=name, config=config)
 
-    def make_qkv_proj(self, x, weight, out, name="qkv_proj"):
-        return self.make_linear(x, weight, out, name=name)
+    def make_qkv_proj(self, x, weight, out, name="qkv_proj", config=None):
+        return self.make_linear(x, weight, out, name=name, config=config)
 
-    def make_o_proj(self, x, weight, out, residual=None, name="o_proj"):
-        return self.make_linear(x, weight, out, residual, name=name)
+    def make_o_proj(self, x, weight, out, residual=None, name="o_proj", config=None):
+        return self.make_linear(x, weight, out, residual, name=name, config=config)
 
     def make_rms_norm(self, x, weight, out, eps=1e-6, residual=None, residual_out=None, name="rms_norm"):
         M, H = x.shape

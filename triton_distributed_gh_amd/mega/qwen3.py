@@ -16,6 +16,7 @@ import torch
 import torch.nn.functional as F
 
 from ..models.kv_cache import PagedKVCache
+from .layers import TPAttnBuilder, TPMLPBuilder
 from .model_builder import ModelBuilder
 
 
@@ -49,30 +50,25 @@ class Qwen3Model:
         act = new(B, inter)
         cos, sin = model.cos_sin_cache
         delta = None
+        self.attn_builders, self.mlp_builders = [], []
         for li, layer in enumerate(model.layers):
             a, m = layer.attn, layer.mlp
+            ab = TPAttnBuilder(b, li, D, model.rank, w).from_layer(a, Hq, Hkv)
+            mb = TPMLPBuilder(b, model.rank, w).from_layer(m)
+            self.attn_builders.append(ab)
+            self.mlp_builders.append(mb)
             if prefetch_weights:
                 b.make_prefetch(m.gate_up_proj, name=f"l{li}.prefetch_fc1")
             b.make_rms_norm(self.hidden if delta is None else delta, layer.input_norm_w, xn, layer.input_norm_eps,
                             residual=None if delta is None else self.hidden,
                             residual_out=None if delta is None else self.hidden, name=f"l{li}.norm1")
-            b.make_qkv_proj(xn, a.wqkv, qkv, name=f"l{li}.qkv")
-            b.make_qk_norm_rope_update_kvcache(qkv, getattr(a, "q_norm_w", None), getattr(a, "k_norm_w", None), cos, sin,
-                                               self.kv_lens, self.kv_cache.k_cache[li], self.kv_cache.v_cache[li],
-                                               self.kv_cache.block_table, q, getattr(a, "q_norm_eps", 1e-6),
-                                               name=f"l{li}.qk_norm_rope_kv")
-            b.make_attn(q, self.kv_cache.k_cache[li], self.kv_cache.v_cache[li], self.kv_cache.block_table, self.kv_lens,
-                        attn, name=f"l{li}.attn")
-            b.make_o_proj(attn.view(B, Hq * D), a.wo, o_buf, name=f"l{li}.o_proj")
-            if w > 1:
-                b.make_allreduce(o_buf, o_red, name=f"l{li}.attn_ar")
-            b.make_rms_norm(o_red, layer.post_norm_w, xn, layer.post_norm_eps, residual=self.hidden,
+            # (the activation buffers are shared by all layers: every task that reuses one depends, through the
+            # chain of ops in between, on the last reader of its previous contents)
+            o_red_l = ab.build_fwd(xn, cos, sin, self.kv_cache, qkv=qkv, q=q, attn=attn, o_out=o_buf,
+                                   ar_out=o_red if w > 1 else None, name=f"l{li}")
+            b.make_rms_norm(o_red_l, layer.post_norm_w, xn, layer.post_norm_eps, residual=self.hidden,
                             residual_out=self.hidden, name=f"l{li}.norm2")
-            b.make_fc1(xn, m.gate_up_proj, act, name=f"l{li}.fc1")
-            b.make_fc2(act, m.down_proj, mlp_buf, name=f"l{li}.fc2")
-            if w > 1:
-                b.make_allreduce(mlp_buf, mlp_red, name=f"l{li}.mlp_ar")
-            delta = mlp_red
+            delta = mb.build_fwd(xn, act_out=act, fc2_out=mlp_buf, ar_out=mlp_red if w > 1 else None, name=f"l{li}")
         self.final = new(B, H)
         b.make_rms_norm(delta, model.norm_weight, self.final, model.norm_variance_epsilon, residual=self.hidden,
                         residual_out=self.hidden, name="final_norm")
