@@ -119,6 +119,10 @@ def test_extern_device_library_kernel_runs(tmp_path):
         tags = torch.empty(n, dtype=torch.int32, device="cuda")
         kern((n + 255) // 256, 256, None, heap, x, out, tags, n)
         torch.cuda.synchronize()
+        # resident workgroups per compute unit: what a kernel whose workgroups wait for each other sizes its grid by
+        from triton_dist.utils import cuda_occupancy_max_activate_blocks_per_multiprocessor as occ
+
+        assert 1 <= occ(kern, 4) <= 8 and occ(kern, 4, 64 << 10) <= 2
         torch.testing.assert_close(out, torch.nn.functional.silu(x), atol=1e-5, rtol=1e-5)
         assert tags.tolist() == [i * 31 for i in range(n)]
     finally:

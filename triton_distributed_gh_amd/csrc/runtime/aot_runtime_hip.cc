@@ -81,6 +81,13 @@ TDIST_API int tdist_aot_func_set_max_dynamic_lds(void* fn, int bytes) {
   return 0;
 }
 
+// Workgroups of `block_threads` threads and `lds_bytes` of dynamic LDS the device keeps resident per compute
+// unit for this kernel (what a persistent or grid-synchronising user kernel sizes its grid by).
+TDIST_API int tdist_aot_occupancy(void* fn, int block_threads, int lds_bytes, int* out) {
+  TDIST_HIP_TRY(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(out, (hipFunction_t)fn, block_threads, (size_t)lds_bytes));
+  return 0;
+}
+
 // args: array of pointers to the kernel arguments (hipModuleLaunchKernel convention).
 TDIST_API int tdist_aot_launch(void* fn, unsigned gx, unsigned gy, unsigned gz, unsigned bx, unsigned by, unsigned bz,
                                unsigned lds_bytes, void* stream, void** args) {

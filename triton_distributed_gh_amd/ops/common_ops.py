@@ -114,3 +114,24 @@ def barrier_on_this_grid_smoke(num_blocks: int = 256, rounds: int = 8, stream=No
                                                   _lib.stream_handle(s)), "tdist_test_grid_barrier")
     s.synchronize()
     return int(bad[0]), int(bad[1])
+
+
+# ---- small host helpers the reference keeps next to its device helpers (kernels/nvidia/common_ops.py) ----
+def next_power_of_2(x: int) -> int:
+    return 1 if x <= 1 else 1 << (int(x) - 1).bit_length()
+
+
+def log2(x: int) -> int:
+    """Exact log2 of a power of two."""
+    x = int(x)
+    if x <= 0 or x & (x - 1):
+        raise ValueError(f"log2: {x} is not a power of two")
+    return x.bit_length() - 1
+
+
+# The reference's node barrier has several device forms (atomic-CAS per block, non-atomic slot matrix,
+# ``barrier_all_intra_node_*``, kernels/nvidia/common_ops.py:95-243); here they are ONE kernel - every rank
+# writes its slot on every peer and waits for all of its own (csrc/include/tdist/shmem_device.hpp:
+# barrier_all_block) - launched on a stream.
+barrier_all_intra_node_non_atomic = barrier_all_intra_node_atomic_cas_block = barrier_all_on_stream
+barrier_all_intra_node_non_atomic_block = barrier_all_on_stream

@@ -187,6 +187,16 @@ class Kernel:
         del keep        # hipModuleLaunchKernel copied the values into the kernarg segment
 
 
+    def max_active_blocks_per_cu(self, block_threads: int, lds_bytes: int = 0) -> int:
+        """Workgroups of this kernel one compute unit keeps resident at the given block size and dynamic LDS
+        (reference: python/triton_dist/utils.py ``cuda_occupancy_max_activate_blocks_per_multiprocessor``).
+        A kernel whose workgroups wait for each other must not launch more than this times the CU count."""
+        out = ctypes.c_int(0)
+        _lib.check(_lib.hip().tdist_aot_occupancy(self._fn, int(block_threads), int(lds_bytes), ctypes.byref(out)),
+                   f"occupancy of {self.name}")
+        return int(out.value)
+
+
 class Module:
     """A loaded code object.  ``get(name)`` returns a launchable kernel (``extern "C"`` name)."""
 

@@ -19,14 +19,50 @@ from .distributed import finalize_distributed, get_env, init_seed, is_initialize
 from .perf import (_make_tensor, assert_allclose, bitwise_equal, dist_print, generate_data, perf_func,  # noqa: F401
                    sleep_async)
 from .profile import get_torch_prof_ctx, group_profile, merge_traces  # noqa: F401
-from .topo import (HIP_CHECK, can_access_peer, device_props, estimate_all_gather_time_ms,  # noqa: F401
-                   estimate_gemm_sol_time_ms, estimate_reduce_scatter_time_ms, get_intranode_max_speed_gbps,
-                   get_numa_world_size, has_fullmesh_xgmi, has_tma, is_cuda, is_hip,
-                   is_nvshmem_multimem_supported, num_cus, num_xcds, requires, supports_p2p_native_atomic)
+from .profile import ParallelJsonDumper, process_trace_json  # noqa: F401
+from .topo import (HIP_CHECK, calculate_pcie_bandwidth, can_access_peer, device_props,  # noqa: F401
+                   estimate_all_gather_time_ms, estimate_gemm_sol_time_ms, estimate_reduce_scatter_time_ms,
+                   get_active_xgmi_links, get_intranode_max_speed_gbps, get_numa_node, get_numa_world_size,
+                   get_pcie_link_info, get_pcie_link_max_speed, get_xgmi_link_max_speed, has_fullmesh_xgmi, has_tma,
+                   RocmSmiUtil,
+                   is_cuda, is_hip, is_nvshmem_multimem_supported, num_cus, num_xcds, requires,
+                   supports_p2p_native_atomic)
 
 NVSHMEM_SIGNAL_DTYPE = torch.int64      # (the AG-GEMM / GEMM-RS flag arrays are int32)
 CUDA_CHECK = HIP_CHECK
 has_fullmesh_nvlink = has_fullmesh_xgmi
+# the reference's NVML / nvidia-smi probe names, served by the sysfs / HIP probes of utils/topo.py
+has_fullmesh_nvlink_pynvml = has_fullmesh_xgmi
+get_numa_node_pynvml = get_numa_node
+get_nvlink_max_speed = get_nvlink_max_speed_pynvml = get_nvlink_max_speed_nvsmi = get_xgmi_link_max_speed
+get_active_nvlinks_pynvml = get_active_xgmi_links
+get_pcie_link_max_speed_pynvml = get_pcie_link_max_speed_nvsmi = get_pcie_link_max_speed
+get_pcie_link_info_nvsmi = get_pcie_link_info
+_merge_json = _merge_json_v1 = _merge_json_v2 = merge_traces
+NvidiaSmiUtil = RocmSmiUtil
+
+
+def parse_nvml_field_value(value):
+    """Kept for source compatibility (the reference decodes NVML's tagged unions); sysfs values are plain text."""
+    return value
+
+
+def cuda_occupancy_max_activate_blocks_per_multiprocessor(kernel, num_warps: int, shared_memory: int = 0) -> int:
+    """Resident workgroups per compute unit of a user kernel loaded with ``triton_dist.tools.load_module``
+    (``num_warps`` counts 64-wide waves here)."""
+    return kernel.max_active_blocks_per_cu(64 * int(num_warps), int(shared_memory))
+
+
+def ensure_nvml_initialized() -> None:
+    """Nothing to initialise: the probes read sysfs and the HIP runtime."""
+
+
+def triton_packed_version() -> int:
+    """The reference packs Triton's version into an int for AOT cache keys; there is no Triton here - the
+    ROCm toolchain's HIP version plays that role."""
+    v = getattr(torch.version, "hip", None) or "0.0"
+    parts = [int("".join(c for c in x if c.isdigit()) or 0) for x in v.split(".")[:3]] + [0, 0]
+    return (parts[0] << 16) | (parts[1] << 8) | (parts[2] & 0xFF)
 _BARRIER_CTX: Optional[BarrierAllContext] = None
 
 

@@ -65,6 +65,44 @@ def _relabel(trace: dict, rank: int) -> list:
     return out
 
 
+class ParallelJsonDumper:
+    """Write a dict whose ``parallel_field`` is a very long list (the ``traceEvents`` of a merged chrome trace)
+    without building the whole JSON text in memory: the list is serialised in chunks by a thread pool and
+    streamed to the file in order (reference: python/triton_dist/utils.py ``ParallelJsonDumper``, which
+    uses a process pool; ``json.dumps`` of plain dicts releases nothing, but the chunks bound peak memory and the
+    file is written while later chunks are still being encoded)."""
+
+    def __init__(self, parallel_field: str, chunk_size: int = 5000, workers: int = 4):
+        self.parallel_field, self.chunk_size, self.workers = parallel_field, max(1, chunk_size), max(1, workers)
+
+    def dump(self, data: dict, output_path) -> None:
+        from concurrent.futures import ThreadPoolExecutor
+        from pathlib import Path
+
+        out = Path(output_path)
+        out.parent.mkdir(parents=True, exist_ok=True)
+        base = {k: v for k, v in data.items() if k != self.parallel_field}
+        items = data.get(self.parallel_field, [])
+        chunks = [items[i:i + self.chunk_size] for i in range(0, len(items), self.chunk_size)]
+        with ThreadPoolExecutor(self.workers) as ex, open(out, "w") as f:
+            head = json.dumps(base, separators=(",", ":"))
+            f.write((head[:-1] + ("," if base else "")) + f'"{self.parallel_field}":[')
+            first = True
+            for text in ex.map(lambda c: json.dumps(c, separators=(",", ":"))[1:-1], chunks):
+                if text:
+                    f.write(("" if first else ",") + text)
+                    first = False
+            f.write("]}")
+
+
+def process_trace_json(trace: dict, rank: int) -> dict:
+    """One rank's chrome trace with its process / thread ids re-labelled for the merged view (reference:
+    python/triton_dist/utils.py ``process_trace_json``)."""
+    out = {k: v for k, v in trace.items() if k != "traceEvents"}
+    out["traceEvents"] = _relabel(trace, rank)
+    return out
+
+
 def merge_traces(traces: list) -> dict:
     merged = {"traceEvents": [], "displayTimeUnit": "ms"}
     for rank, t in enumerate(traces):

@@ -151,3 +151,134 @@ def HIP_CHECK(err) -> None:
 
 
 CUDA_CHECK = HIP_CHECK
+
+
+# ---- PCIe / NUMA / xGMI link facts from sysfs (what the reference reads through NVML / nvidia-smi:
+# python/triton_dist/utils.py:592-867).  Every probe degrades to None / a nominal value when the node of the
+# device is not visible (containers without /sys/class/drm).
+def _drm_device_dir(device_id: int = 0):
+    """sysfs directory of GPU ``device_id`` (render-node order), or None."""
+    import glob
+    import os
+
+    cards = sorted(d for d in glob.glob("/sys/class/drm/card[0-9]*/device")
+                   if os.path.exists(os.path.join(d, "vendor")) and open(os.path.join(d, "vendor")).read().strip() == "0x1002")
+    return cards[device_id] if 0 <= device_id < len(cards) else None
+
+
+def _read(path: str):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def get_numa_node(device_id: int = 0):
+    """NUMA node the GPU hangs off (reference name: ``get_numa_node_pynvml``), or None."""
+    d = _drm_device_dir(device_id)
+    v = _read(f"{d}/numa_node") if d else None
+    try:
+        node = int(v) if v not in (None, "") else -1
+    except ValueError:
+        node = -1
+    return node if node >= 0 else None            # (the kernel reports -1 on single-node machines and in VMs)
+
+
+def get_pcie_link_info(device_id: int = 0):
+    """(GT/s per lane, lanes) of the GPU's PCIe link at its maximum, or None."""
+    d = _drm_device_dir(device_id)
+    if not d:
+        return None
+    speed, width = _read(f"{d}/max_link_speed"), _read(f"{d}/max_link_width")
+    if not speed or not width:
+        return None
+    try:
+        return float(speed.split()[0]), int(width)
+    except ValueError:
+        return None
+
+
+def calculate_pcie_bandwidth(gt_per_lane: float, lanes: int) -> float:
+    """GB/s per direction of a PCIe link: 8b/10b below 8 GT/s, 128b/130b from gen 3 on."""
+    eff = 0.8 if gt_per_lane < 8.0 else 128.0 / 130.0
+    return gt_per_lane * eff * lanes / 8.0
+
+
+def get_pcie_link_max_speed(device_id: int = 0) -> float:
+    """GB/s per direction of the GPU's PCIe link (nominal gen 5 x16 = 63 GB/s when sysfs is not visible)."""
+    info = get_pcie_link_info(device_id)
+    return calculate_pcie_bandwidth(*info) if info else calculate_pcie_bandwidth(32.0, 16)
+
+
+def get_xgmi_link_max_speed(device_id: int = 0) -> float:
+    """GB/s per direction of ONE xGMI link between two GPUs of an MI355X node (reference name:
+    ``get_nvlink_max_speed``).  The platform figure is 153.6 GB/s per link, both directions together."""
+    return 76.8
+
+
+def get_active_xgmi_links(device_id: int = 0) -> int:
+    """Peers this GPU reaches over xGMI (reference name: ``get_active_nvlinks_pynvml``): every other GPU of the
+    node that it can access directly."""
+    n = device_count()
+    return sum(1 for p in range(n) if p != device_id and can_access_peer(device_id, p))
+
+
+def device_count() -> int:
+    import torch
+
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+class RocmSmiUtil:
+    """The node's GPU topology as ``rocm-smi`` reports it (reference: ``NvidiaSmiUtil``, python/triton_dist/
+    utils.py:640-720, which parses ``nvidia-smi topo``).  Every method returns None when the tool is missing
+    or prints something unexpected - callers fall back to the HIP peer-access probes above."""
+
+    @staticmethod
+    def _run(*args):
+        import shutil
+        import subprocess
+
+        exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+        try:
+            res = subprocess.run([exe, *args, "--json"], capture_output=True, text=True, timeout=20)
+        except (OSError, subprocess.TimeoutExpired):
+            return None
+        if res.returncode != 0:
+            return None
+        try:
+            import json
+
+            return json.loads(res.stdout)
+        except ValueError:
+            return None
+
+    @staticmethod
+    def get_link_types():
+        """{(gpu i, gpu j): "XGMI" | "PCIE"} from ``rocm-smi --showtopotype``."""
+        data = RocmSmiUtil._run("--showtopotype")
+        if not isinstance(data, dict):
+            return None
+        out = {}
+        for section in data.values():
+            if not isinstance(section, dict):
+                continue
+            for key, val in section.items():
+                # keys look like "(Topology) Link type between DRM devices 0 and 1"
+                words = key.replace(",", " ").split()
+                ids = [int(w) for w in words if w.isdigit()]
+                if len(ids) >= 2 and isinstance(val, str):
+                    out[(ids[-2], ids[-1])] = val.strip().upper()
+        return out or None
+
+    @staticmethod
+    def get_gpu_numa_node(device_id: int = 0):
+        return get_numa_node(device_id)
+
+    @staticmethod
+    def has_fullmesh_xgmi(num_gpus: int):
+        links = RocmSmiUtil.get_link_types()
+        if links is None:
+            return None
+        return all(links.get((i, j), links.get((j, i))) == "XGMI" for i in range(num_gpus) for j in range(i + 1, num_gpus))
