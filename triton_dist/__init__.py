@@ -30,33 +30,33 @@ ALIASES = {
     "kernels": [],
     "kernels.allreduce": ["ops.allreduce"],
     "kernels.common_ops": ["ops.common_ops"],
-    "kernels.amd": ["ops.ag_gemm", "ops.gemm_rs", "ops.common_ops"],
-    "kernels.amd.all_gather_gemm": ["ops.ag_gemm"],
-    "kernels.amd.gemm_reduce_scatter": ["ops.gemm_rs"],
+    "kernels.amd": ["ops.ag_gemm", "ops.gemm_rs", "ops.common_ops", "ops.compat_names"],
+    "kernels.amd.all_gather_gemm": ["ops.ag_gemm", "ops.compat_names"],
+    "kernels.amd.gemm_reduce_scatter": ["ops.gemm_rs", "ops.compat_names"],
     "kernels.amd.common_ops": ["ops.common_ops"],
     "kernels.nvidia": ["ops.compat_nvidia", "ops.allgather", "ops.moe", "ops.flash_decode", "ops.all_to_all",
                        "ops.sp_ag_attention", "ops.gemm_ar", "ops.allreduce", "ops.reduce_scatter", "ops.ep_a2a",
-                       "ops.p2p", "ops.common_ops"],
-    "kernels.nvidia.allgather_gemm": ["ops.compat_nvidia", "ops.ag_gemm"],
-    "kernels.nvidia.gemm_reduce_scatter": ["ops.compat_nvidia", "ops.gemm_rs"],
-    "kernels.nvidia.allgather": ["ops.allgather", "ops.compat_nvidia"],
-    "kernels.nvidia.low_latency_allgather": ["ops.allgather"],
-    "kernels.nvidia.allreduce": ["ops.allreduce"],
-    "kernels.nvidia.gemm_allreduce": ["ops.gemm_ar"],
-    "kernels.nvidia.reduce_scatter": ["ops.reduce_scatter"],
-    "kernels.nvidia.allgather_group_gemm": ["ops.moe"],
-    "kernels.nvidia.moe_reduce_rs": ["ops.moe"],
-    "kernels.nvidia.moe_utils": ["ops.moe"],
-    "kernels.nvidia.threadblock_swizzle_ag_moe": ["ops.moe"],
-    "kernels.nvidia.low_latency_all_to_all": ["ops.all_to_all"],
-    "kernels.nvidia.ep_a2a": ["ops.ep_a2a"],
-    "kernels.nvidia.flash_decode": ["ops.flash_decode", "tools.aot_kernels"],
-    "kernels.nvidia.sp_ag_attention_intra_node": ["ops.sp_ag_attention"],
-    "kernels.nvidia.sp_ag_attention_inter_node": ["ops.sp_ag_attention"],
+                       "ops.p2p", "ops.common_ops", "ops.compat_names"],
+    "kernels.nvidia.allgather_gemm": ["ops.compat_nvidia", "ops.ag_gemm", "ops.compat_names"],
+    "kernels.nvidia.gemm_reduce_scatter": ["ops.compat_nvidia", "ops.gemm_rs", "ops.compat_names"],
+    "kernels.nvidia.allgather": ["ops.allgather", "ops.compat_nvidia", "ops.compat_names"],
+    "kernels.nvidia.low_latency_allgather": ["ops.allgather", "ops.compat_names"],
+    "kernels.nvidia.allreduce": ["ops.allreduce", "ops.compat_names"],
+    "kernels.nvidia.gemm_allreduce": ["ops.gemm_ar", "ops.compat_names"],
+    "kernels.nvidia.reduce_scatter": ["ops.reduce_scatter", "ops.compat_names"],
+    "kernels.nvidia.allgather_group_gemm": ["ops.moe", "ops.compat_names"],
+    "kernels.nvidia.moe_reduce_rs": ["ops.moe", "ops.compat_names"],
+    "kernels.nvidia.moe_utils": ["ops.moe", "ops.compat_names"],
+    "kernels.nvidia.threadblock_swizzle_ag_moe": ["ops.threadblock_swizzle", "ops.moe"],
+    "kernels.nvidia.low_latency_all_to_all": ["ops.all_to_all", "ops.compat_names"],
+    "kernels.nvidia.ep_a2a": ["ops.ep_a2a", "ops.compat_names"],
+    "kernels.nvidia.flash_decode": ["ops.flash_decode", "tools.aot_kernels", "ops.compat_names"],
+    "kernels.nvidia.sp_ag_attention_intra_node": ["ops.sp_ag_attention", "ops.compat_names"],
+    "kernels.nvidia.sp_ag_attention_inter_node": ["ops.sp_ag_attention", "ops.compat_names"],
     "kernels.nvidia.p2p": ["ops.p2p"],
     "kernels.nvidia.common_ops": ["ops.common_ops"],
-    "kernels.nvidia.comm_perf_model": ["utils.perf_model"],
-    "kernels.nvidia.gemm_perf_model": ["utils.perf_model"],
+    "kernels.nvidia.comm_perf_model": ["utils.perf_model", "ops.compat_names"],
+    "kernels.nvidia.gemm_perf_model": ["utils.perf_model", "ops.compat_names"],
     "layers": ["layers"],
     "layers.amd": ["layers"],
     "layers.amd.tp_mlp": ["layers.tp_mlp"],
@@ -81,32 +81,37 @@ ALIASES = {
     "tools.compile_aot": ["tools.compile_aot"],
     "tools.runtime": ["tools.runtime"],
     "mega_triton_kernel": ["mega"],
-    "mega_triton_kernel.core": ["mega.core"],
-    "mega_triton_kernel.core.task_base": ["mega.core"],
-    "mega_triton_kernel.core.scheduler": ["mega.core"],
-    "mega_triton_kernel.core.registry": ["mega.core"],
-    "mega_triton_kernel.core.builder": ["mega.core"],
+    "mega_triton_kernel.core": ["mega.core", "mega.task_api"],
+    "mega_triton_kernel.core.task_base": ["mega.core", "mega.task_api"],
+    "mega_triton_kernel.core.scheduler": ["mega.core", "mega.task_api"],
+    "mega_triton_kernel.core.registry": ["mega.core", "mega.task_api"],
+    "mega_triton_kernel.core.builder": ["mega.core", "mega.task_api"],
     "mega_triton_kernel.core.config": ["mega.tasks"],
-    "mega_triton_kernel.core.code_generator": ["mega.kernels"],
-    "mega_triton_kernel.tasks": ["mega.tasks"],
-    "mega_triton_kernel.tasks.linear": ["mega.tasks"],
-    "mega_triton_kernel.tasks.norm": ["mega.tasks"],
-    "mega_triton_kernel.tasks.attn": ["mega.tasks"],
-    "mega_triton_kernel.tasks.activation": ["mega.tasks"],
-    "mega_triton_kernel.tasks.elementwise": ["mega.tasks"],
-    "mega_triton_kernel.tasks.allreduce": ["mega.tasks"],
-    "mega_triton_kernel.tasks.barrier": ["mega.tasks"],
-    "mega_triton_kernel.tasks.prefetch": ["mega.tasks"],
-    "mega_triton_kernel.kernels": ["mega.kernels"],
-    "mega_triton_kernel.kernels.task_context": ["mega.kernels"],
+    "mega_triton_kernel.core.code_generator": ["mega.kernels", "mega.task_api"],
+    "mega_triton_kernel.tasks": ["mega.tasks", "mega.task_api"],
+    "mega_triton_kernel.tasks.linear": ["mega.tasks", "mega.task_api"],
+    "mega_triton_kernel.tasks.norm": ["mega.tasks", "mega.task_api"],
+    "mega_triton_kernel.tasks.attn": ["mega.tasks", "mega.task_api"],
+    "mega_triton_kernel.tasks.activation": ["mega.tasks", "mega.task_api"],
+    "mega_triton_kernel.tasks.elementwise": ["mega.tasks", "mega.task_api"],
+    "mega_triton_kernel.tasks.allreduce": ["mega.tasks", "mega.task_api"],
+    "mega_triton_kernel.tasks.barrier": ["mega.tasks", "mega.task_api"],
+    "mega_triton_kernel.tasks.prefetch": ["mega.tasks", "mega.task_api"],
+    "mega_triton_kernel.kernels": ["mega.kernels", "mega.task_api"],
+    "mega_triton_kernel.kernels.task_context": ["mega.kernels", "mega.task_api"],
     "mega_triton_kernel.models.layers": ["mega.layers"],
     "mega_triton_kernel.models.layers.tp_attn": ["mega.layers"],
     "mega_triton_kernel.models.layers.tp_mlp": ["mega.layers"],
     "mega_triton_kernel.models.utils": ["mega.layers"],
     "mega_triton_kernel.models": ["mega.model_builder", "mega.qwen3"],
-    "mega_triton_kernel.models.model_builder": ["mega.model_builder"],
+    "mega_triton_kernel.models.model_builder": ["mega.model_builder", "mega.task_api"],
     "mega_triton_kernel.models.qwen3": ["mega.qwen3"],
     "mega_triton_kernel.models.paged_kv_cache": ["models.kv_cache"],
+    "mega_triton_kernel.tasks.utils": ["mega.tasks", "mega.task_api"],
+    "mega_triton_kernel.kernels.utils": ["ops.common_ops"],
+    "kernels.nvidia.gemm_rs_threadblock_swizzle": ["ops.threadblock_swizzle"],
+    "kernels.nvidia.ag_gemm_threadblock_swizzle": ["ops.threadblock_swizzle"],
+    "kernels.nvidia.threadblock_swizzle_ag_moe_triton": ["ops.threadblock_swizzle"],
 }
 _PACKAGES = {k for k in ALIASES if any(o.startswith(k + ".") for o in ALIASES)}
 

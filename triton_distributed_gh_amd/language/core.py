@@ -24,3 +24,33 @@ def extern_call(symbol: str, args=(), restype=ctypes.c_int, lib: str = "hip", ch
     if check and restype is ctypes.c_int and rc != 0:
         (_lib.check if lib == "hip" else _lib.check_host)(rc, symbol)
     return rc
+
+
+def _type_key(a):
+    import torch
+
+    if isinstance(a, torch.Tensor):
+        return a.dtype
+    if isinstance(a, ctypes._SimpleCData):
+        return type(a)
+    return type(a)
+
+
+def dispatch(func, lib_name: str, lib_path: str, args: list, arg_type_symbol_dict: dict, is_pure: bool = False, **_):
+    """Pick the symbol whose key in ``arg_type_symbol_dict`` equals the tuple of argument types (torch dtypes for
+    tensors, the Python / ctypes type otherwise) and call it: ``func(symbol, args)`` when ``func`` is given,
+    ``extern_call(symbol, args, lib=lib_name)`` otherwise.  ``lib_path`` names a shared library to load instead of
+    the package's own.  (Reference: python/triton_dist/language/core.py:33-83 resolves an overloaded external
+    DEVICE symbol this way at Triton compile time; here it is the host-side overload resolution.)"""
+    key = tuple(_type_key(a) for a in args)
+    if key not in arg_type_symbol_dict:
+        raise ValueError(f"no overload for argument types {key}; known: {sorted(map(str, arg_type_symbol_dict))}")
+    entry = arg_type_symbol_dict[key]
+    symbol, restype = entry if isinstance(entry, tuple) else (entry, ctypes.c_int)
+    if func is not None:
+        return func(symbol, args)
+    if lib_path:
+        fn = getattr(ctypes.CDLL(lib_path), symbol)
+        fn.restype = restype
+        return fn(*args)
+    return extern_call(symbol, args, restype=restype, lib=lib_name or "hip")

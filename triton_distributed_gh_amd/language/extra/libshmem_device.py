@@ -156,3 +156,25 @@ def fcollect(team, dest: torch.Tensor, src: torch.Tensor, nelems: int, stream=No
 
 broadcast_block = broadcast_warp = broadcast
 fcollect_block = fcollect_warp = fcollect
+
+
+def broadcastmem(team, dest: torch.Tensor, src: torch.Tensor, nbytes: int, pe_root: int, stream=None):
+    """Byte-counted ``broadcast``."""
+    _get(dest, src, nbytes, pe_root, stream)
+
+
+def fcollectmem(team, dest: torch.Tensor, src: torch.Tensor, nbytes: int, stream=None):
+    """Byte-counted ``fcollect``."""
+    flat, env = dest.view(-1).view(torch.uint8), get_env()
+    for r in range(env.world_size):
+        _get(flat[r * nbytes:(r + 1) * nbytes], src, nbytes, r, stream)
+
+
+broadcastmem_block = broadcastmem_warp = broadcastmem
+fcollectmem_block = fcollectmem_warp = fcollectmem
+barrier_block = barrier_warp = barrier
+# the "rma" forms address the remote-memory-access transport of an inter-node SHMEM; inside one xGMI node every
+# put is a store through the peer mapping, whatever the scope suffix
+putmem_rma_block = putmem_rma_warp = putmem_rma_nbi_block = putmem_rma_nbi_warp = _put
+putmem_signal_rma_block = putmem_signal_rma_nbi_block = _put_signal
+putmem_signal_rma_warp = putmem_signal_rma_nbi_warp = _put_signal

@@ -15,9 +15,47 @@ from typing import Optional
 import torch
 import torch.nn.functional as F
 
+from ..layers.tp_mlp import shard_local  # noqa: F401  (reference: models/qwen3.py:35)
 from ..models.kv_cache import PagedKVCache
 from .layers import TPAttnBuilder, TPMLPBuilder
 from .model_builder import ModelBuilder
+
+
+class Qwen3LayerBuilder:
+    """One decoder layer recorded from a HuggingFace-layout module (``self_attn`` / ``mlp`` / ``input_layernorm`` /
+    ``post_attention_layernorm``): reference models/qwen3.py:50-110.  ``build_fwd`` takes the residual stream
+    [tokens, H] and returns the tensor holding the updated stream (the same buffer, updated in place by the fused
+    add + norm tasks)."""
+
+    def __init__(self, builder: ModelBuilder, layer_idx: int, head_dim: int, rank: int = 0, world_size: int = 1):
+        self._builder, self.layer_idx, self.head_dim, self.rank, self.world_size = builder, layer_idx, head_dim, rank, world_size
+        self.attn: Optional[TPAttnBuilder] = None
+        self.mlp: Optional[TPMLPBuilder] = None
+        self.input_norm_w = self.post_norm_w = None
+        self.input_norm_eps = self.post_norm_eps = 1e-6
+
+    def init_parameters(self, hf_layer):
+        dev = self._builder.device
+        self.mlp = TPMLPBuilder(self._builder, self.rank, self.world_size)._init_parameters(hf_layer.mlp)
+        self.attn = TPAttnBuilder(self._builder, self.layer_idx, self.head_dim, self.rank,
+                                  self.world_size)._init_parameters(hf_layer.self_attn)
+        n1, n2 = hf_layer.input_layernorm, hf_layer.post_attention_layernorm
+        self.input_norm_w, self.post_norm_w = n1.weight.detach().to(dev), n2.weight.detach().to(dev)
+        self.input_norm_eps = float(getattr(n1, "variance_epsilon", getattr(n1, "eps", 1e-6)))
+        self.post_norm_eps = float(getattr(n2, "variance_epsilon", getattr(n2, "eps", 1e-6)))
+        return self
+
+    def build_fwd(self, hidden_states: torch.Tensor, cos_cache: torch.Tensor, sin_cache: torch.Tensor, kv_cache):
+        b, li = self._builder, self.layer_idx
+        shape = hidden_states.shape
+        h = hidden_states.view(-1, shape[-1])
+        xn = torch.zeros_like(h)
+        b.make_rms_norm(h, self.input_norm_w, xn, self.input_norm_eps, name=f"l{li}.norm1")
+        a = self.attn.build_fwd(xn, cos_cache, sin_cache, kv_cache, name=f"l{li}")
+        b.make_rms_norm(a, self.post_norm_w, xn, self.post_norm_eps, residual=h, residual_out=h, name=f"l{li}.norm2")
+        m = self.mlp.build_fwd(xn, name=f"l{li}")
+        b.make_add(h, m, h, name=f"l{li}.residual")
+        return hidden_states
 
 
 class Qwen3Model:

@@ -268,6 +268,91 @@ def _cq(s: str) -> str:
     return '"' + s.replace("\\", "\\\\").replace('"', '\\"') + '"'
 
 
+def make_kernel_algo_info_struct_name(kernel_name: str) -> str:
+    """Name of the settable algo-info struct of a kernel (reference: tools/compile_aot.py:187)."""
+    return f"{kernel_name}__triton_algo_info_t"
+
+
+_C_TYPES = {bool: "bool", int: "int", float: "float", str: "const char*"}
+
+
+def make_algo_info_decl(kernel_name: str, algo_info: dict) -> str:
+    """C declaration of the algo-info struct, one member per constant, for C / C++ callers of the generated
+    library (reference: tools/compile_aot.py:190-201)."""
+    members = "\n".join(f"  {_C_TYPES.get(type(v), 'int')} {k};" for k, v in algo_info.items())
+    return f"struct {make_kernel_algo_info_struct_name(kernel_name)} {{\n{members}\n}};\n"
+
+
+def aot_runtime_path() -> Path:
+    """Source of the code-object loader that generated libraries link against."""
+    return Path(__file__).resolve().parent.parent / "csrc" / "runtime" / "aot_runtime_hip.cc"
+
+
+def libhip_dirs() -> List[str]:
+    """Directories holding libamdhip64.so."""
+    cands = [Path("/opt/rocm/lib"), Path("/opt/rocm/lib64")]
+    return [str(d) for d in cands if (d / "libamdhip64.so").exists()]
+
+
+libcuda_dirs = libhip_dirs          # the reference's name (tools/compile_aot.py:681)
+
+
+def compile_kernel(path: str, kernel: str, workspace: Path, arch: str = "gfx950", build: bool = True) -> dict:
+    """One ``.hip`` kernel source -> code object ``<workspace>/<stem>.hsaco``; returns its manifest entry."""
+    co = Path(workspace) / f"{Path(path).stem}.hsaco"
+    if build:
+        cmd = ["hipcc", "--genco", f"--offload-arch={arch}", "-O3", "-std=c++17",
+               f"-I{Path(__file__).resolve().parent.parent / 'csrc' / 'include'}", path, "-o", str(co)]
+        subprocess.run(cmd, check=True)
+    return {"source": path, "kernel": kernel, "hsaco": str(co)}
+
+
+def gen_kernel_library(workspace: Path, library: str, specs: Dict[str, dict]) -> Path:
+    """Write ``<library>_registry.cc``: a static registrar that adds every spec (signature, grid, algo-infos) to
+    the native registry when the generated library is loaded."""
+    body = []
+    for name, spec in specs.items():
+        g = [str(x) for x in spec["grid"]]
+        body.append(f"    tdh_registry_add_kernel({_cq(name)}, {_cq(spec['signature'])}, {_cq(g[0])}, {_cq(g[1])}, "
+                    f"{_cq(g[2])});")
+        for info in spec["triton_algo_infos"]:
+            body.append(f"    tdh_registry_add_algo({_cq(name)}, {_cq(_consts_str(info))}, {_cq(name)});")
+    gen = Path(workspace) / f"{library}_registry.cc"
+    gen.write_text(_GEN_TEMPLATE.format(body="\n".join(body)))
+    header = Path(workspace) / f"{library}_algo_infos.h"
+    header.write_text("#pragma once\n" + "".join(make_algo_info_decl(n, sp["triton_algo_infos"][0])
+                                                  for n, sp in specs.items() if sp["triton_algo_infos"]))
+    return gen
+
+
+def gen_cmakelists(workspace: Path, library: str) -> Path:
+    """CMake project that builds the generated registrar into ``lib<library>.so`` against libtdist_host.so."""
+    from .. import build as b
+
+    txt = f"""cmake_minimum_required(VERSION 3.18)
+project({library} LANGUAGES CXX)
+set(CMAKE_CXX_STANDARD 17)
+add_library({library} SHARED {library}_registry.cc)
+target_link_directories({library} PRIVATE {b.HOST_LIB.parent})
+target_link_libraries({library} PRIVATE :{b.HOST_LIB.name})
+set_target_properties({library} PROPERTIES BUILD_RPATH {b.HOST_LIB.parent} INSTALL_RPATH {b.HOST_LIB.parent})
+"""
+    out = Path(workspace) / "CMakeLists.txt"
+    out.write_text(txt)
+    return out
+
+
+def link_all(workspace: Path, library: str) -> Path:
+    """Compile and link the generated registrar: ``<workspace>/lib<library>.so``."""
+    from .. import build as b
+
+    b.build_host(verbose=False)
+    out = Path(workspace) / f"lib{library}.so"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", str(Path(workspace) / f"{library}_registry.cc"), "-o",
+                    str(out), f"-L{b.HOST_LIB.parent}", f"-l:{b.HOST_LIB.name}", f"-Wl,-rpath,{b.HOST_LIB.parent}"], check=True)
+    return out
+
+
 def main(argv=None) -> int:
     ap = argparse.ArgumentParser(prog="compile_aot", description=__doc__.split("\n")[0])
     ap.add_argument("--workspace", required=True)
@@ -283,38 +368,23 @@ def main(argv=None) -> int:
         shutil.rmtree(ws)
     ws.mkdir(parents=True, exist_ok=True)
     manifest = {"library": args.library, "arch": args.arch, "kernels": {}, "code_objects": []}
-    body = []
+    specs: Dict[str, dict] = {}
     for item in args.kernels:
         path, _, kernel = item.rpartition(":")
         if not path:
             raise SystemExit(f"--kernels entries are path:kernel, got {item!r}")
         if path.endswith((".hip", ".cpp", ".cu")):
-            co = ws / f"{Path(path).stem}.hsaco"
-            manifest["code_objects"].append({"source": path, "kernel": kernel, "hsaco": str(co)})
-            if args.build:
-                cmd = ["hipcc", "--genco", f"--offload-arch={args.arch}", "-O3", "-std=c++17",
-                       f"-I{Path(__file__).resolve().parent.parent / 'csrc' / 'include'}", path, "-o", str(co)]
-                subprocess.run(cmd, check=True)
+            manifest["code_objects"].append(compile_kernel(path, kernel, ws, args.arch, args.build))
             continue
         for name, spec in _load_py_specs(path, kernel).items():
             manifest["kernels"][name] = {"signature": spec["signature"], "grid": [str(g) for g in spec["grid"]],
                                          "algo_infos": spec["triton_algo_infos"], "source": f"{path}:{kernel}"}
-            g = [str(x) for x in spec["grid"]]
-            body.append(f"    tdh_registry_add_kernel({_cq(name)}, {_cq(spec['signature'])}, {_cq(g[0])}, {_cq(g[1])}, "
-                        f"{_cq(g[2])});")
-            for info in spec["triton_algo_infos"]:
-                body.append(f"    tdh_registry_add_algo({_cq(name)}, {_cq(_consts_str(info))}, {_cq(name)});")
+            specs[name] = spec
     (ws / "manifest.json").write_text(json.dumps(manifest, indent=1, default=str))
-    gen = ws / f"{args.library}_registry.cc"
-    gen.write_text(_GEN_TEMPLATE.format(body="\n".join(body)))
+    gen_kernel_library(ws, args.library, specs)
+    gen_cmakelists(ws, args.library)
     if args.build:
-        from .. import build as b
-
-        b.build_host(verbose=False)
-        out = ws / f"lib{args.library}.so"
-        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", str(gen), "-o", str(out),
-                        f"-L{b.HOST_LIB.parent}", f"-l:{b.HOST_LIB.name}", f"-Wl,-rpath,{b.HOST_LIB.parent}"], check=True)
-        print(f"built {out}")
+        print(f"built {link_all(ws, args.library)}")
     print(f"wrote {ws / 'manifest.json'} ({len(manifest['kernels'])} kernels, {len(manifest['code_objects'])} code objects)")
     return 0
 

@@ -63,7 +63,6 @@ def triton_packed_version() -> int:
     v = getattr(torch.version, "hip", None) or "0.0"
     parts = [int("".join(c for c in x if c.isdigit()) or 0) for x in v.split(".")[:3]] + [0, 0]
     return (parts[0] << 16) | (parts[1] << 8) | (parts[2] & 0xFF)
-_BARRIER_CTX: Optional[BarrierAllContext] = None
 
 
 def initialize_distributed(seed=None, **kwargs):
@@ -113,11 +112,11 @@ rocshmem_create_tensor_list_intra_node = nvshmem_create_tensors
 
 
 def nvshmem_barrier_all_on_stream(stream: Optional["torch.cuda.Stream"] = None) -> None:
-    global _BARRIER_CTX
     env = get_env()
-    if _BARRIER_CTX is None or _BARRIER_CTX.env is not env:
-        _BARRIER_CTX = BarrierAllContext(env=env)
-    barrier_all_on_stream(_BARRIER_CTX, stream)
+    ctx = getattr(env, "_barrier_all_ctx", None)      # one per environment: virtual ranks each keep their own
+    if ctx is None:
+        ctx = env._barrier_all_ctx = BarrierAllContext(env=env)
+    barrier_all_on_stream(ctx, stream)
 
 
 def nvshmem_signal_wait(signal: torch.Tensor, pe: int, signal_val: int, signal_op: int = 0,

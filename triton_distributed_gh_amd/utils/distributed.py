@@ -16,7 +16,9 @@ from __future__ import annotations
 
 import atexit
 import datetime
+import contextlib
 import os
+import threading
 import random
 from dataclasses import dataclass
 from typing import Optional
@@ -64,11 +66,29 @@ def init_seed(seed: int = 0) -> None:
     random.seed(seed)
 
 
+_SCOPED = threading.local()
+
+
+@contextlib.contextmanager
+def use_env(env: "DistEnv"):
+    """Make ``env`` what ``get_env()`` returns on this thread (a virtual cluster runs every rank's function
+    inside one, so code written against the process-wide environment runs unchanged as any rank)."""
+    prev = getattr(_SCOPED, "env", None)
+    _SCOPED.env = env
+    try:
+        yield env
+    finally:
+        _SCOPED.env = prev
+
+
 def is_initialized() -> bool:
-    return _ENV is not None
+    return getattr(_SCOPED, "env", None) is not None or _ENV is not None
 
 
 def get_env() -> DistEnv:
+    scoped = getattr(_SCOPED, "env", None)
+    if scoped is not None:
+        return scoped
     if _ENV is None:
         raise RuntimeError("call initialize_distributed() first")
     return _ENV

@@ -27,7 +27,7 @@ from typing import Callable, List, Optional
 import torch
 
 from .. import _lib
-from .distributed import create_virtual_node
+from .distributed import create_virtual_node, use_env
 
 _POOL = {"main": [], "side": [], "gate": []}
 
@@ -62,7 +62,7 @@ class VirtualCluster:
         outs = [None] * self.world_size
         if self.backend == "hip":
             for r, env in enumerate(self.envs):
-                with torch.cuda.stream(self.streams[r]):
+                with torch.cuda.stream(self.streams[r]), use_env(env):
                     outs[r] = fn(r, env)
             if sync:
                 torch.cuda.synchronize()
@@ -71,7 +71,8 @@ class VirtualCluster:
 
         def work(r):
             try:
-                outs[r] = fn(r, self.envs[r])
+                with use_env(self.envs[r]):
+                    outs[r] = fn(r, self.envs[r])
             except BaseException as e:  # noqa: BLE001 - re-raised below on the main thread
                 errs[r] = e
 
