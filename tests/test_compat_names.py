@@ -104,6 +104,26 @@ def test_gemm_rs_swizzle_visits_next_rank_first_and_own_rows_last():
         check_gemm_rs_swizzle(M, w, nn, bm)
     assert f(0, 4096, 2, 8, 1, 256) == 3 * 2 and f(15, 4096, 2, 8, 1, 256) == 2 * 2 + 1
 
+    from triton_dist.kernels.nvidia.ag_gemm_threadblock_swizzle import check_ag_gemm_swizzle, threadblock_swizzle_allgather_gemm as g
+
+    for M, w, nn, bm in ((4096, 8, 1, 256), (4096, 8, 2, 128), (1536, 4, 1, 256), (8 * 200, 8, 1, 128)):
+        check_ag_gemm_swizzle(M, w, nn, bm)
+    assert [g(i, 2048, 2, 4, 1, 256) for i in range(8)] == [4, 5, 6, 7, 0, 1, 2, 3]       # own rows, then ranks 3, 0, 1
+
+
+def test_overload_dispatch_reaches_native_symbols():
+    import ctypes
+
+    from triton_dist.language.core import dispatch, extern_elementwise
+
+    table = {(): "tdh_registry_num_kernels", (torch.float32, int): ("no_such_symbol", ctypes.c_int)}
+    assert dispatch(None, "host", "", [], table) >= 0
+    assert dispatch(lambda sym, args: (sym, len(args)), "host", "", [], table) == ("tdh_registry_num_kernels", 0)
+    with pytest.raises(ValueError):
+        dispatch(None, "host", "", [1.5], table)
+    with pytest.raises(AttributeError):
+        extern_elementwise("host", "", [torch.zeros(2), 3], table)
+
 
 def test_moe_index_helpers():
     from triton_dist.kernels.nvidia import moe_utils as mu

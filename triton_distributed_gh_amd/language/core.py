@@ -53,4 +53,17 @@ def dispatch(func, lib_name: str, lib_path: str, args: list, arg_type_symbol_dic
         fn = getattr(ctypes.CDLL(lib_path), symbol)
         fn.restype = restype
         return fn(*args)
-    return extern_call(symbol, args, restype=restype, lib=lib_name or "hip")
+    return extern_call(symbol, args, restype=restype, lib=lib_name or "hip", check=False)
+
+
+def extern_elementwise(lib_name: str, lib_path: str, args: list, arg_type_symbol_dict: dict, is_pure: bool = False, **kw):
+    """Overload-resolved call of an external element-wise launcher (tensor arguments pass as pointers): the host-side
+    counterpart of the reference's pointer-capable ``extern_elementwise`` (python/triton_dist/language/core.py:121-164).
+    The symbol receives the arguments as given, tensors as ``void*``."""
+    import torch
+
+    conv = [ctypes.c_void_p(a.data_ptr()) if isinstance(a, torch.Tensor) else a for a in args]
+    key = tuple(_type_key(a) for a in args)
+    if key not in arg_type_symbol_dict:
+        raise ValueError(f"no overload for argument types {key}")
+    return dispatch(None, lib_name, lib_path, conv, {tuple(_type_key(a) for a in conv): arg_type_symbol_dict[key]}, is_pure)

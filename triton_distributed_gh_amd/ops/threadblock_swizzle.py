@@ -161,3 +161,34 @@ def check_gemm_rs_swizzle(M: int, WORLD_SIZE: int, NNODES: int = 1, BLOCK_SIZE_M
     for rank in range(WORLD_SIZE):
         got = [threadblock_swizzle_gemm_reduce_scatter(i, M, rank, WORLD_SIZE, NNODES, BLOCK_SIZE_M) for i in range(n)]
         assert sorted(got) == list(range(n)), f"rank {rank}: {got}"
+
+
+# ---- AG + GEMM ----------------------------------------------------------------------------------------------------
+def threadblock_swizzle_allgather_gemm(tiled_m: int, M: int, rank: int, WORLD_SIZE: int, NNODES: int = 1,
+                                       BLOCK_SIZE_M: int = 256) -> int:
+    """Position ``tiled_m`` of the row-block order of AG + GEMM -> row block of the gathered A computed there
+    (reference: kernels/nvidia/ag_gemm_threadblock_swizzle.py:51-136, a device function there).  Row blocks are
+    visited in ARRIVAL order: the rank's own rows (already local), then the ranks after it on its node, then the
+    same rotation on the following nodes.  A block that straddles two sources runs with the later one."""
+    assert WORLD_SIZE % NNODES == 0 and M % WORLD_SIZE == 0
+    local = WORLD_SIZE // NNODES
+    node, lrank = rank // local, rank % local
+    rows = M // WORLD_SIZE
+    sources = [((node + dn) % NNODES) * local + (lrank + d) % local for dn in range(NNODES) for d in range(local)]
+    arrival = {s: i for i, s in enumerate(sources)}
+    nblk = cdiv(M, BLOCK_SIZE_M)
+
+    def last_source(blk):
+        lo, hi = blk * BLOCK_SIZE_M, min((blk + 1) * BLOCK_SIZE_M, M) - 1
+        return max(arrival[s] for s in range(lo // rows, hi // rows + 1))
+
+    order = sorted(range(nblk), key=lambda b: (last_source(b), arrival[min((b * BLOCK_SIZE_M) // rows, WORLD_SIZE - 1)], b))
+    return order[tiled_m]
+
+
+def check_ag_gemm_swizzle(M: int, WORLD_SIZE: int, NNODES: int = 1, BLOCK_SIZE_M: int = 256) -> None:
+    n = cdiv(M, BLOCK_SIZE_M)
+    for rank in range(WORLD_SIZE):
+        got = [threadblock_swizzle_allgather_gemm(i, M, rank, WORLD_SIZE, NNODES, BLOCK_SIZE_M) for i in range(n)]
+        assert sorted(got) == list(range(n)), f"rank {rank}: {got}"
+        assert got[0] * BLOCK_SIZE_M // (M // WORLD_SIZE) == rank, "the first block is one of the rank's own"
