@@ -794,6 +794,154 @@ __device__ __forceinline__ void mainloop_256_4w(const TileArgs& t, char* smem, A
   asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
 }
 
+// Four-wave form with REGISTER staging (variant 12).  Same tile, wave layout, LDS image and fragment
+// double-buffering as mainloop_256_4w, but a slab travels global -> registers -> LDS: an LDS-DMA piece
+// holds the issuing wave for about 60 cycles, and with one wave per SIMD nothing else feeds the matrix
+// pipe meanwhile (8 pieces per 1024 MFMA cycles: the 40 % the LDS-DMA form loses), whereas a
+// `global_load_dwordx4` and a `ds_write_b128` each fit the 8 spare issue cycles behind a 16-cycle MFMA.
+//   * two register sets of 8 x 16 bytes per lane: during slab s, set s&1 (slab s+2, loaded during slab s-2)
+//     is written to LDS buffer (s+2)&3 piece by piece and each piece's registers are reloaded with slab s+4
+//     at once - a load has two slabs (~2000 cycles) to land;
+//   * first half of the slab's MFMAs: the 8 write + load pairs; second half: the 16 fragment reads of slab
+//     s+1, in the order the next slab's MFMAs consume them, so none is waited for at the slab boundary;
+//   * one barrier per slab: it publishes the writes of slab s+2 to the other waves' reads a slab later.
+template <bool IS_BF16>
+__device__ __forceinline__ void mainloop_256_4w_rs(const TileArgs& t, char* smem, Acc4<IS_BF16>& acc) {
+  using F = Frag<IS_BF16>;
+  using V = typename F::T;
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63;
+  const int wr = w >> 1, wc = w & 1;
+  const int i = l >> 2;
+  const int kchunk = (l & 3) ^ (((l >> 5) & 1) << 1);
+  const uint16_t* pa[4];
+  const uint16_t* pb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ts = 4 * w + j;
+    int ar = ts * 16 + i;
+    ar = ar < t.a_rows ? ar : t.a_rows - 1;
+    int br = (ts >> 3) * 128 + ((ts & 7) >> 1) * 32 + (i >> 2) * 8 + (ts & 1) * 4 + (i & 3);
+    br = br < t.b_rows ? br : t.b_rows - 1;
+    pa[j] = t.A + (long long)ar * t.lda + kchunk * 8;
+    pb[j] = t.B + (long long)br * t.ldb + kchunk * 8;
+  }
+  const int ns = t.K / 32;                                  // even, >= 4
+  char* st_dst = smem + w * 4096 + l * 16;                  // lane-linear image of a staged piece
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+  u32x4 st[2][8];
+  auto ld_piece = [&](int s, int set, auto jc) {
+    constexpr int j = decltype(jc)::value;                  // 0..3 A, 4..7 B
+    const uint16_t* src = (j < 4 ? pa[j & 3] : pb[j & 3]) + (long long)s * 32;
+    st[set][j] = *(const __attribute__((address_space(1))) u32x4*)src;
+  };
+  auto wr_piece = [&](int s, int set, auto jc) {
+    constexpr int j = decltype(jc)::value;
+    *(__attribute__((address_space(3))) u32x4*)(st_dst + (s & 3) * W4_SLAB + (j < 4 ? 0 : 16384) + (j & 3) * 1024) = st[set][j];
+  };
+  const int lane_off = (((l & 15) * 64) + ((l >> 4) * 16)) ^ ((((l & 15) >> 3) & 1) << 5);
+  const char* a_rd = smem + wr * 8192 + lane_off;
+  const char* b_rd = smem + 16384 + wc * 8192 + lane_off;
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int n = 0; n < 8; ++n) acc.v[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto for8 = [&](auto&& f) {
+    f(std::integral_constant<int, 0>{}); f(std::integral_constant<int, 1>{}); f(std::integral_constant<int, 2>{});
+    f(std::integral_constant<int, 3>{}); f(std::integral_constant<int, 4>{}); f(std::integral_constant<int, 5>{});
+    f(std::integral_constant<int, 6>{}); f(std::integral_constant<int, 7>{});
+  };
+  // prologue: slabs 0, 1 into LDS, slabs 2, 3 into the two register sets
+  for8([&](auto j) { ld_piece(0, 0, j); });
+  for8([&](auto j) { ld_piece(1, 1, j); });
+  for8([&](auto j) { wr_piece(0, 0, j); });
+  for8([&](auto j) { ld_piece(2, 0, j); });
+  for8([&](auto j) { wr_piece(1, 1, j); });
+  for8([&](auto j) { ld_piece(3, 1, j); });
+  __syncthreads();
+  V fa[2][8], fb[2][8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    fa[0][m] = *(const V*)(a_rd + m * 1024);
+    fb[0][m] = *(const V*)(b_rd + m * 1024);
+  }
+
+  auto slab_body = [&](int s, auto pc, auto steady_c) {
+    constexpr int P = decltype(pc)::value;
+    constexpr bool STEADY = decltype(steady_c)::value;
+    const bool more = STEADY || s + 1 < ns;                 // slab s+1 exists: read its fragments
+    const bool wr_next = STEADY || s + 2 < ns;              // slab s+2 exists: it sits in set P, write it
+    const bool ld_next = STEADY || s + 4 < ns;              // slab s+4 exists: load it into set P
+    // The wave's writes of slab s+1 (first half of the previous slab) must be complete before the barrier that
+    // publishes them; they are older than the 16 fragment reads issued behind them, so "all but the 15
+    // youngest" covers them.  The reads themselves need no retiring here: with four buffers the one they read
+    // is not rewritten before slab s+3.
+    if constexpr (STEADY) {
+      asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    const int nb = ((s + 1) & 3) * W4_SLAB;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      const int m = i >> 3, n = i & 7;
+      F::mfma_acc(fb[P][n], fa[P][m], acc.v[m][n]);
+      if (i >= 32) {
+        if ((i & 1) == 0 && more) {
+          const int j = (i - 32) >> 1;
+          if (j < 8)
+            fb[P ^ 1][j] = *(const V*)(b_rd + nb + j * 1024);
+          else
+            fa[P ^ 1][j - 8] = *(const V*)(a_rd + nb + (j - 8) * 1024);
+        }
+      } else if ((i & 3) == 0) {
+        if (wr_next) {
+          switch (i >> 2) {
+            case 0: wr_piece(s + 2, P, std::integral_constant<int, 0>{}); break;
+            case 1: wr_piece(s + 2, P, std::integral_constant<int, 1>{}); break;
+            case 2: wr_piece(s + 2, P, std::integral_constant<int, 2>{}); break;
+            case 3: wr_piece(s + 2, P, std::integral_constant<int, 3>{}); break;
+            case 4: wr_piece(s + 2, P, std::integral_constant<int, 4>{}); break;
+            case 5: wr_piece(s + 2, P, std::integral_constant<int, 5>{}); break;
+            case 6: wr_piece(s + 2, P, std::integral_constant<int, 6>{}); break;
+            default: wr_piece(s + 2, P, std::integral_constant<int, 7>{}); break;
+          }
+        }
+      } else if ((i & 3) == 2) {
+        if (ld_next) {
+          switch (i >> 2) {
+            case 0: ld_piece(s + 4, P, std::integral_constant<int, 0>{}); break;
+            case 1: ld_piece(s + 4, P, std::integral_constant<int, 1>{}); break;
+            case 2: ld_piece(s + 4, P, std::integral_constant<int, 2>{}); break;
+            case 3: ld_piece(s + 4, P, std::integral_constant<int, 3>{}); break;
+            case 4: ld_piece(s + 4, P, std::integral_constant<int, 4>{}); break;
+            case 5: ld_piece(s + 4, P, std::integral_constant<int, 5>{}); break;
+            case 6: ld_piece(s + 4, P, std::integral_constant<int, 6>{}); break;
+            default: ld_piece(s + 4, P, std::integral_constant<int, 7>{}); break;
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  int s = 0;
+  for (; s + 5 < ns; s += 2) {
+    slab_body(s, P0{}, std::true_type{});
+    slab_body(s + 1, P1{}, std::true_type{});
+  }
+  for (; s < ns; s += 2) {
+    slab_body(s, P0{}, std::false_type{});
+    slab_body(s + 1, P1{}, std::false_type{});
+  }
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+}
+
 // Stores of the four-wave accumulators straight from registers: 32 pieces of 16 bytes per lane,
 // `store(row_in_tile, col_in_tile, uint4)`.
 template <bool IS_BF16, class StoreFn>

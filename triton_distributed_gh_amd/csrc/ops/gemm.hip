@@ -108,7 +108,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_256_persistent_kernel(cons
 }
 
 // Four-wave persistent form (variant 4): see mainloop_256_4w.
-template <bool IS_BF16, bool SPREAD>
+template <bool IS_BF16, int MODE>
 __global__ __launch_bounds__(W4_THREADS) void gemm_nt_256_4w_kernel(const uint16_t* __restrict__ A,
                                                                     const uint16_t* __restrict__ B,
                                                                     uint16_t* __restrict__ C, int M, int N, int K,
@@ -132,7 +132,10 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_nt_256_4w_kernel(const uint16
     t.b_rows = N - col0;
     t.K = K;
     Acc4<IS_BF16> acc;
-    mainloop_256_4w<IS_BF16, SPREAD>(t, smem, acc);
+    if constexpr (MODE == 2)
+      mainloop_256_4w_rs<IS_BF16>(t, smem, acc);
+    else
+      mainloop_256_4w<IS_BF16, MODE == 1>(t, smem, acc);
     const int mrem = M - row0, nrem = N - col0;
     uint16_t* cbase = C + (long long)row0 * ldc + col0;
     epilogue_256_4w_direct<IS_BF16>(acc, [&](int r, int c, const uint4& v) {
@@ -334,35 +337,27 @@ TDIST_API int tdist_gemm_nt(const void* A, const void* B, void* C, int M, int N,
         TDIST_HIP_TRY(hipFuncSetAttribute((const void*)table[i][j], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set = true;
   }
-  if ((variant & 255) == 4 || (variant & 255) == 11) {
-    const bool spread = (variant & 255) == 11;
+  if ((variant & 255) == 4 || (variant & 255) == 11 || (variant & 255) == 12) {
+    // four-wave forms: 4 = LDS-DMA in groups, 11 = LDS-DMA spread between the MFMAs, 12 = register staging
+    typedef void (*k4_t)(const uint16_t*, const uint16_t*, uint16_t*, int, int, int, long long, long long, long long, int);
+    static const k4_t k4[2][3] = {{gemm_nt_256_4w_kernel<true, 0>, gemm_nt_256_4w_kernel<true, 1>, gemm_nt_256_4w_kernel<true, 2>},
+                                  {gemm_nt_256_4w_kernel<false, 0>, gemm_nt_256_4w_kernel<false, 0>,
+                                   gemm_nt_256_4w_kernel<false, 2>}};
     static int num_cus4 = 0;
     if (!num_cus4) {
       int dev = 0;
       TDIST_HIP_TRY(hipGetDevice(&dev));
       TDIST_HIP_TRY(hipDeviceGetAttribute(&num_cus4, hipDeviceAttributeMultiprocessorCount, dev));
-      TDIST_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_256_4w_kernel<true, false>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES));
-      TDIST_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_256_4w_kernel<true, true>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES));
-      TDIST_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_256_4w_kernel<false, false>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES));
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 3; ++j)
+          TDIST_HIP_TRY(hipFuncSetAttribute((const void*)k4[i][j], hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES));
     }
     int grid = num_cus4 & ~7;
     if (grid < 8) grid = 8;
     if (tiles < grid) grid = tiles;
-    if (dtype == 0 && spread)
-      hipLaunchKernelGGL((gemm_nt_256_4w_kernel<true, true>), dim3(grid), dim3(W4_THREADS), W4_LDS_BYTES,
-                         (hipStream_t)stream, (const uint16_t*)A, (const uint16_t*)B, (uint16_t*)C, M, N, K, lda, ldb,
-                         ldc, group_m);
-    else if (dtype == 0)
-      hipLaunchKernelGGL((gemm_nt_256_4w_kernel<true, false>), dim3(grid), dim3(W4_THREADS), W4_LDS_BYTES,
-                         (hipStream_t)stream, (const uint16_t*)A, (const uint16_t*)B, (uint16_t*)C, M, N, K, lda, ldb,
-                         ldc, group_m);
-    else
-      hipLaunchKernelGGL((gemm_nt_256_4w_kernel<false, false>), dim3(grid), dim3(W4_THREADS), W4_LDS_BYTES,
-                         (hipStream_t)stream, (const uint16_t*)A, (const uint16_t*)B, (uint16_t*)C, M, N, K, lda, ldb,
-                         ldc, group_m);
+    const int mode = (variant & 255) == 4 ? 0 : ((variant & 255) == 11 ? 1 : 2);
+    hipLaunchKernelGGL(k4[dtype == 0 ? 0 : 1][mode], dim3(grid), dim3(W4_THREADS), W4_LDS_BYTES, (hipStream_t)stream,
+                       (const uint16_t*)A, (const uint16_t*)B, (uint16_t*)C, M, N, K, lda, ldb, ldc, group_m);
     TDIST_HIP_TRY(hipGetLastError());
     return 0;
   }
