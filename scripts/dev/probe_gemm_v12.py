@@ -25,12 +25,14 @@ for (M, N, K) in [(256, 256, 128), (512, 768, 256), (300, 520, 192), (4096, 8192
         b = (torch.rand(N, K, device="cuda") * 2 - 1).to(dt)
         out = torch.full((M, N), 7.0, device="cuda", dtype=dt)
         ref = a.float() @ b.float().t()
-        gemm_nt(a, b, out=out, force_native=True, variant=12)
-        torch.cuda.synchronize()
-        good = torch.allclose(out.float(), ref, atol=0.15 * (K / 1024) ** 0.5, rtol=2e-2)
-        err = ((out.float() - ref).abs().max() / ref.abs().max()).item()
-        ok &= good
-        print(f"v12 {M}x{N}x{K} {dt}: rel err {err:.2e} {'ok' if good else 'FAIL'}", flush=True)
+        for variant in (12, 13):
+            out.fill_(7.0)
+            gemm_nt(a, b, out=out, force_native=True, variant=variant)
+            torch.cuda.synchronize()
+            good = torch.allclose(out.float(), ref, atol=0.15 * (K / 1024) ** 0.5, rtol=2e-2)
+            err = ((out.float() - ref).abs().max() / ref.abs().max()).item()
+            ok &= good
+            print(f"v{variant} {M}x{N}x{K} {dt}: rel err {err:.2e} {'ok' if good else 'FAIL'}", flush=True)
 if not ok:
     sys.exit(1)
 
@@ -40,7 +42,7 @@ b = (torch.rand(N, K, device="cuda") * 2 - 1).bfloat16()
 out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
 fns = {"v3": lambda: gemm_nt(a, b, out=out, force_native=True, variant=3 | (3 << 16)),
        "v12": lambda: gemm_nt(a, b, out=out, force_native=True, variant=12),
-       "v11": lambda: gemm_nt(a, b, out=out, force_native=True, variant=11),
+       "v13": lambda: gemm_nt(a, b, out=out, force_native=True, variant=13),
        "torch": lambda: torch.matmul(a, b.t(), out=out)}
 for _ in range(40):
     for f in fns.values():

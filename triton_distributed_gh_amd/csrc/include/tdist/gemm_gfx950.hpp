@@ -942,6 +942,194 @@ __device__ __forceinline__ void mainloop_256_4w_rs(const TileArgs& t, char* smem
   asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
 }
 
+// ---------------------------------------------------------------------------------------------
+// Four-wave form on 32x32x16 MFMAs (variant 13).  One wave per SIMD has nobody to hide its memory
+// instructions behind, and behind a 16-cycle 16x16x32 MFMA a wave has only ~8 spare issue cycles - less
+// than a `ds_read_b128` takes (the 40 % the other four-wave forms lose).  A 32x32x16 MFMA keeps the
+// matrix pipe busy for 32 cycles per issue, which leaves room for one memory instruction per MFMA.
+//   * wave tile 128 x 128 = 4 x 4 accumulator blocks of 32 x 32 (16 registers each, 256 accumulation
+//     registers); per 32-deep slab two k16 steps x 16 MFMAs, 16 fragment reads and 8 LDS-DMA pieces;
+//   * a staged piece is [16 rows][4 chunks of 8 k] (adjacent lanes load adjacent bytes of a row), stored
+//     lane-linear with chunk' = chunk ^ (row bits 2..3); a fragment of 32 rows x 16 k is then read from two
+//     pieces with every 16-lane service group of `ds_read_b128` on 16 distinct bank slots;
+//   * B rows are permuted at staging (fragment row f holds column 16*bit2(f) + 4*(f >> 3) + (f & 3) of its
+//     32) so that a lane's 16 accumulator values of a block are 16 CONSECUTIVE columns of one output row;
+//   * ring of four slab buffers, pieces of three slabs in flight, one barrier per slab (as mainloop_256_4w).
+// EXP (timing experiments only, wrong results): bit 0 drops the barrier, bit 1 the staging inside the loop, bit 2
+// the fragment reads.  Measured at 4096 x 8192 x 8192: MFMAs alone 296 us, + reads 334, + staging 381, all 413
+// (barrier: 4 us) - an LDS-DMA piece still idles the matrix pipe for ~37 cycles and a read for ~9, so one wave
+// per SIMD does not reach the eight-wave kernel (344 us) with this MFMA shape either.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <bool IS_BF16>
+struct Acc32 {
+  f32x16 v[4][4];
+};
+
+template <bool IS_BF16>
+__device__ __forceinline__ void mfma32_acc(typename Frag<IS_BF16>::T a, typename Frag<IS_BF16>::T b, f32x16& c) {
+  if constexpr (IS_BF16) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  } else {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  }
+}
+
+template <bool IS_BF16, int EXP = 0>
+__device__ __forceinline__ void mainloop_256_4w32(const TileArgs& t, char* smem, Acc32<IS_BF16>& acc) {
+  using F = Frag<IS_BF16>;
+  using V = typename F::T;
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63;
+  const int wr = w >> 1, wc = w & 1;
+  const int rl = l >> 2;                                    // row inside a staged piece
+  const int kchunk = (l & 3) ^ ((rl >> 2) & 3);             // source chunk of the slot this lane fills
+  const uint16_t* pa[4];
+  const uint16_t* pb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int piece = 4 * w + j;                            // 0..15 inside the slab's A / B half
+    int ar = piece * 16 + rl;
+    ar = ar < t.a_rows ? ar : t.a_rows - 1;
+    // B piece = half (piece & 1) of fragment (piece >> 1); its row rl is fragment row f = 16 * half + rl
+    int br = (piece >> 1) * 32 + 16 * ((rl >> 2) & 1) + 4 * (2 * (piece & 1) + (rl >> 3)) + (rl & 3);
+    br = br < t.b_rows ? br : t.b_rows - 1;
+    pa[j] = t.A + (long long)ar * t.lda + kchunk * 8;
+    pb[j] = t.B + (long long)br * t.ldb + kchunk * 8;
+  }
+  const int ns = t.K / 32;                                  // even, >= 4
+  char* stage_dst = smem + w * 4096;
+  auto stage_piece = [&](int s, auto jc) {
+    constexpr int j = decltype(jc)::value;                  // 0..3 A, 4..7 B
+    const uint16_t* src = (j < 4 ? pa[j & 3] : pb[j & 3]) + (long long)s * 32;
+    char* dst = stage_dst + (s & 3) * W4_SLAB + (j < 4 ? 0 : 16384) + (j & 3) * 1024;
+    __builtin_amdgcn_global_load_lds(TDIST_GLB_PTR(src), TDIST_LDS_PTR(dst), 16, 0, 0);
+  };
+  auto stage_slab = [&](int s) {
+    stage_piece(s, std::integral_constant<int, 0>{}); stage_piece(s, std::integral_constant<int, 1>{});
+    stage_piece(s, std::integral_constant<int, 2>{}); stage_piece(s, std::integral_constant<int, 3>{});
+    stage_piece(s, std::integral_constant<int, 4>{}); stage_piece(s, std::integral_constant<int, 5>{});
+    stage_piece(s, std::integral_constant<int, 6>{}); stage_piece(s, std::integral_constant<int, 7>{});
+  };
+  // fragment read offsets: lane = (row l & 31 of the fragment, k half l >> 5); k16 step c reads chunk 2c + h
+  const int frl = l & 15, fh = l >> 5, fsw = (frl >> 2) & 3;
+  const int lane_off0 = ((l >> 4) & 1) * 1024 + frl * 64 + ((fh ^ fsw) << 4);
+  const int lane_off1 = ((l >> 4) & 1) * 1024 + frl * 64 + (((2 + fh) ^ fsw) << 4);
+  const char* a_rd0 = smem + wr * 8192 + lane_off0;         // + slab buffer + m * 2048
+  const char* a_rd1 = smem + wr * 8192 + lane_off1;
+  const char* b_rd0 = smem + 16384 + wc * 8192 + lane_off0; // + slab buffer + n * 2048
+  const char* b_rd1 = smem + 16384 + wc * 8192 + lane_off1;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc.v[m][n][r] = 0.f;
+
+  V fa[2][2][4], fb[2][2][4];                               // [slab parity][k16 step][block]
+  stage_slab(0); stage_slab(1); stage_slab(2); stage_slab(3);
+  asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    fb[0][0][m] = *(const V*)(b_rd0 + m * 2048);
+    fa[0][0][m] = *(const V*)(a_rd0 + m * 2048);
+    fb[0][1][m] = *(const V*)(b_rd1 + m * 2048);
+    fa[0][1][m] = *(const V*)(a_rd1 + m * 2048);
+  }
+
+  auto slab_body = [&](int s, auto pc, auto steady_c) {
+    constexpr int P = decltype(pc)::value;
+    constexpr bool STEADY = decltype(steady_c)::value;
+    const bool more = (EXP & 4) ? false : (STEADY || s + 1 < ns);
+    if constexpr (STEADY) {
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else if (more) {
+      if (s + 3 < ns) {
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      } else if (s + 2 < ns) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+    // this wave's reads of slab s (issued during slab s-1) are retired before the barrier: after it another
+    // wave restages that buffer
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!(EXP & 1)) __builtin_amdgcn_s_barrier();
+    const int nb = ((s + 1) & 3) * W4_SLAB;
+    const bool restage = (EXP & 2) ? false : (STEADY || s + 4 < ns);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int c = i >> 4, m = (i >> 2) & 3, n = i & 3;
+      mfma32_acc<IS_BF16>(fb[P][c][n], fa[P][c][m], acc.v[m][n]);
+      if (i < 16) {
+        // next slab's fragments in the order its MFMAs need them: k16 step 0 (B0..3, A0..3), then step 1
+        if (more) {
+          const int j = i & 3;
+          switch (i >> 2) {
+            case 0: fb[P ^ 1][0][j] = *(const V*)(b_rd0 + nb + j * 2048); break;
+            case 1: fa[P ^ 1][0][j] = *(const V*)(a_rd0 + nb + j * 2048); break;
+            case 2: fb[P ^ 1][1][j] = *(const V*)(b_rd1 + nb + j * 2048); break;
+            default: fa[P ^ 1][1][j] = *(const V*)(a_rd1 + nb + j * 2048); break;
+          }
+        }
+      } else if ((i & 1) == 0 && restage) {
+        switch ((i - 16) >> 1) {
+          case 0: stage_piece(s + 4, std::integral_constant<int, 0>{}); break;
+          case 1: stage_piece(s + 4, std::integral_constant<int, 1>{}); break;
+          case 2: stage_piece(s + 4, std::integral_constant<int, 2>{}); break;
+          case 3: stage_piece(s + 4, std::integral_constant<int, 3>{}); break;
+          case 4: stage_piece(s + 4, std::integral_constant<int, 4>{}); break;
+          case 5: stage_piece(s + 4, std::integral_constant<int, 5>{}); break;
+          case 6: stage_piece(s + 4, std::integral_constant<int, 6>{}); break;
+          default: stage_piece(s + 4, std::integral_constant<int, 7>{}); break;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  int s = 0;
+  for (; s + 5 < ns; s += 2) {
+    slab_body(s, P0{}, std::true_type{});
+    slab_body(s + 1, P1{}, std::true_type{});
+  }
+  for (; s < ns; s += 2) {
+    slab_body(s, P0{}, std::false_type{});
+    slab_body(s + 1, P1{}, std::false_type{});
+  }
+  // the MFMAs are inline assembly: cover the read-after-MFMA distance of a 16-pass MFMA by hand
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+}
+
+// Stores of the 32x32-block accumulators: per block a lane holds 16 consecutive columns of one row.
+template <bool IS_BF16, class StoreFn>
+__device__ __forceinline__ void epilogue_256_4w32_direct(const Acc32<IS_BF16>& acc, StoreFn&& store) {
+  using F = Frag<IS_BF16>;
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, l = tid & 63;
+  const int row = (w >> 1) * 128 + (l & 31);
+  const int col = (w & 1) * 128 + (l >> 5) * 16;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const f32x16& a = acc.v[m][n];
+        uint4 v;
+        v.x = F::pack2(a[8 * hh + 0], a[8 * hh + 1]);
+        v.y = F::pack2(a[8 * hh + 2], a[8 * hh + 3]);
+        v.z = F::pack2(a[8 * hh + 4], a[8 * hh + 5]);
+        v.w = F::pack2(a[8 * hh + 6], a[8 * hh + 7]);
+        store(row + 32 * m, col + 32 * n + 8 * hh, v);
+      }
+}
+
 // Stores of the four-wave accumulators straight from registers: 32 pieces of 16 bytes per lane,
 // `store(row_in_tile, col_in_tile, uint4)`.
 template <bool IS_BF16, class StoreFn>

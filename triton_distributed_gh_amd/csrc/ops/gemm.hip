@@ -146,6 +146,42 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_nt_256_4w_kernel(const uint16
   }
 }
 
+// Four-wave persistent form on 32x32x16 MFMAs (variant 13): see mainloop_256_4w32.
+template <bool IS_BF16, int EXP = 0>
+__global__ __launch_bounds__(W4_THREADS) void gemm_nt_256_4w32_kernel(const uint16_t* __restrict__ A,
+                                                                      const uint16_t* __restrict__ B,
+                                                                      uint16_t* __restrict__ C, int M, int N, int K,
+                                                                      long long lda, long long ldb, long long ldc,
+                                                                      int group_m) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int num_pid_m = (M + BM - 1) / BM;
+  const int num_pid_n = (N + BN - 1) / BN;
+  const int nwg = num_pid_m * num_pid_n;
+  for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
+    const int id = xcd_remap(vb, nwg);
+    int pid_m, pid_n;
+    tile_coords(id, num_pid_m, num_pid_n, group_m, pid_m, pid_n);
+    const int row0 = pid_m * BM, col0 = pid_n * BN;
+    TileArgs t;
+    t.A = A + (long long)row0 * lda;
+    t.B = B + (long long)col0 * ldb;
+    t.lda = lda;
+    t.ldb = ldb;
+    t.a_rows = M - row0;
+    t.b_rows = N - col0;
+    t.K = K;
+    Acc32<IS_BF16> acc;
+    mainloop_256_4w32<IS_BF16, EXP>(t, smem, acc);
+    const int mrem = M - row0, nrem = N - col0;
+    uint16_t* cbase = C + (long long)row0 * ldc + col0;
+    epilogue_256_4w32_direct<IS_BF16>(acc, [&](int r, int c, const uint4& v) {
+      if (r < mrem && c < nrem) *(uint4*)(cbase + (long long)r * ldc + c) = v;
+    });
+    // the next tile's prologue restages all four slabs: every wave must be done reading first
+    __syncthreads();
+  }
+}
+
 // Decode-shaped GEMM (M <= 16): the weights are streamed exactly once with non-temporal 16-byte
 // loads and feed 16x16x32 MFMAs whose M dimension is the zero-padded batch.  A workgroup of four
 // (or eight, NW) waves covers BN = 16 * WN output columns (WN = 1 / 2 / 4); wave k owns the k-th slice
@@ -336,6 +372,25 @@ TDIST_API int tdist_gemm_nt(const void* A, const void* B, void* C, int M, int N,
       for (int j = 0; j < 8; ++j)
         TDIST_HIP_TRY(hipFuncSetAttribute((const void*)table[i][j], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set = true;
+  }
+  if ((variant & 255) == 13) {
+    typedef void (*k4_t)(const uint16_t*, const uint16_t*, uint16_t*, int, int, int, long long, long long, long long, int);
+    static const k4_t k32[2] = {gemm_nt_256_4w32_kernel<true>, gemm_nt_256_4w32_kernel<false>};
+    static int num_cus32 = 0;
+    if (!num_cus32) {
+      int dev = 0;
+      TDIST_HIP_TRY(hipGetDevice(&dev));
+      TDIST_HIP_TRY(hipDeviceGetAttribute(&num_cus32, hipDeviceAttributeMultiprocessorCount, dev));
+      for (int i = 0; i < 2; ++i)
+        TDIST_HIP_TRY(hipFuncSetAttribute((const void*)k32[i], hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES));
+    }
+    int grid = num_cus32 & ~7;
+    if (grid < 8) grid = 8;
+    if (tiles < grid) grid = tiles;
+    hipLaunchKernelGGL(k32[dtype == 0 ? 0 : 1], dim3(grid), dim3(W4_THREADS), W4_LDS_BYTES, (hipStream_t)stream,
+                       (const uint16_t*)A, (const uint16_t*)B, (uint16_t*)C, M, N, K, lda, ldb, ldc, group_m);
+    TDIST_HIP_TRY(hipGetLastError());
+    return 0;
   }
   if ((variant & 255) == 4 || (variant & 255) == 11 || (variant & 255) == 12) {
     // four-wave forms: 4 = LDS-DMA in groups, 11 = LDS-DMA spread between the MFMAs, 12 = register staging
