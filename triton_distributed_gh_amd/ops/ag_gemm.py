@@ -112,6 +112,12 @@ def create_ag_gemm_intra_node_context(max_M, N, K, input_dtype, output_dtype, ra
     # "kernel": push kernel (device-side stores + system-scope flag), no driver-dependent ordering.
     # "copy_engine": SDMA copies; flags by 4-byte copies (as the reference) or stream write-value.
     producer = producer or os.environ.get("TDIST_AG_PRODUCER", "kernel")
+    if producer == "copy_engine" and env.backend == "hip" and env.shared_gpu and env.cpu_group is not None and num_ranks > 1:
+        # Several PROCESSES on one GPU: the consumer launch never returns once copies into another process's
+        # mapping of the same device are queued (observed with two ranks: both block inside the kernel launch).
+        # One process with virtual ranks, and one GPU per process, do not go through that driver path.
+        raise RuntimeError("the copy-engine producer is not available when several processes share one GPU; "
+                           "use producer='kernel' (default) or one GPU per rank")
     epoch_table = scratch = state = None
     if env.backend == "hip":
         epoch_table = torch.arange(EPOCH_MOD + 2, dtype=torch.int32, device=env.device)
