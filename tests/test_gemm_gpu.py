@@ -137,6 +137,73 @@ def test_decode_gemm_with_silu_mul_epilogue(M, I, K):
     assert (got.float() - two.float()).abs().max().item() <= 1e-2 * ref.abs().max().item() + 1e-3
 
 
+@pytest.mark.parametrize("M", [1, 3, 5])
+@pytest.mark.parametrize("N,K", [(6144, 4096), (4096, 4096), (1000, 192), (16384, 1024), (40, 128)])
+@pytest.mark.parametrize("with_residual", [False, True])
+def test_decode_gemm_with_fused_rms_norm(M, N, K, with_residual):
+    """RMSNorm (+ residual add) folded into the decode GEMM vs the two kernels and vs fp32: every column-block
+    size, partial column blocks, a K below one batch of loads per wave, strided activations."""
+    from triton_distributed_gh_amd.ops.elementwise import rms_norm
+    from triton_distributed_gh_amd.ops.gemm import gemm_nt_norm, norm_gemm_supported
+
+    torch.manual_seed(M + N + K)
+    xa = ((torch.rand(M, K + 64, device="cuda") * 2 - 1) * 3).bfloat16()
+    x = xa[:, :K]
+    res = ((torch.rand(M, K, device="cuda") * 2 - 1) * 3).bfloat16() if with_residual else None
+    g = (torch.rand(K, device="cuda") + 0.5).bfloat16()
+    w = ((torch.rand(N, K, device="cuda") * 2 - 1) * 0.1).bfloat16()
+    assert norm_gemm_supported(x, w, g, res)
+    res_before = res.clone() if with_residual else None
+    out, hidden = gemm_nt_norm(x, g, 1e-5, w, residual=res)
+    if with_residual:
+        y2, h2 = rms_norm(x.contiguous(), g, 1e-5, residual=res)
+        assert torch.equal(hidden, h2), "x + residual must be bit-identical to the norm kernel's"
+        assert torch.equal(res, res_before)
+    else:
+        y2 = rms_norm(x.contiguous(), g, 1e-5)
+        assert hidden is x
+    two = gemm_nt(y2, w, force_native=True)
+    hf = (x.float() + res.float()).bfloat16().float() if with_residual else x.float()
+    ref = (hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + 1e-5) * g.float()) @ w.float().t()
+    scale = ref.abs().max().item()
+    assert (out.float() - ref).abs().max().item() <= 2e-2 * scale + 1e-3
+    assert (out.float() - two.float()).abs().max().item() <= 2e-2 * scale + 1e-3
+
+
+@pytest.mark.parametrize("M", [1, 4])
+def test_decode_gemm_with_fused_rms_norm_and_silu(M):
+    from triton_distributed_gh_amd.ops.gemm import gemm_nt_norm
+
+    torch.manual_seed(M)
+    K, I = 4096, 12288
+    x = ((torch.rand(M, K, device="cuda") * 2 - 1) * 2).bfloat16()
+    res = ((torch.rand(M, K, device="cuda") * 2 - 1) * 2).bfloat16()
+    g = (torch.rand(K, device="cuda") + 0.5).bfloat16()
+    w = ((torch.rand(2 * I, K, device="cuda") * 2 - 1) * 0.05).bfloat16()
+    out, hidden = gemm_nt_norm(x, g, 1e-6, w, residual=res, silu=True)
+    hf = (x.float() + res.float()).bfloat16().float()
+    assert torch.equal(hidden.float(), hf)
+    gu = (hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + 1e-6) * g.float()) @ w.float().t()
+    ref = torch.nn.functional.silu(gu[:, :I]) * gu[:, I:]
+    assert out.shape == (M, I)
+    assert (out.float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item() + 1e-3
+
+
+def test_fused_rms_norm_gemm_falls_back_outside_its_shapes():
+    """More than 16 rows (or rows x K beyond the LDS buffer): the norm kernel followed by the GEMM, same contract."""
+    from triton_distributed_gh_amd.ops.gemm import gemm_nt_norm, norm_gemm_supported
+
+    torch.manual_seed(0)
+    x = (torch.rand(16, 4096, device="cuda") * 2 - 1).bfloat16()
+    g = torch.ones(4096, device="cuda", dtype=torch.bfloat16)
+    w = ((torch.rand(512, 4096, device="cuda") * 2 - 1) * 0.1).bfloat16()
+    assert not norm_gemm_supported(x, w, g, None)           # 16 x 8 KiB of activations do not fit
+    out, hidden = gemm_nt_norm(x, g, 1e-6, w)
+    xf = x.float()
+    ref = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)) @ w.float().t()
+    assert hidden is x and (out.float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+
+
 def test_measured_gemm_times_sit_between_the_speed_of_light_and_the_model():
     """The perf model's MI355X tables against this GPU: a measured GEMM can never beat the speed-of-light
     estimate, and stays within 2x of what the model expects of the tile engine / the streaming kernel."""

@@ -195,11 +195,22 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_nt_256_4w32_kernel(const uint
 // n0 .. n0+15 and the matching up columns I + n0 .. I + n0+15, and the epilogue stores
 // silu(gate) * up into C [M, I] - the activation kernel of a gated MLP folded into its first projection
 // (reference: mega_triton_kernel/kernels/mlp_fc1.py + activation.py as two tasks).
-template <bool IS_BF16, int WN, int NW, bool SILU = false>
+//
+// NORM (bf16): the RMSNorm in front of the projection rides along.  X is the un-normalised input, R an optional
+// residual added to it first (h = bf16(X + R); workgroup 0 writes h to Hout, which must not alias X or R) and G the
+// norm weight: the MFMAs consume bf16(h * G) and the epilogue multiplies every row by rsqrt(mean(h^2) + eps),
+// whose sum of squares each wave collects over its own K slice from the fragments it loads anyway.  Every
+// workgroup repeats that arithmetic (a few VALU operations per 16 bytes of weights: the kernel is HBM-bound), and
+// a decode step loses the two norm launches per layer with their dependent round trips.
+template <bool IS_BF16, int WN, int NW, bool SILU = false, bool NORM = false>
 __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const uint16_t* __restrict__ X,
                                                              const uint16_t* __restrict__ W,
                                                              uint16_t* __restrict__ C, int M, int N, int K,
-                                                             long long ldx, long long ldw, long long ldc) {
+                                                             long long ldx, long long ldw, long long ldc,
+                                                             const uint16_t* __restrict__ R = nullptr,
+                                                             const uint16_t* __restrict__ G = nullptr,
+                                                             uint16_t* __restrict__ Hout = nullptr, float eps = 0.f) {
+  static_assert(!NORM || IS_BF16, "the fused norm is built for bf16");
   using F = Frag<IS_BF16>;
   using VT = typename F::T;
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -223,9 +234,58 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const uint16_t*
   f32x4 acc[WN];
 #pragma unroll
   for (int j = 0; j < WN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // ---- fused norm (see the comment above the kernel): normalised-but-unscaled activations go to LDS ----
+  extern __shared__ __attribute__((aligned(16))) char tbuf[];     // NORM: [M][K * 2 + 64] bytes (rows padded: banks)
+  __shared__ float s_ss[16];
+  const long long trow = (long long)K * 2 + 64;
+  auto norm_prepass = [&]() {
+    if constexpr (NORM) {
+      if (threadIdx.x < 16) s_ss[threadIdx.x] = 0.f;
+      __syncthreads();
+      const int nvec = K / 8;
+      for (int row = 0; row < M; ++row) {
+        float ss = 0.f;
+        for (int c = threadIdx.x; c < nvec; c += 64 * NW) {
+          const u32x4 xv = *(const u32x4*)(X + (long long)row * ldx + c * 8);
+          const u32x4 gv = *(const u32x4*)(G + c * 8);
+          u32x4 rv = {0, 0, 0, 0}, hb, t;
+          if (R) rv = *(const u32x4*)(R + (long long)row * K + c * 8);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float lo = __builtin_bit_cast(float, xv[i] << 16), hi = __builtin_bit_cast(float, xv[i] & 0xffff0000u);
+            hb[i] = xv[i];
+            if (R) {
+              lo += __builtin_bit_cast(float, rv[i] << 16);
+              hi += __builtin_bit_cast(float, rv[i] & 0xffff0000u);
+              hb[i] = F::pack2(lo, hi);      // the sum rounded to 16 bits is what the norm sees (as the separate kernel)
+              lo = __builtin_bit_cast(float, hb[i] << 16), hi = __builtin_bit_cast(float, hb[i] & 0xffff0000u);
+            }
+            ss += lo * lo + hi * hi;
+            t[i] = F::pack2(lo * __builtin_bit_cast(float, gv[i] << 16), hi * __builtin_bit_cast(float, gv[i] & 0xffff0000u));
+          }
+          *(u32x4*)(tbuf + row * trow + c * 16) = t;
+          if (R && blockIdx.x == 0) *(u32x4*)(Hout + (long long)row * K + c * 8) = hb;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        if (lane == 0) atomicAdd(&s_ss[row], ss);
+      }
+      __syncthreads();
+    }
+  };
+  auto load_x = [&](int ks) -> u32x4 {
+    if constexpr (NORM) {
+      return xvalid ? *(const u32x4*)(tbuf + li * trow + (ks * 32 + lg * 8) * 2) : u32x4{0, 0, 0, 0};
+    } else {
+      return xvalid ? *(const u32x4*)(xr + ks * 32) : u32x4{0, 0, 0, 0};
+    }
+  };
   // (Walking K from a per-workgroup rotated start, against power-of-two row strides all starting on
   // the same HBM channel, was measured: no gain at N x K = 12800 x 8192, 3-6 % slower at 32768 x 4096.)
   const int nfull = (ks1 - ks0) / U;
+  // The pre-pass holds workgroup barriers: every wave runs it exactly once - behind its first batch of weight
+  // loads when it has a full batch, in front of the loop otherwise.
+  if (nfull == 0) norm_prepass();
   for (int bi = 0; bi < nfull; ++bi) {
     const int ks = ks0 + bi * U;
     u32x4 wv[U][WN], xv[U];
@@ -233,8 +293,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const uint16_t*
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int j = 0; j < WN; ++j) wv[u][j] = __builtin_nontemporal_load((const u32x4*)(wr[j] + (ks + u) * 32));
+    if (bi == 0) norm_prepass();
 #pragma unroll
-    for (int u = 0; u < U; ++u) xv[u] = xvalid ? *(const u32x4*)(xr + (ks + u) * 32) : u32x4{0, 0, 0, 0};
+    for (int u = 0; u < U; ++u) xv[u] = load_x(ks + u);
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -242,7 +303,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const uint16_t*
         acc[j] = F::mfma(__builtin_bit_cast(VT, xv[u]), __builtin_bit_cast(VT, wv[u][j]), acc[j]);
   }
   for (int ks = ks0 + nfull * U; ks < ks1; ++ks) {
-    const u32x4 xv = xvalid ? *(const u32x4*)(xr + ks * 32) : u32x4{0, 0, 0, 0};
+    const u32x4 xv = load_x(ks);
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
       const u32x4 wv = __builtin_nontemporal_load((const u32x4*)(wr[j] + ks * 32));
@@ -257,6 +318,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const uint16_t*
     for (int r = 0; r < 4; ++r) slot[r] = acc[j][r];
   }
   __syncthreads();
+  float inv[4] = {1.f, 1.f, 1.f, 1.f};                  // per-row scale of the fused norm (rows 4 lg .. 4 lg + 3)
+  if constexpr (NORM) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) inv[r] = rsqrtf(s_ss[4 * lg + r] / (float)K + eps);
+  }
   if constexpr (SILU) {
     if (wk != 0) return;
     f32x4 g = {0.f, 0.f, 0.f, 0.f}, up = {0.f, 0.f, 0.f, 0.f};
@@ -272,8 +338,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const uint16_t*
     for (int r = 0; r < 4; ++r) {
       const int row = 4 * lg + r;
       // the separate kernels round gate and up to 16 bits first: do the same, then activate
-      const float gr = IS_BF16 ? (float)(__bf16)g[r] : (float)(_Float16)g[r];
-      const float ur = IS_BF16 ? (float)(__bf16)up[r] : (float)(_Float16)up[r];
+      const float gr = IS_BF16 ? (float)(__bf16)(g[r] * inv[r]) : (float)(_Float16)g[r];
+      const float ur = IS_BF16 ? (float)(__bf16)(up[r] * inv[r]) : (float)(_Float16)up[r];
       const float mine = gr / (1.f + __expf(-gr)) * ur;
       const float other = __shfl_xor(mine, 1);
       if (row < M && col < N && (li & 1) == 0) *(uint32_t*)(C + (long long)row * ldc + col) = F::pack2(mine, other);
@@ -293,7 +359,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const uint16_t*
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = 4 * lg + r;
-    const float mine = sum[r];
+    const float mine = sum[r] * inv[r];
     const float other = __shfl_xor(mine, 1);
     if (row < M && col < N && (li & 1) == 0) *(uint32_t*)(C + (long long)row * ldc + col) = F::pack2(mine, other);
   }
@@ -324,6 +390,48 @@ static void launch_skinny(const void* A, const void* B, void* C, int M, int N, i
     hipLaunchKernelGGL((gemm_nt_skinny_kernel<IS_BF16, 1, 8>), grid, dim3(512), 0, s, a, b, c, M, N, K, lda, ldb, ldc);
   else
     hipLaunchKernelGGL((gemm_nt_skinny_kernel<IS_BF16, 1, 4>), grid, dim3(256), 0, s, a, b, c, M, N, K, lda, ldb, ldc);
+}
+
+// C[M, N] = rmsnorm(X [+ R]) * G @ W^T for M <= 16, bf16 (see the NORM comment on the kernel); `silu` != 0: W is a
+// gate_up weight [2 N, K] and C = silu(gate) * up.  Hout [M, K] receives X + R when R is given.
+TDIST_API int tdist_gemm_nt_norm(const void* X, const void* R, const void* G, float eps, const void* W, void* C,
+                                 void* Hout, int M, int N, int K, long long ldx, long long ldw, long long ldc, int silu,
+                                 void* stream) {
+  TDIST_REQUIRE(M > 0 && M <= 16 && N > 0 && N % 2 == 0, "M must be in [1, 16], N even");
+  TDIST_REQUIRE(K >= 128 && K % 32 == 0, "K must be a multiple of 32 and >= 128");
+  TDIST_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && ldc % 2 == 0, "row strides must keep the vector alignment");
+  TDIST_REQUIRE((((uintptr_t)X | (uintptr_t)W | (uintptr_t)G | (uintptr_t)R | (uintptr_t)Hout) & 15) == 0 &&
+                    (((uintptr_t)C) & 3) == 0, "operands must be aligned");
+  TDIST_REQUIRE(G != nullptr && (R == nullptr || (Hout != nullptr && Hout != X && Hout != R)),
+                "norm weight required; the residual output must be a buffer of its own");
+  const uint16_t *x = (const uint16_t*)X, *w = (const uint16_t*)W, *r = (const uint16_t*)R, *g = (const uint16_t*)G;
+  uint16_t *c = (uint16_t*)C, *h = (uint16_t*)Hout;
+  hipStream_t s = (hipStream_t)stream;
+  const long long lds = (long long)M * ((long long)K * 2 + 64);       // normalised activations of the M rows
+  TDIST_REQUIRE(lds <= 48 * 1024, "fused norm: M x K too large for the activation buffer in LDS");
+  if (silu) {
+    hipLaunchKernelGGL((gemm_nt_skinny_kernel<true, 2, 4, true, true>), dim3((N + 15) / 16), dim3(256), (size_t)lds, s, x, w,
+                       c, M, N, K, ldx, ldw, ldc, r, g, h, eps);
+  } else {
+    // same column-block rule as launch_skinny
+    int bn = M <= 4 ? (N >= 16384 ? 32 : 16) : (N >= 32768 ? 64 : (N >= 6144 ? 32 : 16));
+    const dim3 grid((N + bn - 1) / bn);
+    const bool wide = bn == 16 && grid.x < 1024 && K >= 4096;
+    if (bn == 64)
+      hipLaunchKernelGGL((gemm_nt_skinny_kernel<true, 4, 4, false, true>), grid, dim3(256), (size_t)lds, s, x, w, c, M, N, K, ldx,
+                         ldw, ldc, r, g, h, eps);
+    else if (bn == 32)
+      hipLaunchKernelGGL((gemm_nt_skinny_kernel<true, 2, 4, false, true>), grid, dim3(256), (size_t)lds, s, x, w, c, M, N, K, ldx,
+                         ldw, ldc, r, g, h, eps);
+    else if (wide)
+      hipLaunchKernelGGL((gemm_nt_skinny_kernel<true, 1, 8, false, true>), grid, dim3(512), (size_t)lds, s, x, w, c, M, N, K, ldx,
+                         ldw, ldc, r, g, h, eps);
+    else
+      hipLaunchKernelGGL((gemm_nt_skinny_kernel<true, 1, 4, false, true>), grid, dim3(256), (size_t)lds, s, x, w, c, M, N, K, ldx,
+                         ldw, ldc, r, g, h, eps);
+  }
+  TDIST_HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 // C[M, I] = silu(X W[0:I]^T) * (X W[I:2I]^T) for M <= 16 (W = gate_up weight [2 I, K], bf16 only).

@@ -15,7 +15,8 @@ from ..ops.allreduce import AllReduceMethod, all_reduce, create_allreduce_ctx
 from ..ops.flash_attn import flash_attn_with_kvcache
 from ..ops.gemm_rs import create_gemm_rs_intra_node_context, gemm_rs_intra_node
 from ..utils.distributed import get_env
-from .tp_mlp import _linear, shard_local
+from ..ops.gemm import gemm_nt_norm, norm_gemm_supported
+from .tp_mlp import _linear, prenorm_generic, shard_local
 
 
 def layer_norm(hidden_states: torch.Tensor, eps: float, w: torch.Tensor) -> torch.Tensor:
@@ -164,8 +165,9 @@ class TP_Attn:
         return out.view(bsz, q_len, -1)
 
     @torch.inference_mode()
-    def dist_triton_AR_fwd(self, x, position_ids, cos_sin_cache, kv_cache, layer_idx: int):
-        qkv = _linear(x, self.wqkv)
+    def dist_triton_AR_fwd(self, x, position_ids, cos_sin_cache, kv_cache, layer_idx: int, qkv=None):
+        """``qkv``: the projection when the caller has computed it already (``fwd_prenorm``; x then only gives the shape)."""
+        qkv = _linear(x, self.wqkv) if qkv is None else qkv
         out = self._attend(qkv, position_ids, cos_sin_cache, kv_cache, layer_idx)
         out = _linear(out, self.wo)
         if self.world_size > 1:
@@ -174,9 +176,9 @@ class TP_Attn:
         return out.view_as(x)
 
     @torch.inference_mode()
-    def dist_triton_gemm_ar_fwd(self, x, position_ids, cos_sin_cache, kv_cache, layer_idx: int):
+    def dist_triton_gemm_ar_fwd(self, x, position_ids, cos_sin_cache, kv_cache, layer_idx: int, qkv=None):
         bsz, q_len, _ = x.shape
-        qkv = _linear(x, self.wqkv)
+        qkv = _linear(x, self.wqkv) if qkv is None else qkv
         out = self._attend(qkv, position_ids, cos_sin_cache, kv_cache, layer_idx)
         assert self.gemm_ar_ctx is not None, "GemmAR context is not initialized."
         out = self.gemm_ar_ctx.forward(out.reshape(bsz * q_len, -1), self.wo)
@@ -184,3 +186,19 @@ class TP_Attn:
 
     def fwd(self, x, position_ids, cos_sin_cache, kv_cache, layer_idx: int):
         raise NotImplementedError("Please use torch_fwd or dist_triton_fwd instead.")
+
+    @torch.inference_mode()
+    def fwd_prenorm(self, x, residual, norm_w, eps, position_ids, cos_sin_cache, kv_cache, layer_idx: int):
+        """RMSNorm(x [+ residual]) -> this block: (block output, x + residual).  Decode-sized inputs of the modes
+        whose QKV projection is a local GEMM run the norm inside that GEMM's launch (``gemm_nt_norm``)."""
+        fn = getattr(self.fwd, "__func__", None)
+        if fn in (TP_Attn.dist_triton_AR_fwd, TP_Attn.dist_triton_gemm_ar_fwd):
+            x2 = x.reshape(-1, x.shape[-1])
+            r2 = residual.reshape(x2.shape) if residual is not None else None
+            if norm_gemm_supported(x2, self.wqkv, norm_w, r2):
+                qkv, hidden = gemm_nt_norm(x2, norm_w, eps, self.wqkv, residual=r2)
+                shape = residual.shape if residual is not None else x.shape
+                out = self.fwd(x.reshape(shape), position_ids, cos_sin_cache, kv_cache, layer_idx,
+                               qkv=qkv.view(*shape[:-1], -1))
+                return out, hidden.view(shape)
+        return prenorm_generic(self, x, residual, norm_w, eps, position_ids, cos_sin_cache, kv_cache, layer_idx)

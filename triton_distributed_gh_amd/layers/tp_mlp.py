@@ -17,7 +17,7 @@ import torch
 from ..ops import elementwise
 from ..ops.ag_gemm import ag_gemm_intra_node, create_ag_gemm_intra_node_context
 from ..ops.allreduce import AllReduceMethod, all_reduce, create_allreduce_ctx
-from ..ops.gemm import gemm_nt, gemm_nt_silu_mul
+from ..ops.gemm import gemm_nt, gemm_nt_norm, gemm_nt_silu_mul, norm_gemm_supported
 from ..ops.gemm_rs import create_gemm_rs_intra_node_context, gemm_rs_intra_node
 from ..utils.distributed import get_env
 
@@ -33,6 +33,14 @@ def shard_local(tensor: torch.Tensor, world_size: int, dim: int, local_rank: int
     if rem != 0 or per == 0:
         raise ValueError(f"shard_local: cannot cut {n} entries of dim {dim} into {world_size} equal non-empty shards")
     return tensor.narrow(dim, local_rank * per, per).contiguous()
+
+
+def prenorm_generic(layer, x, residual, norm_w, eps, *args):
+    """RMSNorm of ``x`` (+ ``residual``) as its own kernel, then ``layer.fwd``: -> (block output, x + residual)."""
+    if residual is None:
+        return layer.fwd(elementwise.rms_norm(x, norm_w, eps), *args), x
+    y, hidden = elementwise.rms_norm(x.reshape(residual.shape), norm_w, eps, residual=residual)
+    return layer.fwd(y, *args), hidden
 
 
 def _linear(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
@@ -150,9 +158,10 @@ class TP_MLP:
         return out.view(*shape[:-1], -1)
 
     @torch.inference_mode()
-    def dist_triton_AR_fwd(self, x):
-        """x replicated [M, H]; GEMMs are local, the sum runs on the symmetric-memory all-reduce."""
-        out = self._gate_up_act(x)
+    def dist_triton_AR_fwd(self, x, act=None):
+        """x replicated [M, H]; GEMMs are local, the sum runs on the symmetric-memory all-reduce.  ``act``: the
+        activated gate / up product when the caller has computed it already (``fwd_prenorm``)."""
+        out = self._gate_up_act(x) if act is None else act
         out = _linear(out, self.down_proj)
         if self.world_size > 1:
             assert self.ar_ctx is not None, "AllReduce context is not initialized."
@@ -160,17 +169,31 @@ class TP_MLP:
         return out.view_as(x)
 
     @torch.inference_mode()
-    def dist_triton_gemm_ar_fwd(self, x):
+    def dist_triton_gemm_ar_fwd(self, x, act=None):
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
         assert self.gemm_ar_ctx is not None, "GemmAR context is not initialized."
-        out = self._act(_linear(x2, self.gate_up_proj))
+        out = self._act(_linear(x2, self.gate_up_proj)) if act is None else act.reshape(x2.shape[0], -1)
         out = self.gemm_ar_ctx.forward(out, self.down_proj)
         return out.view(*shape[:-1], -1)
 
     @torch.inference_mode()
     def fwd(self, x: torch.Tensor):
         raise NotImplementedError("Please use torch_fwd or dist_triton_fwd instead.")
+
+    @torch.inference_mode()
+    def fwd_prenorm(self, x, residual, norm_w, eps):
+        """RMSNorm(x [+ residual]) -> this block: (block output, x + residual).  Decode-sized inputs of the modes
+        whose first projection is a local GEMM run the norm inside that GEMM's launch (``gemm_nt_norm``)."""
+        fn = getattr(self.fwd, "__func__", None)
+        if fn in (TP_MLP.dist_triton_AR_fwd, TP_MLP.dist_triton_gemm_ar_fwd) and self._is_silu():
+            x2 = x.reshape(-1, x.shape[-1])
+            r2 = residual.reshape(x2.shape) if residual is not None else None
+            if norm_gemm_supported(x2, self.gate_up_proj, norm_w, r2):
+                act, hidden = gemm_nt_norm(x2, norm_w, eps, self.gate_up_proj, residual=r2, silu=True)
+                shape = residual.shape if residual is not None else x.shape
+                return self.fwd(x.reshape(shape), act=act.view(*shape[:-1], -1)), hidden.view(shape)
+        return prenorm_generic(self, x, residual, norm_w, eps)
 
     # ---- single-op helpers (used by the per-op tests / benchmarks) --------------------------------
     @torch.inference_mode()

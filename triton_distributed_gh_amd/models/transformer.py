@@ -72,13 +72,19 @@ class DecoderLayer:
     def fwd_fused(self, hidden, delta, position_ids, cos_sin_cache, kv_cache):
         """``hidden + delta`` is the block input (``delta`` None for the first block).  Returns the
         new (hidden, delta) pair so the next block's norm can absorb the pending add."""
+        # (the norms travel with the blocks: decode-sized inputs fold them into the first projection's launch)
         if delta is None:
-            x = elementwise.rms_norm(hidden, self.input_norm_w, self.input_norm_eps)
+            a, hidden = self.attn.fwd_prenorm(hidden, None, self.input_norm_w, self.input_norm_eps, position_ids,
+                                              cos_sin_cache, kv_cache, self.layer_idx)
         else:
-            x, hidden = elementwise.rms_norm(delta, self.input_norm_w, self.input_norm_eps, residual=hidden)
-        a = self.attn.fwd(x, position_ids, cos_sin_cache, kv_cache, self.layer_idx)
-        x, hidden = elementwise.rms_norm(a, self.post_norm_w, self.post_norm_eps, residual=hidden)
-        return hidden, self.mlp.fwd(x)
+            a, hidden = self.attn.fwd_prenorm(delta, hidden, self.input_norm_w, self.input_norm_eps, position_ids,
+                                              cos_sin_cache, kv_cache, self.layer_idx)
+        if hasattr(self.mlp, "fwd_prenorm"):
+            m, hidden = self.mlp.fwd_prenorm(a, hidden, self.post_norm_w, self.post_norm_eps)
+        else:
+            x, hidden = elementwise.rms_norm(a, self.post_norm_w, self.post_norm_eps, residual=hidden)
+            m = self.mlp.fwd(x)
+        return hidden, m
 
     @torch.inference_mode()
     def fwd(self, hidden_states, position_ids, cos_sin_cache, kv_cache):

@@ -252,3 +252,43 @@ def gemm_nt_silu_mul(a: torch.Tensor, gate_up: torch.Tensor) -> torch.Tensor:
         return out
     from .elementwise import silu_mul
     return silu_mul(gemm_nt(a, gate_up))
+
+
+def norm_gemm_supported(x: torch.Tensor, w: torch.Tensor, norm_w: torch.Tensor, residual: Optional[torch.Tensor]) -> bool:
+    """Shapes the decode GEMM takes with the RMSNorm folded in: at most 16 rows, bf16, the rows' normalised copy
+    (M x (2 K + 64) bytes) within 48 KiB of LDS."""
+    M, K = x.shape
+    return (x.is_cuda and M <= 16 and x.dtype == torch.bfloat16 == w.dtype == norm_w.dtype and gemm_supported(x, w)
+            and K % 32 == 0 and K >= 128 and M * (2 * K + 64) <= 48 * 1024 and norm_w.is_contiguous()
+            and (residual is None or (residual.dtype == x.dtype and residual.shape == x.shape)))
+
+
+def gemm_nt_norm(x: torch.Tensor, norm_w: torch.Tensor, eps: float, w: torch.Tensor,
+                 residual: Optional[torch.Tensor] = None, silu: bool = False):
+    """``rmsnorm(x [+ residual]) * norm_w @ w^T`` -> (out, hidden) with hidden = x + residual (or x).
+    ``silu``: ``w`` is a gate_up weight [2 I, K] and out = silu(gate) * up [M, I].
+
+    Decode-sized bf16 inputs run ONE launch (the weight-streaming GEMM computes the norm from the fragments it
+    loads anyway: csrc/ops/gemm.hip, NORM); everything else is the norm kernel followed by the GEMM.  In the fused
+    form the MFMAs see bf16(h * norm_w) and the row scale is applied in fp32 afterwards, so results differ from the
+    two-kernel form by bf16 rounding order only."""
+    from .elementwise import rms_norm
+
+    M, K = x.shape
+    N = w.shape[0] // (2 if silu else 1)
+    if norm_gemm_supported(x, w, norm_w, residual) and N % 2 == 0 and x.stride(1) == 1:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+        res = residual.contiguous() if residual is not None else None
+        hidden = torch.empty((M, K), dtype=x.dtype, device=x.device) if res is not None else x
+        _lib.check(
+            _lib.hip().tdist_gemm_nt_norm(_lib.ptr(x), _lib.ptr(res), _lib.ptr(norm_w), ctypes.c_float(eps), _lib.ptr(w),
+                                          _lib.ptr(out), _lib.ptr(hidden) if res is not None else ctypes.c_void_p(0), M, N, K,
+                                          ctypes.c_longlong(x.stride(0)), ctypes.c_longlong(w.stride(0)),
+                                          ctypes.c_longlong(out.stride(0)), 1 if silu else 0, _lib.stream_handle()),
+            "tdist_gemm_nt_norm")
+        return out, hidden
+    if residual is not None:
+        y, hidden = rms_norm(x, norm_w, eps, residual=residual)
+    else:
+        y, hidden = rms_norm(x, norm_w, eps), x
+    return (gemm_nt_silu_mul(y, w) if silu else gemm_nt(y, w)), hidden
