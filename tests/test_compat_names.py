@@ -283,3 +283,36 @@ def test_qwen3_layer_builder_records_a_layer():
     assert names[0] == "l0.norm1" and names[-1] == "l0.residual" and "l0.attn_split" in names and "l0.fc1" in names
     check_schedule(round_robin_scheduler(b.build_tasks(), 16))
     assert lb.post_norm_eps == 1e-5
+
+
+@pytest.mark.parametrize("zigzag", [True, False])
+def test_copy_engine_kv_all_gather_places_every_shard(zigzag):
+    """Every rank's K / V shard rows land at their place of the full per-sequence K / V of every peer
+    (zig-zag: half-shards at slabs r and 2w-1-r of 2w), checked against a directly built full tensor."""
+    from triton_dist.kernels.nvidia.sp_ag_attention_intra_node import cp_engine_producer_kv_all_gather
+
+    w, H, D = 2, 2, 8
+    full_lens = [16, 32]
+    cu = [0, 16, 48]
+    full_k = [torch.randn(L, H, D) for L in full_lens]
+    full_v = [torch.randn(L, H, D) for L in full_lens]
+
+    def shard(full, r):
+        rows = []
+        for t in full:
+            L = t.shape[0]
+            if zigzag:
+                h = L // (2 * w)
+                rows += [t[r * h:(r + 1) * h], t[(2 * w - 1 - r) * h:(2 * w - r) * h]]
+            else:
+                s = L // w
+                rows.append(t[r * s:(r + 1) * s])
+        return torch.cat(rows)
+
+    kb = [torch.zeros(sum(full_lens), H, D) for _ in range(w)]
+    vb = [torch.zeros(sum(full_lens), H, D) for _ in range(w)]
+    for r in range(w):
+        cp_engine_producer_kv_all_gather(shard(full_k, r), shard(full_v, r), kb[r], vb[r], kb, vb, torch.tensor(cu), r, w,
+                                         enable_zig_zag=zigzag)
+    for r in range(w):
+        assert torch.equal(kb[r], torch.cat(full_k)) and torch.equal(vb[r], torch.cat(full_v))
