@@ -3,7 +3,7 @@
 One step = one tensor-parallel MLP-style pair on every rank:
     AG-GEMM : C1[M, N/w] = AllGather_M(A1[M/w, K]) @ W1[N/w, K]^T
     GEMM-RS : C2[M/w, N] = ReduceScatter_M(A2[M, K/w] @ W2[N, K/w]^T)
-with M=4096, N=K=8192 (the shape BASELINE.json names; total work is fixed -> strong scaling).
+with M=4096, N=K=8192 (the headline shape; total work is fixed as the GPU count grows -> strong scaling).
 `value` is the per-step latency in microseconds (AG-GEMM + GEMM-RS, max over ranks); the two ops
 are also timed separately, and the same pair built from torch.matmul + RCCL collectives is timed in
 the same process as the yardstick the reference uses (reference:
