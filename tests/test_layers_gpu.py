@@ -451,3 +451,38 @@ def test_engine_graph_decode_matches_eager():
     eng.no_graph = False
     graphed = eng.serve(prompt, gen_len=8)
     assert torch.equal(eager, graphed)
+
+
+def test_decode_blocks_fold_their_norm(monkeypatch):
+    """A decode step in the modes whose first projections are local GEMMs calls the fused norm + GEMM once per
+    attention block and once per MLP block (no separate norm launch), prefill keeps the separate kernels, and the
+    logits match the torch mode."""
+    from triton_distributed_gh_amd.layers import tp_attn, tp_mlp
+
+    calls = {"attn": 0, "mlp": 0}
+    real = tp_attn.gemm_nt_norm
+
+    def spy(kind):
+        def f(*a, **k):
+            calls[kind] += 1
+            return real(*a, **k)
+        return f
+
+    monkeypatch.setattr(tp_attn, "gemm_nt_norm", spy("attn"))
+    monkeypatch.setattr(tp_mlp, "gemm_nt_norm", spy("mlp"))
+    bsz, prompt, L = 2, 16, 128
+    torch.manual_seed(11)
+    m = AutoLLM.from_pretrained(ModelConfig(model_name="tdist/tiny-dense", max_length=L, dtype=BF, rank=0, world_size=1))
+    ids = torch.randint(0, 1000, (bsz, prompt), device="cuda")
+    pos = torch.arange(prompt, device="cuda")[None].repeat(bsz, 1)
+    outs = {}
+    for mode in ("torch", "triton_dist_AR"):
+        m.set_fwd(mode)
+        kv = KV_Cache(m.num_layers, bsz, L, m.num_key_value_heads, m.head_dim, BF, 1)
+        first = m.inference(ids, pos, kv)
+        assert calls == {"attn": 0, "mlp": 0}, "prefill-sized inputs keep the norm kernel"
+        kv.kv_offset.fill_(prompt)
+        tok = first[:, -1].argmax(-1, keepdim=True)
+        outs[mode] = m.inference(tok, kv.get_kv_len()[:, None].long(), kv)
+    assert calls == {"attn": m.num_layers, "mlp": m.num_layers}, calls
+    assert _rel(outs["triton_dist_AR"], outs["torch"]) < 5e-2
