@@ -205,6 +205,58 @@ def test_qkv_prep_matches_separate_kernels(B, S, Hq, Hkv, D, norm):
     assert torch.equal(kc == 0, kc_ref == 0) or (kc != 0).sum() == (kc_ref != 0).sum()
 
 
+@pytest.mark.parametrize("B,Hq,Hkv,max_len,norm,splits", [
+    (1, 32, 8, 1024, True, -1), (1, 32, 8, 1024, True, 1), (4, 32, 8, 512, True, 3), (2, 8, 1, 1000, False, 2),
+    (3, 64, 2, 256, True, -1), (2, 4, 4, 16, True, 1), (64, 32, 8, 2048, True, -1)])
+def test_decode_step_from_qkv_matches_prep_then_attention(B, Hq, Hkv, max_len, norm, splits):
+    """The attention kernel that norms, rotates and appends the new token itself, against the two launches it
+    replaces (qkv_prep, then split-KV decode) and against an fp32 reference, at cache lengths around every block
+    edge.  Unwritten cache slots hold NaN: nothing outside the attended tokens may reach the result."""
+    from triton_distributed_gh_amd.ops import elementwise, flash_decode
+
+    torch.manual_seed(B * 1000 + Hq * 10 + Hkv)
+    dev, bf, D = "cuda", torch.bfloat16, 128
+    W = (Hq + 2 * Hkv) * D
+    qw = (torch.rand(D, device=dev) + 0.5).to(bf) if norm else None
+    kw = (torch.rand(D, device=dev) + 0.5).to(bf) if norm else None
+    cos, sin = elementwise.rope_cache(max_len + 8, D, device=dev)
+    edge = [0, 1, 15, 16, 30, 31, 32, 33, 63, 64, 127, 128, 129, 255, 256, 511, max_len - 2, max_len - 1]
+    edge = [e for e in edge if e < max_len]
+    for it in range(4):
+        offs = torch.tensor([edge[(it * 5 + 3 * b) % len(edge)] for b in range(B)], dtype=torch.int32, device=dev)
+        pos = (offs.long() + 2)[:, None]                           # rotary position need not equal the slot
+        big = (torch.rand(B, 1, W + 64, device=dev) * 2 - 1).to(bf)
+        qkv = big[:, :, :W]                                        # strided rows
+        kc = torch.full((B, max_len, Hkv, D), float("nan"), device=dev, dtype=bf)
+        vc = torch.full_like(kc, float("nan"))
+        for b in range(B):
+            n = int(offs[b])
+            kc[b, :n] = (torch.randn(n, Hkv, D, device=dev) * 0.5).to(bf)
+            vc[b, :n] = torch.randn(n, Hkv, D, device=dev).to(bf)
+        kc2, vc2 = kc.clone(), vc.clone()
+        total, total2 = torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)
+        assert flash_decode.decode_step_from_qkv_supported(qkv, kc, vc, D, cos)
+        out = flash_decode.decode_step_from_qkv(qkv, qw, kw, 1e-6, 1e-6, pos, cos, sin, kc, vc, offs, total, Hq, Hkv,
+                                                kv_split=splits)
+        # the two launches
+        q2 = elementwise.qkv_prep(qkv, qw, kw, 1e-6, 1e-6, pos, cos, sin, kc2, vc2, offs, total2, Hq, Hkv, D)
+        table = torch.arange(B, dtype=torch.int32, device=dev).view(B, 1)
+        out2 = flash_decode.gqa_fwd_batch_decode_persistent(q2[:, 0], kc2, vc2, None, None, total2, table, D ** -0.5,
+                                                            kv_split=splits)
+        assert torch.equal(total, offs + 1) and torch.equal(total, total2)
+        for b in range(B):
+            n = int(offs[b])
+            assert torch.equal(vc[b, :n + 1], vc2[b, :n + 1]), "V rows (old ones untouched, new one appended)"
+            assert torch.equal(kc[b, :n], kc2[b, :n]), "old K rows untouched"
+            assert (kc[b, n].float() - kc2[b, n].float()).abs().max().item() <= 2e-2
+            assert torch.isnan(kc[b, n + 1:].float()).all() and torch.isnan(vc[b, n + 1:].float()).all(), \
+                "nothing written past the new token"
+        ref = flash_decode.decode_reference(q2[:, 0], kc2, vc2, total2, table, D ** -0.5)
+        assert torch.isfinite(out.float()).all()
+        assert (out.float() - out2.float()).abs().max().item() <= 2e-2
+        assert (out.float() - ref).abs().max().item() <= 2e-2
+
+
 def test_attention_running_max_covers_every_lane_group():
     """One key far above the rest, placed at every position of a 32-token block in turn: the running maximum
     must be the maximum over ALL lane groups of the wave.  With a maximum taken from one group only, a

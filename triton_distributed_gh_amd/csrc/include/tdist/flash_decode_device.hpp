@@ -36,6 +36,18 @@ struct DecodeArgs {
   int p16;                    // 1: partial rows in the 16-bit type of q (the reference's *_fp16_fp16_fp16 kernels)
   int deep;                   // 1: two register sets (loads one block ahead): throughput launches, many workgroups per CU
   float sm_scale, soft_cap;
+  // PREP (decode_split_body<..., PREP>): the step's Q / K / V come straight from the QKV projection
+  const uint16_t* qkv = nullptr;   // [batch, qkv_stride]: q heads, then k heads, then v heads of the new token
+  long long qkv_stride = 0;
+  const uint16_t* q_w = nullptr;   // per-head RMSNorm weights [D] (null: no norm)
+  const uint16_t* k_w = nullptr;
+  float q_eps = 0.f, k_eps = 0.f;
+  const long long* pos = nullptr;  // [batch] rotary position of the new token
+  const float* cos_t = nullptr;    // [positions, D / 2]
+  const float* sin_t = nullptr;
+  const int* kv_offset = nullptr;  // [batch] tokens in the cache before this step
+  int* total_out = nullptr;        // [batch] <- kv_offset + 1
+  long long max_slots = 0;         // slots per sequence (a full cache drops the new token instead of writing outside)
 };
 
 __device__ __forceinline__ long long slot_of(const DecodeArgs& a, const int* table, int tok) {
@@ -158,12 +170,72 @@ __device__ __forceinline__ void merge_rows(const void* part_, long long stride, 
   }
 }
 
+// One head of the new token, D = 128, as the lane (k-group lg) of an MFMA operand holds it: elements 32 s + 8 lg + j,
+// s = 0..3.  Optional RMSNorm over the head (the four lanes lg of one row hold all of it: two shuffles), rounded to
+// bf16 like the stand-alone kernel, then the neox rotation, whose pairs (e, e + 64) are chunks s and s + 2 of the
+// SAME lane.  `src` / `w` already point at element 8 lg; `cs` / `sn` at [position][8 lg].
+__device__ __forceinline__ void prep_head_d128(const uint16_t* src, bool valid, const uint16_t* w, float eps, const float* cs,
+                                               const float* sn, uint4 (&out)[4]) {
+  float x[4][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    uint4 v = uint4{0, 0, 0, 0};
+    if (valid) v = *(const uint4*)(src + 32 * s);
+    const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      x[s][2 * i] = __builtin_bit_cast(float, u[i] << 16);
+      x[s][2 * i + 1] = __builtin_bit_cast(float, u[i] & 0xffff0000u);
+      ss += x[s][2 * i] * x[s][2 * i] + x[s][2 * i + 1] * x[s][2 * i + 1];
+    }
+  }
+  if (w) {
+    ss += __shfl_xor(ss, 16);
+    ss += __shfl_xor(ss, 32);
+    const float inv = rsqrtf(ss / 128.f + eps);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const uint4 wv = *(const uint4*)(w + 32 * s);
+      const uint32_t u[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        x[s][2 * i] = (float)(__bf16)(x[s][2 * i] * inv * __builtin_bit_cast(float, u[i] << 16));
+        x[s][2 * i + 1] = (float)(__bf16)(x[s][2 * i + 1] * inv * __builtin_bit_cast(float, u[i] & 0xffff0000u));
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    float co[8], si[8];
+    *(float4*)co = *(const float4*)(cs + 32 * s);
+    *(float4*)(co + 4) = *(const float4*)(cs + 32 * s + 4);
+    *(float4*)si = *(const float4*)(sn + 32 * s);
+    *(float4*)(si + 4) = *(const float4*)(sn + 32 * s + 4);
+    uint32_t lo[4], hi[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float a0 = x[s][2 * i], a1 = x[s][2 * i + 1], c0 = x[s + 2][2 * i], c1 = x[s + 2][2 * i + 1];
+      lo[i] = Frag<true>::pack2(a0 * co[2 * i] - c0 * si[2 * i], a1 * co[2 * i + 1] - c1 * si[2 * i + 1]);
+      hi[i] = Frag<true>::pack2(c0 * co[2 * i] + a0 * si[2 * i], c1 * co[2 * i + 1] + a1 * si[2 * i + 1]);
+    }
+    out[s] = uint4{lo[0], lo[1], lo[2], lo[3]};
+    out[s + 2] = uint4{hi[0], hi[1], hi[2], hi[3]};
+  }
+}
+
 // Split-KV body for work item (batch b, head block by, split z); writes the normalised partial row
 // (+ LSE) of every head of the block.  `smem` needs (128 + 64 * D) floats; 256 threads.
 // ALLOW_DEEP = false compiles the single-register-set loop only (the mega kernel: its task interpreter must
 // keep two workgroups per CU resident, and the second set costs 56 VGPRs).
-template <bool IS_BF16, int D, bool ALLOW_DEEP = true>
+//
+// PREP (bf16, D = 128, one new token per sequence, whole-sequence pages): the kernel replaces the launch between
+// the QKV projection and the attention - every workgroup norms and rotates its own query heads out of `qkv`, the
+// one wave whose 32-token block holds the new position norms and rotates the new K row, takes K / V of that token
+// from registers instead of the cache and (head block 0) appends them to the cache for the steps to come.
+template <bool IS_BF16, int D, bool ALLOW_DEEP = true, bool PREP = false>
 __device__ __forceinline__ void decode_split_body(const DecodeArgs& a, const int b, const int by, const int z, char* smem) {
+  static_assert(!PREP || (IS_BF16 && D == 128), "the fused projection epilogue is built for bf16, head_dim 128");
   using F = Frag<IS_BF16>;
   using VT = typename F::T;
   constexpr int KS = D / 32;    // MFMA k-steps over the head dim for S
@@ -187,7 +259,13 @@ __device__ __forceinline__ void decode_split_body(const DecodeArgs& a, const int
   const int li = lane & 15;   // head (S / O column), token row of K operand, dv column of V operand
   const int lg = lane >> 4;   // k-group
 
-  const int kv_len = a.kv_len[b];
+  int kv_len;
+  if constexpr (PREP) {
+    kv_len = a.kv_offset[b] + 1;
+    if (by == 0 && z == 0 && threadIdx.x == 0) a.total_out[b] = kv_len;
+  } else {
+    kv_len = a.kv_len[b];
+  }
   const int per = (((kv_len + a.splits - 1) / a.splits) + 31) & ~31;
   const int start = z * per;
   const int end = min(start + per, kv_len);
@@ -195,7 +273,14 @@ __device__ __forceinline__ void decode_split_body(const DecodeArgs& a, const int
 
   // Q operand: lane (head li, k-group lg) holds Q[h0 + li][32 s + 8 lg .. +8]
   VT qreg[KS];
-  {
+  if constexpr (PREP) {
+    const long long p = a.pos[b];
+    uint4 qv[4];
+    prep_head_d128(a.qkv + b * a.qkv_stride + (long long)(h0 + li) * D + lg * 8, li < valid_h, a.q_w ? a.q_w + lg * 8 : nullptr,
+                   a.q_eps, a.cos_t + p * (D / 2) + lg * 8, a.sin_t + p * (D / 2) + lg * 8, qv);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qreg[s] = __builtin_bit_cast(VT, qv[s]);
+  } else {
     const uint16_t* qp = a.q + b * a.q_stride_b + (long long)(h0 + li) * a.q_stride_h + lg * 8;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -252,6 +337,42 @@ __device__ __forceinline__ void decode_split_body(const DecodeArgs& a, const int
       } else {
         const uint2 v = *(const uint2*)vp;
         r.v[t][0] = v.x, r.v[t][1] = v.y;
+      }
+    }
+    if constexpr (PREP) {
+      const int last = kv_len - 1;
+      if (n0 <= last && last < n0 + 32) {                  // wave-uniform: this block holds the new token
+        const int rel = last - n0;
+        const long long p = a.pos[b];
+        const uint16_t* tok_qkv = a.qkv + b * a.qkv_stride;
+        uint4 kn[4];
+        prep_head_d128(tok_qkv + (long long)(a.q_heads + kvh) * D + lg * 8, true, a.k_w ? a.k_w + lg * 8 : nullptr, a.k_eps,
+                       a.cos_t + p * (D / 2) + lg * 8, a.sin_t + p * (D / 2) + lg * 8, kn);
+        const uint4 vn = *(const uint4*)(tok_qkv + (long long)(a.q_heads + a.kv_heads + kvh) * D + li * NDV);
+        // every row clamped to the new token takes the register copy: its cache slot is not written yet, and
+        // whatever it holds (a NaN would survive the zero probability of a masked row) must not reach the MFMAs
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+          if (n0 + 16 * blk + li >= last) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) r.k[blk][s] = kn[s];
+          }
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          if (n0 + 16 * (t >> 2) + 4 * lg + (t & 3) >= last) {
+            r.v[t][0] = vn.x, r.v[t][1] = vn.y, r.v[t][2] = vn.z, r.v[t][3] = vn.w;
+          }
+        // append to the cache for the steps to come (one head block does it; a full cache drops the token)
+        if (hblk == 0 && last < a.max_slots) {
+          const long long slot = one_page ? slot0 + rel : slot_of(a, table, last);
+          if (li == 0) {
+            uint16_t* kd = const_cast<uint16_t*>(a.k_cache) + slot * a.k_stride_slot + (long long)kvh * a.k_stride_h + lg * 8;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) *(uint4*)(kd + 32 * s) = kn[s];
+          }
+          if (lg == 0)
+            *(uint4*)(const_cast<uint16_t*>(a.v_cache) + slot * a.v_stride_slot + (long long)kvh * a.v_stride_h + li * NDV) = vn;
+        }
       }
     }
   };

@@ -28,7 +28,7 @@ namespace {
 
 using namespace tdist::fdec;
 
-template <bool IS_BF16, int D>
+template <bool IS_BF16, int D, bool PREP = false>
 __global__ __launch_bounds__(256) void decode_split_kernel(DecodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int s_last;
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void decode_split_kernel(DecodeArgs a) {
   const int hblk = blockIdx.y - kvh * hblocks;
   const int h0 = kvh * group + hblk * 16;
   const int valid_h = min(16, group - hblk * 16);
-  decode_split_body<IS_BF16, D>(a, b, (int)blockIdx.y, (int)blockIdx.z, smem);
+  decode_split_body<IS_BF16, D, true, PREP>(a, b, (int)blockIdx.y, (int)blockIdx.z, smem);
 
   if (!a.fused || (a.fused == 1 && a.splits == 1)) return;
   if (a.p16) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // 16-bit rows went out as plain stores
@@ -91,21 +91,32 @@ __global__ __launch_bounds__(64) void decode_combine_kernel(const void* part, lo
   merge_rows<IS_BF16, P16>(p, p_stride_n, n, D, lens ? lens + b : nullptr, lens_stride, o, out_mode, threadIdx.x, 64);
 }
 
-template <bool IS_BF16, int D>
+template <bool IS_BF16, int D, bool PREP = false>
 hipError_t launch_split(const DecodeArgs& a, int batch, hipStream_t st) {
   const int group = a.q_heads / a.kv_heads;
   const int hblocks = (group + 15) / 16;
   const size_t lds = (128 + 64 * D) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    const hipError_t e = hipFuncSetAttribute((const void*)decode_split_kernel<IS_BF16, D>,
+    const hipError_t e = hipFuncSetAttribute((const void*)decode_split_kernel<IS_BF16, D, PREP>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((decode_split_kernel<IS_BF16, D>), dim3(batch, a.kv_heads * hblocks, a.splits), dim3(256),
+  hipLaunchKernelGGL((decode_split_kernel<IS_BF16, D, PREP>), dim3(batch, a.kv_heads * hblocks, a.splits), dim3(256),
                      lds, st, a);
   return hipGetLastError();
+}
+
+int num_cus_cached() {
+  static int num_cus = 0;
+  if (!num_cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      num_cus = 256;
+  }
+  return num_cus;
 }
 
 }  // namespace
@@ -144,14 +155,8 @@ TDIST_API int tdist_flash_decode_split(const void* q, const void* k_cache, const
   TDIST_REQUIRE(fused >= 0 && fused <= 3, "fused must be 0..3");
   a.sm_scale = sm_scale, a.soft_cap = soft_cap;
   {
-    static int num_cus = 0;
-    if (!num_cus) {
-      int dev = 0;
-      TDIST_HIP_TRY(hipGetDevice(&dev));
-      TDIST_HIP_TRY(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
-    }
     const int hblocks = (q_heads / kv_heads + 15) / 16;
-    a.deep = (long long)batch * kv_heads * hblocks * splits > 2ll * num_cus ? 1 : 0;
+    a.deep = (long long)batch * kv_heads * hblocks * splits > 2ll * num_cus_cached() ? 1 : 0;
   }
   hipStream_t st = (hipStream_t)stream;
   const bool bf = dtype == 0;
@@ -160,6 +165,50 @@ TDIST_API int tdist_flash_decode_split(const void* q, const void* k_cache, const
   else if (head_dim == 128) e = bf ? launch_split<true, 128>(a, batch, st) : launch_split<false, 128>(a, batch, st);
   else e = bf ? launch_split<true, 256>(a, batch, st) : launch_split<false, 256>(a, batch, st);
   TDIST_HIP_TRY(e);
+  return 0;
+}
+
+// A decode step straight from the QKV projection (bf16, head_dim 128, one new token per sequence; the cache of
+// sequence b is the contiguous run of `max_len` slots starting at slot b * max_len).  One launch does what
+// tdist_qkv_prep + tdist_flash_decode_split(fused = 1) do in two: per-head RMSNorm (q_w / k_w, may be null) and
+// neox rotation of the q and k heads at pos[b], K / V of the new token appended at slot kv_offset[b],
+// total_out[b] = kv_offset[b] + 1, attention over those total_out[b] tokens, splits merged by the last workgroup.
+TDIST_API int tdist_flash_decode_prep(const void* qkv, long long qkv_stride, const void* q_w, const void* k_w,
+                                      float q_eps, float k_eps, const long long* pos, const float* cos_t,
+                                      const float* sin_t, void* k_cache, void* v_cache, const int* kv_offset,
+                                      int* total_out, const int* seq_table, void* partial, void* out, int* tickets,
+                                      int batch, int q_heads, int kv_heads, long long max_len, int splits,
+                                      long long o_stride_b, long long o_stride_h, float sm_scale, void* stream) {
+  constexpr int D = 128;
+  TDIST_REQUIRE(batch > 0 && q_heads > 0 && kv_heads > 0 && q_heads % kv_heads == 0, "bad head counts");
+  TDIST_REQUIRE(splits >= 1 && max_len >= 1 && max_len < (1ll << 30), "bad splits / cache length");
+  TDIST_REQUIRE(qkv && pos && cos_t && sin_t && k_cache && v_cache && kv_offset && total_out && seq_table && partial &&
+                    out && tickets,
+                "null argument");
+  TDIST_REQUIRE(qkv_stride % 8 == 0 && qkv_stride >= (long long)(q_heads + 2 * kv_heads) * D &&
+                    ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)k_cache & 15) == 0 && ((uintptr_t)v_cache & 15) == 0 &&
+                    ((uintptr_t)cos_t & 15) == 0 && ((uintptr_t)sin_t & 15) == 0 &&
+                    (!q_w || ((uintptr_t)q_w & 15) == 0) && (!k_w || ((uintptr_t)k_w & 15) == 0),
+                "qkv rows, caches, rotation tables and norm weights must keep 16-byte alignment");
+  DecodeArgs a;
+  a.q = nullptr, a.k_cache = (const uint16_t*)k_cache, a.v_cache = (const uint16_t*)v_cache;
+  a.block_table = seq_table, a.kv_len = nullptr, a.partial = partial, a.out = out, a.tickets = tickets;
+  a.q_stride_b = 0, a.q_stride_h = 0;
+  a.k_stride_slot = a.v_stride_slot = (long long)kv_heads * D;
+  a.k_stride_h = a.v_stride_h = D;
+  a.p_stride_s = D + 1, a.p_stride_h = (long long)splits * (D + 1), a.p_stride_b = (long long)q_heads * splits * (D + 1);
+  a.o_stride_b = o_stride_b, a.o_stride_h = o_stride_h;
+  // one page per sequence; the page arithmetic only needs a power of two that covers it
+  a.table_stride = 1;
+  a.page_size = (int)max_len;
+  a.page_shift = (max_len & (max_len - 1)) == 0 ? __builtin_ctzll(max_len) : -1;
+  a.q_heads = q_heads, a.kv_heads = kv_heads, a.splits = splits, a.fused = 1, a.p16 = 0;
+  a.sm_scale = sm_scale, a.soft_cap = 0.f;
+  a.deep = (long long)batch * kv_heads * ((q_heads / kv_heads + 15) / 16) * splits > 2ll * num_cus_cached() ? 1 : 0;
+  a.qkv = (const uint16_t*)qkv, a.qkv_stride = qkv_stride;
+  a.q_w = (const uint16_t*)q_w, a.k_w = (const uint16_t*)k_w, a.q_eps = q_eps, a.k_eps = k_eps;
+  a.pos = pos, a.cos_t = cos_t, a.sin_t = sin_t, a.kv_offset = kv_offset, a.total_out = total_out, a.max_slots = max_len;
+  TDIST_HIP_TRY((launch_split<true, D, true>(a, batch, (hipStream_t)stream)));
   return 0;
 }
 

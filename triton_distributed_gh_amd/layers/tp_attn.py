@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import torch
 
-from ..ops import elementwise
+from ..ops import elementwise, flash_decode
 from ..ops.ag_gemm import ag_gemm_intra_node, create_ag_gemm_intra_node_context
 from ..ops.allreduce import AllReduceMethod, all_reduce, create_allreduce_ctx
 from ..ops.flash_attn import flash_attn_with_kvcache
@@ -119,6 +119,14 @@ class TP_Attn:
         total = getattr(kv_cache, "total_len", None)
         if (total is not None and kv_offset.dtype == torch.int32 and k_cache.dim() == 4 and k_cache.shape[0] == bsz
                 and elementwise.qkv_prep_supported(qkv, k_cache, v_cache, D) and cos_sin_cache[0].is_cuda):
+            if q_len == 1 and flash_decode.decode_step_from_qkv_supported(qkv, k_cache, v_cache, D, cos_sin_cache[0]):
+                # a decode step: the attention kernel norms, rotates and appends on its own - one launch in all
+                out = flash_decode.decode_step_from_qkv(
+                    qkv, getattr(self, "q_norm_w", None), getattr(self, "k_norm_w", None),
+                    getattr(self, "q_norm_eps", 0.0), getattr(self, "k_norm_eps", 0.0), position_ids, cos_sin_cache[0],
+                    cos_sin_cache[1], k_cache, v_cache, kv_offset, total, self.q_size // D, self.kv_size // D,
+                    seq_table=getattr(kv_cache, "seq_table", None))
+                return out.reshape(bsz, q_len, -1)
             # one launch: per-head norms, rotation, cache append, attended length (ops/elementwise.py: qkv_prep)
             q = elementwise.qkv_prep(qkv, getattr(self, "q_norm_w", None), getattr(self, "k_norm_w", None),
                                      getattr(self, "q_norm_eps", 0.0), getattr(self, "k_norm_eps", 0.0), position_ids,

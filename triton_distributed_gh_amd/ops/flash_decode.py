@@ -181,6 +181,61 @@ def gqa_fwd_batch_decode_persistent(q, k_cache, v_cache, workspace, q_lens, kv_l
     return out
 
 
+def decode_step_from_qkv_supported(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, head_dim: int,
+                                   cos: torch.Tensor) -> bool:
+    """Shapes ``decode_step_from_qkv`` is built for: bf16, head_dim 128, one new token per sequence, contiguous
+    per-sequence caches ``[B, max_len, Hkv, 128]``, fp32 rotation tables on the GPU."""
+    return (qkv.is_cuda and qkv.dtype == torch.bfloat16 and k_cache.dtype == v_cache.dtype == torch.bfloat16
+            and head_dim == 128 and qkv.dim() == 3 and qkv.shape[1] == 1 and qkv.stride(2) == 1 and qkv.stride(0) % 8 == 0
+            and qkv.data_ptr() % 16 == 0 and k_cache.dim() == 4 and k_cache.shape[0] == qkv.shape[0]
+            and k_cache.is_contiguous() and v_cache.is_contiguous() and k_cache.shape == v_cache.shape
+            and cos.is_cuda and cos.dtype == torch.float32 and cos.is_contiguous() and cos.shape[-1] == 64
+            and os.environ.get("TDIST_DECODE_FUSED_PREP", "1") != "0")
+
+
+def decode_step_from_qkv(qkv: torch.Tensor, q_w: Optional[torch.Tensor], k_w: Optional[torch.Tensor], q_eps: float,
+                         k_eps: float, position_ids: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
+                         k_cache: torch.Tensor, v_cache: torch.Tensor, kv_offset: torch.Tensor, total_out: torch.Tensor,
+                         num_q_heads: int, num_kv_heads: int, seq_table: Optional[torch.Tensor] = None,
+                         scale: Optional[float] = None, kv_split: int = -1) -> torch.Tensor:
+    """One launch from the QKV projection of a decode step to the attention output.
+
+    ``qkv [B, 1, (Hq + 2 Hkv) * 128]``: q / k heads get their optional per-head RMSNorm and the neox rotation at
+    ``position_ids [B, 1]``, K / V of the new token go to slot ``kv_offset[b]`` of ``k_cache / v_cache
+    [B, max_len, Hkv, 128]``, ``total_out[b] = kv_offset[b] + 1`` and the token attends over those tokens.
+    Returns ``[B, Hq, 128]``.  The same arithmetic as ``elementwise.qkv_prep`` followed by
+    ``gqa_fwd_batch_decode_persistent`` - the workgroups of the attention kernel prepare their own heads
+    (csrc/include/tdist/flash_decode_device.hpp, PREP) - without the launch in between.  Call
+    ``decode_step_from_qkv_supported`` first."""
+    B, D = qkv.shape[0], 128
+    max_len = k_cache.shape[1]
+    assert kv_offset.dtype == torch.int32 and total_out.dtype == torch.int32 and kv_offset.numel() >= B
+    assert qkv.shape[2] == (num_q_heads + 2 * num_kv_heads) * D and k_cache.shape[2] == num_kv_heads
+    pos = position_ids.reshape(-1)
+    if pos.dtype != torch.int64 or not pos.is_contiguous():
+        pos = pos.to(torch.int64).contiguous()
+    assert pos.numel() == B
+    if seq_table is None:
+        seq_table = torch.arange(B, dtype=torch.int32, device=qkv.device).view(B, 1)
+    assert seq_table.dtype == torch.int32 and seq_table.numel() >= B
+    for w in (q_w, k_w):
+        assert w is None or (w.dtype == torch.bfloat16 and w.numel() == D and w.is_contiguous())
+    splits = int(kv_split) if kv_split and kv_split > 0 else \
+        int(os.environ.get("TDIST_DECODE_KV_SPLITS", "0")) or auto_kv_splits(B, num_q_heads, num_kv_heads, max_len)
+    part = torch.empty((B, num_q_heads, splits, D + 1), dtype=torch.float32, device=qkv.device)
+    out = torch.empty((B, num_q_heads, D), dtype=qkv.dtype, device=qkv.device)
+    tick = _tickets(qkv.device, B * num_kv_heads * ((num_q_heads // num_kv_heads + 15) // 16))
+    _lib.check(
+        _lib.hip().tdist_flash_decode_prep(
+            _lib.ptr(qkv), ctypes.c_longlong(qkv.stride(0)), _lib.ptr(q_w), _lib.ptr(k_w), ctypes.c_float(q_eps),
+            ctypes.c_float(k_eps), _lib.ptr(pos), _lib.ptr(cos), _lib.ptr(sin), _lib.ptr(k_cache), _lib.ptr(v_cache),
+            _lib.ptr(kv_offset), _lib.ptr(total_out), _lib.ptr(seq_table), _lib.ptr(part), _lib.ptr(out), _lib.ptr(tick),
+            B, num_q_heads, num_kv_heads, ctypes.c_longlong(max_len), splits, ctypes.c_longlong(out.stride(0)),
+            ctypes.c_longlong(out.stride(1)), ctypes.c_float(scale if scale is not None else 1.0 / math.sqrt(D)),
+            _lib.stream_handle()), "tdist_flash_decode_prep")
+    return out
+
+
 # the reference exposes AOT-compiled twins of the two entry points; here every kernel is AOT
 gqa_fwd_batch_decode_aot = gqa_fwd_batch_decode
 gqa_fwd_batch_decode_intra_rank_aot = gqa_fwd_batch_decode_intra_rank
