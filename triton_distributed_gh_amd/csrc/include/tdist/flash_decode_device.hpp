@@ -302,11 +302,19 @@ __device__ __forceinline__ void decode_split_body(const DecodeArgs& a, const int
   // Pages of a power-of-two size >= 32 tokens: a wave's 32-token block (32-aligned) lies in ONE page, so the
   // page index is a single wave-uniform (scalar) look-up per block, fetched one block ahead, instead of ten
   // per-lane look-ups through the vector L1 in front of the sixteen K / V loads that depend on them.
-  const bool one_page = a.page_shift >= 5;
+  // The same holds for any page size that is a multiple of 32, and for a sequence that fits its first page
+  // whatever the page size (a cache of one contiguous run of max_len slots per sequence: max_len is arbitrary).
+  const bool single = kv_len <= a.page_size;
+  const bool one_page = single || a.page_shift >= 5 || (a.page_shift < 0 && (a.page_size & 31) == 0);
   auto block_slot0 = [&](int n0) -> long long {     // slot of token n0 (wave-uniform)
     const int n0u = __builtin_amdgcn_readfirstlane(n0);
-    const int page = table[n0u >> a.page_shift];
-    return ((long long)page << a.page_shift) + (n0u & (a.page_size - 1));
+    if (single) return (long long)table[0] * a.page_size + n0u;
+    if (a.page_shift >= 0) {
+      const int page = table[n0u >> a.page_shift];
+      return ((long long)page << a.page_shift) + (n0u & (a.page_size - 1));
+    }
+    const int pi = n0u / a.page_size;
+    return (long long)table[pi] * a.page_size + (n0u - pi * a.page_size);
   };
   // One 32-token block of K and V in registers (16 x 16 bytes per lane for D = 128).
   struct KVBlock {

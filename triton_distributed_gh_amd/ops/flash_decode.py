@@ -34,12 +34,24 @@ def _tickets(device, n: int) -> torch.Tensor:
     return t
 
 
-def auto_kv_splits(batch: int, q_heads: int, kv_heads: int, max_kv_len: int, num_cus: int = 256) -> int:
-    """Enough workgroups for ~2 waves of the chip, but at least 256 tokens of KV per split - or 64
-    when even that many splits leave most CUs idle (small batch, short context: with 8 KV heads and
-    512 tokens two splits are 16 workgroups streaming 128 KiB each, 27 us on MI355X)."""
+def auto_kv_splits(batch: int, q_heads: int, kv_heads: int, max_kv_len: int, num_cus: int = 256,
+                   fused: bool = False) -> int:
+    """Number of KV splits of a decode launch.
+
+    Two launches (split, then a merge kernel that is parallel over heads): enough workgroups for ~2 waves of the
+    chip, but at least 256 tokens of KV per split - or 64 when even that many splits leave most CUs idle.
+
+    ``fused`` (one launch; the last workgroup of a (sequence, head block) merges its splits, so the merge grows with
+    the number of splits and the workgroups - one per CU at head_dim 128 - should fit ONE round of the chip):
+    streaming costs ~ L / s and merging ~ s, which puts the optimum at s ~ sqrt(L / 32); measured on MI355X with
+    cold K / V (scripts/dev/probe_decode_splits.py, 32 / 8 heads): batch 1 - 4 splits at 512-1024 tokens, 8 at 4096,
+    16 at 8192, 32 at 32768; batch 4 x 8192 - 8 (one round) 39.8 us against 46.7 at 16; batch 8 x 2048 - 4: 24.0
+    against 32.0 at 8; batch 16 x 4096 - 2."""
     group = q_heads // kv_heads
     base = batch * kv_heads * ((group + 15) // 16)
+    if fused:
+        want = max(1, int(round(math.sqrt(max_kv_len / 32.0))))
+        return int(max(1, min(want, max(1, num_cus // base), max(1, max_kv_len // 64), 64)))
     want = max(1, (2 * num_cus + base - 1) // base)
     cap = max(1, max_kv_len // 256)
     if base * cap < num_cus:
@@ -112,14 +124,14 @@ def _combine(partial, strides, n, batch, heads, D, lens, out, out_mode, dtype_co
             _lib.stream_handle()), "tdist_flash_decode_combine")
 
 
-def _splits(q, k_cache, block_table, kv_split):
+def _splits(q, k_cache, block_table, kv_split, fused=False):
     if kv_split is not None and kv_split > 0:
         return int(kv_split)
     forced = int(os.environ.get("TDIST_DECODE_KV_SPLITS", "0"))        # tuning knob
     if forced > 0:
         return forced
     batch, q_heads, _ = q.shape
-    return auto_kv_splits(batch, q_heads, k_cache.shape[2], block_table.shape[1] * k_cache.shape[1])
+    return auto_kv_splits(batch, q_heads, k_cache.shape[2], block_table.shape[1] * k_cache.shape[1], fused=fused)
 
 
 def _partial(q, splits, output_split):
@@ -173,7 +185,7 @@ def gqa_fwd_batch_decode_persistent(q, k_cache, v_cache, workspace, q_lens, kv_l
     batch, q_heads, D = q.shape
     if not q.is_cuda:
         return decode_reference(q, k_cache, v_cache, kv_lens, block_table, scale, soft_cap).to(q.dtype)
-    splits = _splits(q, k_cache, block_table, kv_split)
+    splits = _splits(q, k_cache, block_table, kv_split, fused=True)
     part = _partial(q, splits, output_split)
     out = output_combine if (output_combine is not None and output_combine.dtype == q.dtype) else \
         torch.empty((batch, q_heads, D), dtype=q.dtype, device=q.device)
@@ -221,7 +233,7 @@ def decode_step_from_qkv(qkv: torch.Tensor, q_w: Optional[torch.Tensor], k_w: Op
     for w in (q_w, k_w):
         assert w is None or (w.dtype == torch.bfloat16 and w.numel() == D and w.is_contiguous())
     splits = int(kv_split) if kv_split and kv_split > 0 else \
-        int(os.environ.get("TDIST_DECODE_KV_SPLITS", "0")) or auto_kv_splits(B, num_q_heads, num_kv_heads, max_len)
+        int(os.environ.get("TDIST_DECODE_KV_SPLITS", "0")) or auto_kv_splits(B, num_q_heads, num_kv_heads, max_len, fused=True)
     part = torch.empty((B, num_q_heads, splits, D + 1), dtype=torch.float32, device=qkv.device)
     out = torch.empty((B, num_q_heads, D), dtype=qkv.dtype, device=qkv.device)
     tick = _tickets(qkv.device, B * num_kv_heads * ((num_q_heads // num_kv_heads + 15) // 16))

@@ -33,6 +33,7 @@ MID_GEMM = os.environ.get("TDIST_MID_GEMM", "native")
 MID_MAX_M = int(os.environ.get("TDIST_MID_MAX_M", "1024"))
 # decode shapes (M <= 16) with long K / mid-sized weights on the mid-M kernel's split-K ("1"; default off)
 DECODE_SPLITK = os.environ.get("TDIST_DECODE_SPLITK", "0") != "0"
+DECODE_SPLITK_MIN_M = 1 if DECODE_SPLITK else int(os.environ.get("TDIST_DECODE_SPLITK_MIN_M", "2"))
 
 
 def gemm_supported(a: torch.Tensor, b: torch.Tensor) -> bool:
@@ -81,7 +82,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     # 25-36 us).  Inside a real decode step, where every layer streams from HBM instead of the memory-side
     # cache, the step time is the same (Qwen3-8B, HIP graph: 4.399 vs 4.388 ms), so the rule is opt-in:
     # TDIST_DECODE_SPLITK=1.
-    if (M <= 16 and DECODE_SPLITK and variant == GEMM_VARIANT and N <= 32768
+    if (DECODE_SPLITK_MIN_M <= M <= 16 and variant == GEMM_VARIANT and N <= 32768
             and (K >= 8192 or N * K >= 20_000_000)):
         return gemm_nt_mid(a, b, out)
     # Otherwise decode shapes stay on the weight-streaming kernel.  Called back to back on ONE 100-270 MB layer the
@@ -254,11 +255,14 @@ def gemm_nt_silu_mul(a: torch.Tensor, gate_up: torch.Tensor) -> torch.Tensor:
     return silu_mul(gemm_nt(a, gate_up))
 
 
+NORM_GEMM_MAX_M = min(16, int(os.environ.get("TDIST_NORM_GEMM_MAX_M", "16")))
+
+
 def norm_gemm_supported(x: torch.Tensor, w: torch.Tensor, norm_w: torch.Tensor, residual: Optional[torch.Tensor]) -> bool:
     """Shapes the decode GEMM takes with the RMSNorm folded in: at most 16 rows, bf16, the rows' normalised copy
     (M x (2 K + 64) bytes) within 48 KiB of LDS."""
     M, K = x.shape
-    return (x.is_cuda and M <= 16 and x.dtype == torch.bfloat16 == w.dtype == norm_w.dtype and gemm_supported(x, w)
+    return (x.is_cuda and M <= NORM_GEMM_MAX_M and x.dtype == torch.bfloat16 == w.dtype == norm_w.dtype and gemm_supported(x, w)
             and K % 32 == 0 and K >= 128 and M * (2 * K + 64) <= 48 * 1024 and norm_w.is_contiguous()
             and (residual is None or (residual.dtype == x.dtype and residual.shape == x.shape)))
 
