@@ -49,3 +49,25 @@ for B, L in [(1, 512), (1, 1024), (1, 2048), (1, 4096), (1, 8192), (1, 32768), (
         res.append(f"{sp}{'*' if sp == auto else ''}:{t:.1f}")
     print(f"B={B} L={L} base={base} copies={copies}: " + "  ".join(res), flush=True)
     del kcs, vcs
+
+# capacity far above the attended length: the split count of the grid against the count the sequence uses
+print("capacity 8192, one sequence: attended length -> us (automatic / same grid, every split used)")
+B, L = 1, 8192
+kcs = [torch.randn(B, L, Hkv, D, device=dev).to(bf) for _ in range(18)]
+vcs = [torch.randn(B, L, Hkv, D, device=dev).to(bf) for _ in range(18)]
+q = torch.randn(B, Hq, D, device=dev).to(bf)
+table = torch.arange(B, dtype=torch.int32, device=dev).view(B, 1)
+auto = flash_decode.auto_kv_splits(B, Hq, Hkv, L, fused=True)
+for n in (100, 300, 1000, 3000, 8192):
+    lens = torch.full((B,), n, dtype=torch.int32, device=dev)
+    out = []
+    for sp in (-1, auto):
+        it = [0]
+
+        def call():
+            i = it[0] % 18
+            it[0] += 1
+            flash_decode.gqa_fwd_batch_decode_persistent(q, kcs[i], vcs[i], None, None, lens, table, D ** -0.5, kv_split=sp)
+
+        out.append(bench(call, n=18))
+    print(f"  len {n}: {out[0]:.1f} / {out[1]:.1f}", flush=True)

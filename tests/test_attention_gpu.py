@@ -207,7 +207,8 @@ def test_qkv_prep_matches_separate_kernels(B, S, Hq, Hkv, D, norm):
 
 @pytest.mark.parametrize("B,Hq,Hkv,max_len,norm,splits", [
     (1, 32, 8, 1024, True, -1), (1, 32, 8, 1024, True, 1), (4, 32, 8, 512, True, 3), (2, 8, 1, 1000, False, 2),
-    (3, 64, 2, 256, True, -1), (2, 4, 4, 16, True, 1), (64, 32, 8, 2048, True, -1)])
+    (3, 64, 2, 256, True, -1), (2, 4, 4, 16, True, 1), (64, 32, 8, 2048, True, -1), (2, 32, 8, 8192, True, -1),
+    (3, 16, 2, 1000, True, -1)])
 def test_decode_step_from_qkv_matches_prep_then_attention(B, Hq, Hkv, max_len, norm, splits):
     """The attention kernel that norms, rotates and appends the new token itself, against the two launches it
     replaces (qkv_prep, then split-KV decode) and against an fp32 reference, at cache lengths around every block

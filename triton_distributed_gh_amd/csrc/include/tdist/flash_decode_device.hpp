@@ -48,6 +48,9 @@ struct DecodeArgs {
   const int* kv_offset = nullptr;  // [batch] tokens in the cache before this step
   int* total_out = nullptr;        // [batch] <- kv_offset + 1
   long long max_slots = 0;         // slots per sequence (a full cache drops the new token instead of writing outside)
+  // 1 (fused launches whose grid was sized from the cache CAPACITY): a sequence uses min(splits, ~sqrt(kv_len / 32))
+  // splits - the optimum of streaming ~ L / s against merging ~ s - and the workgroups of later splits leave at once
+  int adaptive = 0;
 };
 
 __device__ __forceinline__ long long slot_of(const DecodeArgs& a, const int* table, int tok) {
@@ -233,8 +236,9 @@ __device__ __forceinline__ void prep_head_d128(const uint16_t* src, bool valid, 
 // the QKV projection and the attention - every workgroup norms and rotates its own query heads out of `qkv`, the
 // one wave whose 32-token block holds the new position norms and rotates the new K row, takes K / V of that token
 // from registers instead of the cache and (head block 0) appends them to the cache for the steps to come.
+// Returns the number of splits in use for this sequence (a.splits unless a.adaptive).
 template <bool IS_BF16, int D, bool ALLOW_DEEP = true, bool PREP = false>
-__device__ __forceinline__ void decode_split_body(const DecodeArgs& a, const int b, const int by, const int z, char* smem) {
+__device__ __forceinline__ int decode_split_body(const DecodeArgs& a, const int b, const int by, const int z, char* smem) {
   static_assert(!PREP || (IS_BF16 && D == 128), "the fused projection epilogue is built for bf16, head_dim 128");
   using F = Frag<IS_BF16>;
   using VT = typename F::T;
@@ -266,7 +270,12 @@ __device__ __forceinline__ void decode_split_body(const DecodeArgs& a, const int
   } else {
     kv_len = a.kv_len[b];
   }
-  const int per = (((kv_len + a.splits - 1) / a.splits) + 31) & ~31;
+  int nsplit = a.splits;
+  if (a.adaptive) {
+    nsplit = min(nsplit, max(1, (int)(__builtin_sqrtf((float)kv_len * (1.f / 32.f)) + 0.5f)));
+    if (z >= nsplit) return nsplit;
+  }
+  const int per = (((kv_len + nsplit - 1) / nsplit) + 31) & ~31;
   const int start = z * per;
   const int end = min(start + per, kv_len);
   const int* table = a.block_table + (long long)b * a.table_stride;
@@ -491,7 +500,7 @@ __device__ __forceinline__ void decode_split_body(const DecodeArgs& a, const int
     float* dst = (float*)a.partial + doff;
     const float val = L > 0.f ? o / L : 0.f;
     const float lse = L > 0.f ? (M + __log2f(L)) * 0.6931471805599453f : -INFINITY;
-    if (a.fused == 1 && a.splits == 1) {
+    if (a.fused == 1 && nsplit == 1) {
       // a single split is the final result: no partial row, no ticket, no second pass
       ((uint16_t*)a.out)[b * a.o_stride_b + (long long)(h0 + h) * a.o_stride_h + c] = to16<IS_BF16>(val);
     } else if (a.p16) {
@@ -509,6 +518,7 @@ __device__ __forceinline__ void decode_split_body(const DecodeArgs& a, const int
       if (c == 0) dst[D] = lse;
     }
   }
+  return nsplit;
 }
 
 }  // namespace fdec

@@ -40,9 +40,9 @@ __global__ __launch_bounds__(256) void decode_split_kernel(DecodeArgs a) {
   const int hblk = blockIdx.y - kvh * hblocks;
   const int h0 = kvh * group + hblk * 16;
   const int valid_h = min(16, group - hblk * 16);
-  decode_split_body<IS_BF16, D, true, PREP>(a, b, (int)blockIdx.y, (int)blockIdx.z, smem);
+  const int nsplit = decode_split_body<IS_BF16, D, true, PREP>(a, b, (int)blockIdx.y, (int)blockIdx.z, smem);
 
-  if (!a.fused || (a.fused == 1 && a.splits == 1)) return;
+  if (!a.fused || (a.fused == 1 && nsplit == 1) || (int)blockIdx.z >= nsplit) return;
   if (a.p16) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // 16-bit rows went out as plain stores
   // ---- last workgroup of this (batch, head block) merges the splits.  The partial rows were
   // stored write-through: every wave drains its stores, the workgroup barriers, one lane takes a
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void decode_split_kernel(DecodeArgs a) {
   if (threadIdx.x == 0) {
     int* t = a.tickets + b * gridDim.y + blockIdx.y;
     const int prev = __hip_atomic_fetch_add(t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = prev == a.splits - 1;
+    s_last = prev == nsplit - 1;
     if (s_last) __hip_atomic_store(t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
   }
   __syncthreads();
@@ -70,9 +70,9 @@ __global__ __launch_bounds__(256) void decode_split_kernel(DecodeArgs a) {
       const long long poff = b * a.p_stride_b + (long long)(h0 + h) * a.p_stride_h;
       char* o = (char*)a.out + (b * a.o_stride_b + (long long)(h0 + h) * a.o_stride_h) * (a.fused == 2 ? 4 : 2);
       if (a.p16)
-        merge_rows<IS_BF16, true>((const uint16_t*)a.partial + poff, a.p_stride_s, a.splits, D, nullptr, 0, o, a.fused, sub, 16);
+        merge_rows<IS_BF16, true>((const uint16_t*)a.partial + poff, a.p_stride_s, nsplit, D, nullptr, 0, o, a.fused, sub, 16);
       else
-        merge_rows<IS_BF16, false>((const float*)a.partial + poff, a.p_stride_s, a.splits, D, nullptr, 0, o, a.fused, sub, 16);
+        merge_rows<IS_BF16, false>((const float*)a.partial + poff, a.p_stride_s, nsplit, D, nullptr, 0, o, a.fused, sub, 16);
     }
   }
 }
@@ -122,7 +122,8 @@ int num_cus_cached() {
 }  // namespace
 
 // dtype: 0 = bf16, 1 = fp16; + 16: the partial rows are stored in that 16-bit type instead of fp32.
-// fused: 0 partials only / 1 merged 16-bit / 2 merged fp32 + LSE / 3 merged 16-bit + LSE.
+// fused: 0 partials only / 1 merged 16-bit / 2 merged fp32 + LSE / 3 merged 16-bit + LSE; + 4 (with 1..3): `splits`
+// was sized from the cache capacity and every sequence uses as many of them as its own length calls for.
 TDIST_API int tdist_flash_decode_split(const void* q, const void* k_cache, const void* v_cache, const int* block_table,
                                        const int* kv_len, void* partial, void* out, int* tickets, int batch,
                                        int q_heads, int kv_heads, int head_dim, int splits, int page_size,
@@ -148,6 +149,9 @@ TDIST_API int tdist_flash_decode_split(const void* q, const void* k_cache, const
   a.o_stride_b = o_stride_b, a.o_stride_h = o_stride_h;
   a.table_stride = table_stride, a.page_size = page_size;
   a.page_shift = (page_size & (page_size - 1)) == 0 ? __builtin_ctz(page_size) : -1;
+  a.adaptive = (fused & 4) ? 1 : 0;
+  fused &= ~4;
+  TDIST_REQUIRE(!a.adaptive || fused != 0, "adaptive splits need the fused merge");
   a.q_heads = q_heads, a.kv_heads = kv_heads, a.splits = splits, a.fused = fused;
   a.p16 = (dtype & 16) ? 1 : 0;
   dtype &= 15;
@@ -178,7 +182,8 @@ TDIST_API int tdist_flash_decode_prep(const void* qkv, long long qkv_stride, con
                                       const float* sin_t, void* k_cache, void* v_cache, const int* kv_offset,
                                       int* total_out, const int* seq_table, void* partial, void* out, int* tickets,
                                       int batch, int q_heads, int kv_heads, long long max_len, int splits,
-                                      long long o_stride_b, long long o_stride_h, float sm_scale, void* stream) {
+                                      long long o_stride_b, long long o_stride_h, float sm_scale, int adaptive,
+                                      void* stream) {
   constexpr int D = 128;
   TDIST_REQUIRE(batch > 0 && q_heads > 0 && kv_heads > 0 && q_heads % kv_heads == 0, "bad head counts");
   TDIST_REQUIRE(splits >= 1 && max_len >= 1 && max_len < (1ll << 30), "bad splits / cache length");
@@ -208,6 +213,7 @@ TDIST_API int tdist_flash_decode_prep(const void* qkv, long long qkv_stride, con
   a.qkv = (const uint16_t*)qkv, a.qkv_stride = qkv_stride;
   a.q_w = (const uint16_t*)q_w, a.k_w = (const uint16_t*)k_w, a.q_eps = q_eps, a.k_eps = k_eps;
   a.pos = pos, a.cos_t = cos_t, a.sin_t = sin_t, a.kv_offset = kv_offset, a.total_out = total_out, a.max_slots = max_len;
+  a.adaptive = adaptive ? 1 : 0;
   TDIST_HIP_TRY((launch_split<true, D, true>(a, batch, (hipStream_t)stream)));
   return 0;
 }

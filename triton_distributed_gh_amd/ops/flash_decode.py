@@ -134,6 +134,10 @@ def _splits(q, k_cache, block_table, kv_split, fused=False):
     return auto_kv_splits(batch, q_heads, k_cache.shape[2], block_table.shape[1] * k_cache.shape[1], fused=fused)
 
 
+def _splits_forced(kv_split) -> bool:
+    return bool(kv_split is not None and kv_split > 0) or int(os.environ.get("TDIST_DECODE_KV_SPLITS", "0")) > 0
+
+
 def _partial(q, splits, output_split):
     batch, q_heads, D = q.shape
     if output_split is not None and output_split.dtype == torch.float32 and output_split.is_contiguous() \
@@ -189,7 +193,9 @@ def gqa_fwd_batch_decode_persistent(q, k_cache, v_cache, workspace, q_lens, kv_l
     part = _partial(q, splits, output_split)
     out = output_combine if (output_combine is not None and output_combine.dtype == q.dtype) else \
         torch.empty((batch, q_heads, D), dtype=q.dtype, device=q.device)
-    _launch(q, k_cache, v_cache, kv_lens, block_table, scale, soft_cap, splits, 1, part, out)
+    # an automatic split count comes from the cache CAPACITY: let every sequence use what its own length needs (+ 4)
+    _launch(q, k_cache, v_cache, kv_lens, block_table, scale, soft_cap, splits, 1 + (0 if _splits_forced(kv_split) else 4),
+            part, out)
     return out
 
 
@@ -244,7 +250,7 @@ def decode_step_from_qkv(qkv: torch.Tensor, q_w: Optional[torch.Tensor], k_w: Op
             _lib.ptr(kv_offset), _lib.ptr(total_out), _lib.ptr(seq_table), _lib.ptr(part), _lib.ptr(out), _lib.ptr(tick),
             B, num_q_heads, num_kv_heads, ctypes.c_longlong(max_len), splits, ctypes.c_longlong(out.stride(0)),
             ctypes.c_longlong(out.stride(1)), ctypes.c_float(scale if scale is not None else 1.0 / math.sqrt(D)),
-            _lib.stream_handle()), "tdist_flash_decode_prep")
+            0 if _splits_forced(kv_split) else 1, _lib.stream_handle()), "tdist_flash_decode_prep")
     return out
 
 
