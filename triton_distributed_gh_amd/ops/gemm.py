@@ -31,7 +31,7 @@ DECODE_LIB_BYTES = int(os.environ.get("TDIST_DECODE_GEMM_LIB_MB", "0")) << 20
 # the band between the decode kernel and chip-filling 256x256 tiles: "native" (mid-M kernel) or "lib"
 MID_GEMM = os.environ.get("TDIST_MID_GEMM", "native")
 MID_MAX_M = int(os.environ.get("TDIST_MID_MAX_M", "1024"))
-# decode shapes (M <= 16) with long K / mid-sized weights on the mid-M kernel's split-K ("1"; default off)
+# decode shapes (M <= 16) with long K / mid-sized weights on the mid-M kernel's split-K: from this many rows on
 DECODE_SPLITK = os.environ.get("TDIST_DECODE_SPLITK", "0") != "0"
 DECODE_SPLITK_MIN_M = 1 if DECODE_SPLITK else int(os.environ.get("TDIST_DECODE_SPLITK_MIN_M", "2"))
 
@@ -76,12 +76,12 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
             return out
         if M <= MID_MAX_M:
             return gemm_nt_mid(a, b, out)
-    # Decode shapes (M <= 16): the weight-streaming kernel has no split of K across workgroups, and on one
-    # layer called back to back the mid-M kernel (rows padded to 32, split-K) is ahead on long-K / mid-sized
-    # weights (scripts/dev/probe_decode_splitk.py: 4096 x 12288 18.5 vs 22.9-30.9 us, 1024 x 16384 13.1 vs
-    # 25-36 us).  Inside a real decode step, where every layer streams from HBM instead of the memory-side
-    # cache, the step time is the same (Qwen3-8B, HIP graph: 4.399 vs 4.388 ms), so the rule is opt-in:
-    # TDIST_DECODE_SPLITK=1.
+    # Decode shapes (M <= 16): the weight-streaming kernel has no split of K across workgroups and every workgroup
+    # reads all M activation rows (at 16 rows as many bytes as its weight slice), so from two rows on the long-K /
+    # mid-sized layers go to the mid-M kernel (rows padded to 32, split-K).  Qwen3-8B decode step, HIP graph, `down`
+    # (4096 x 12288) moved: batch 4 4.77 -> 4.67 ms, batch 8 5.18 -> 4.86, batch 16 5.50 -> 5.04; at one row the
+    # step time is the same either way (4.399 vs 4.388 ms), so one row stays on the streaming kernel.
+    # TDIST_DECODE_SPLITK_MIN_M moves the first row count (17 = never); TDIST_DECODE_SPLITK=1 is 1.
     if (DECODE_SPLITK_MIN_M <= M <= 16 and variant == GEMM_VARIANT and N <= 32768
             and (K >= 8192 or N * K >= 20_000_000)):
         return gemm_nt_mid(a, b, out)
