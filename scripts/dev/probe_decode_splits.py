@@ -23,7 +23,7 @@ def bench(fn, n=20, reps=10):
     return s.elapsed_time(e) / (n * reps) * 1e3
 
 dev, bf, Hq, Hkv, D = "cuda", torch.bfloat16, 32, 8, 128
-for B, L in [(1, 512), (1, 1024), (1, 2048), (1, 4096), (1, 8192), (1, 32768), (2, 512), (2, 2048), (4, 512), (4, 2048), (4, 8192), (8, 512), (8, 2048), (8, 8192), (16, 512), (16, 4096), (32, 2048), (48, 2048), (64, 4096), (1, 576), (3, 1000), (5, 700), (4, 576)]:
+for B, L in [(1, 512), (1, 2048), (1, 4096), (1, 8192), (1, 32768), (1, 131072), (2, 2048), (2, 32768), (4, 2048), (4, 8192), (4, 32768), (8, 8192), (16, 4096)]:
     per = 2 * B * L * Hkv * D * 2
     copies = max(2, min(160, int(600e6 / per) + 1))          # cold K / V on every call, like a layer of a model
     kcs = [torch.randn(B, L, Hkv, D, device=dev).to(bf) for _ in range(copies)]
@@ -47,7 +47,20 @@ for B, L in [(1, 512), (1, 1024), (1, 2048), (1, 4096), (1, 8192), (1, 32768), (
         it[0] = 0
         t = bench(call, n=min(copies, 40))
         res.append(f"{sp}{'*' if sp == auto else ''}:{t:.1f}")
-    print(f"B={B} L={L} base={base} copies={copies}: " + "  ".join(res), flush=True)
+    # the two-launch form (split kernel, then a merge kernel that is parallel over heads)
+    two = []
+    for sp in sorted({flash_decode.auto_kv_splits(B, Hq, Hkv, L), max(1, 256 // base), max(1, 512 // base), 16, 32, 64}):
+        if sp > max(1, L // 64) or sp > 64:
+            continue
+        it = [0]
+
+        def call2():
+            i = it[0] % copies
+            it[0] += 1
+            flash_decode.gqa_fwd_batch_decode(q, kcs[i], vcs[i], None, None, lens, table, D ** -0.5, kv_split=sp)
+
+        two.append(f"{sp}:{bench(call2, n=min(copies, 40)):.1f}")
+    print(f"B={B} L={L} base={base} copies={copies}: " + "  ".join(res) + "   | two launches: " + "  ".join(two), flush=True)
     del kcs, vcs
 
 # capacity far above the attended length: the split count of the grid against the count the sequence uses

@@ -238,7 +238,7 @@ def test_decode_step_from_qkv_matches_prep_then_attention(B, Hq, Hkv, max_len, n
         total, total2 = torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)
         assert flash_decode.decode_step_from_qkv_supported(qkv, kc, vc, D, cos)
         out = flash_decode.decode_step_from_qkv(qkv, qw, kw, 1e-6, 1e-6, pos, cos, sin, kc, vc, offs, total, Hq, Hkv,
-                                                kv_split=splits)
+                                                kv_split=splits, one_launch=bool(it & 1))
         # the two launches
         q2 = elementwise.qkv_prep(qkv, qw, kw, 1e-6, 1e-6, pos, cos, sin, kc2, vc2, offs, total2, Hq, Hkv, D)
         table = torch.arange(B, dtype=torch.int32, device=dev).view(B, 1)

@@ -48,8 +48,10 @@ struct DecodeArgs {
   const int* kv_offset = nullptr;  // [batch] tokens in the cache before this step
   int* total_out = nullptr;        // [batch] <- kv_offset + 1
   long long max_slots = 0;         // slots per sequence (a full cache drops the new token instead of writing outside)
-  // 1 (fused launches whose grid was sized from the cache CAPACITY): a sequence uses min(splits, ~sqrt(kv_len / 32))
-  // splits - the optimum of streaming ~ L / s against merging ~ s - and the workgroups of later splits leave at once
+  // 1 (the grid was sized from the cache CAPACITY): a sequence uses as many of the `splits` as its own length calls
+  // for - fused launches min(splits, ~sqrt(kv_len / 32)), the optimum of streaming ~ L / s against merging ~ s in one
+  // workgroup, and the workgroups of later splits leave at once; launches with a separate merge kernel
+  // min(splits, kv_len / 128), and later splits write empty partial rows
   int adaptive = 0;
 };
 
@@ -120,6 +122,68 @@ __device__ __forceinline__ void merge_rows(const void* part_, long long stride, 
     }
   };
   const Rows part{part_};
+  // Up to 4 * nthreads rows (every launch of this package: at most 64 splits, 16 or 64 threads per head): the LSE
+  // column is read ONCE - thread t keeps the weights of rows t, t + nthreads, ... and hands them out by shuffle -
+  // and the value loads of eight rows are in flight together.  (Before, the accumulation re-read the LSE of every
+  // row and kept two rows in flight: ~0.5 us per split for the one workgroup that merges a head block.)
+  if (n <= 4 * nthreads && D >= nthreads) {
+    float l[4], w[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int s = tid + j * nthreads;
+      l[j] = -INFINITY;
+      if (s < n && !(lens && lens[(long long)s * lens_stride] <= 0)) l[j] = part[s * stride + D];
+      mx = fmaxf(mx, l[j]);
+    }
+    for (int off = nthreads >> 1; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float den = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      w[j] = (l[j] == -INFINITY) ? 0.f : __expf(l[j] - mx);
+      den += w[j];
+    }
+    for (int off = nthreads >> 1; off > 0; off >>= 1) den += __shfl_xor(den, off);
+    const float inv = den > 0.f ? 1.f / den : 0.f;
+    for (int c0 = tid; c0 < D; c0 += 4 * nthreads) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int sn = min(nthreads, n - j * nthreads);
+#pragma unroll 8
+        for (int si = 0; si < sn; ++si) {
+          const float wgt = __shfl(w[j], si, nthreads);
+          const Rows row = part + (long long)(j * nthreads + si) * stride;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int c = c0 + k * nthreads;
+            const float v = (c < D && wgt != 0.f) ? row[c] : 0.f;
+            acc[k] += wgt * v;
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = c0 + k * nthreads;
+        if (c >= D) continue;
+        const float r = acc[k] * inv;
+        if (out_mode == 2) {
+          ((float*)out)[c] = r;
+        } else {
+          ((uint16_t*)out)[c] = to16<IS_BF16>(r);
+        }
+      }
+    }
+    if (out_mode >= 2 && tid == 0) {
+      const float lse = den > 0.f ? mx + __logf(den) : -INFINITY;
+      if (out_mode == 2) {
+        ((float*)out)[D] = lse;
+      } else {
+        ((uint16_t*)out)[D] = to16<IS_BF16>(lse);
+      }
+    }
+    return;
+  }
   float mx = -INFINITY;
   for (int s = tid; s < n; s += nthreads) {
     if (lens && lens[(long long)s * lens_stride] <= 0) continue;
@@ -272,8 +336,8 @@ __device__ __forceinline__ int decode_split_body(const DecodeArgs& a, const int 
   }
   int nsplit = a.splits;
   if (a.adaptive) {
-    nsplit = min(nsplit, max(1, (int)(__builtin_sqrtf((float)kv_len * (1.f / 32.f)) + 0.5f)));
-    if (z >= nsplit) return nsplit;
+    nsplit = min(nsplit, max(1, a.fused ? (int)(__builtin_sqrtf((float)kv_len * (1.f / 32.f)) + 0.5f) : kv_len >> 7));
+    if (a.fused && z >= nsplit) return nsplit;
   }
   const int per = (((kv_len + nsplit - 1) / nsplit) + 31) & ~31;
   const int start = z * per;

@@ -122,8 +122,8 @@ int num_cus_cached() {
 }  // namespace
 
 // dtype: 0 = bf16, 1 = fp16; + 16: the partial rows are stored in that 16-bit type instead of fp32.
-// fused: 0 partials only / 1 merged 16-bit / 2 merged fp32 + LSE / 3 merged 16-bit + LSE; + 4 (with 1..3): `splits`
-// was sized from the cache capacity and every sequence uses as many of them as its own length calls for.
+// fused: 0 partials only / 1 merged 16-bit / 2 merged fp32 + LSE / 3 merged 16-bit + LSE; + 4: `splits` was sized
+// from the cache capacity and every sequence uses as many of them as its own length calls for.
 TDIST_API int tdist_flash_decode_split(const void* q, const void* k_cache, const void* v_cache, const int* block_table,
                                        const int* kv_len, void* partial, void* out, int* tickets, int batch,
                                        int q_heads, int kv_heads, int head_dim, int splits, int page_size,
@@ -137,8 +137,11 @@ TDIST_API int tdist_flash_decode_split(const void* q, const void* k_cache, const
   TDIST_REQUIRE(q_stride_h % 8 == 0 && q_stride_b % 8 == 0 && k_stride_slot % 8 == 0 && k_stride_h % 8 == 0 &&
                     v_stride_slot % 8 == 0 && v_stride_h % 8 == 0,
                 "q/k/v strides must keep 16-byte alignment");
+  const int adaptive = (fused & 4) ? 1 : 0;
+  fused &= ~4;
   TDIST_REQUIRE(fused == 0 || (out && tickets), "fused merge needs out and tickets");
   DecodeArgs a;
+  a.adaptive = adaptive;
   a.q = (const uint16_t*)q, a.k_cache = (const uint16_t*)k_cache, a.v_cache = (const uint16_t*)v_cache;
   a.block_table = block_table, a.kv_len = kv_len, a.partial = partial, a.out = out, a.tickets = tickets;
   a.q_stride_b = q_stride_b, a.q_stride_h = q_stride_h;
@@ -149,9 +152,6 @@ TDIST_API int tdist_flash_decode_split(const void* q, const void* k_cache, const
   a.o_stride_b = o_stride_b, a.o_stride_h = o_stride_h;
   a.table_stride = table_stride, a.page_size = page_size;
   a.page_shift = (page_size & (page_size - 1)) == 0 ? __builtin_ctz(page_size) : -1;
-  a.adaptive = (fused & 4) ? 1 : 0;
-  fused &= ~4;
-  TDIST_REQUIRE(!a.adaptive || fused != 0, "adaptive splits need the fused merge");
   a.q_heads = q_heads, a.kv_heads = kv_heads, a.splits = splits, a.fused = fused;
   a.p16 = (dtype & 16) ? 1 : 0;
   dtype &= 15;
@@ -176,20 +176,21 @@ TDIST_API int tdist_flash_decode_split(const void* q, const void* k_cache, const
 // sequence b is the contiguous run of `max_len` slots starting at slot b * max_len).  One launch does what
 // tdist_qkv_prep + tdist_flash_decode_split(fused = 1) do in two: per-head RMSNorm (q_w / k_w, may be null) and
 // neox rotation of the q and k heads at pos[b], K / V of the new token appended at slot kv_offset[b],
-// total_out[b] = kv_offset[b] + 1, attention over those total_out[b] tokens, splits merged by the last workgroup.
+// total_out[b] = kv_offset[b] + 1, attention over those total_out[b] tokens; `fused` 1: splits merged by the last
+// workgroup into `out`, 0: fp32 partial rows [batch, q_heads, splits, 129] for tdist_flash_decode_combine.
 TDIST_API int tdist_flash_decode_prep(const void* qkv, long long qkv_stride, const void* q_w, const void* k_w,
                                       float q_eps, float k_eps, const long long* pos, const float* cos_t,
                                       const float* sin_t, void* k_cache, void* v_cache, const int* kv_offset,
                                       int* total_out, const int* seq_table, void* partial, void* out, int* tickets,
                                       int batch, int q_heads, int kv_heads, long long max_len, int splits,
                                       long long o_stride_b, long long o_stride_h, float sm_scale, int adaptive,
-                                      void* stream) {
+                                      int fused, void* stream) {
   constexpr int D = 128;
   TDIST_REQUIRE(batch > 0 && q_heads > 0 && kv_heads > 0 && q_heads % kv_heads == 0, "bad head counts");
   TDIST_REQUIRE(splits >= 1 && max_len >= 1 && max_len < (1ll << 30), "bad splits / cache length");
-  TDIST_REQUIRE(qkv && pos && cos_t && sin_t && k_cache && v_cache && kv_offset && total_out && seq_table && partial &&
-                    out && tickets,
+  TDIST_REQUIRE(qkv && pos && cos_t && sin_t && k_cache && v_cache && kv_offset && total_out && seq_table && partial,
                 "null argument");
+  TDIST_REQUIRE(fused == 0 || (fused == 1 && out && tickets), "fused must be 0 or 1; the fused merge needs out and tickets");
   TDIST_REQUIRE(qkv_stride % 8 == 0 && qkv_stride >= (long long)(q_heads + 2 * kv_heads) * D &&
                     ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)k_cache & 15) == 0 && ((uintptr_t)v_cache & 15) == 0 &&
                     ((uintptr_t)cos_t & 15) == 0 && ((uintptr_t)sin_t & 15) == 0 &&
@@ -207,7 +208,7 @@ TDIST_API int tdist_flash_decode_prep(const void* qkv, long long qkv_stride, con
   a.table_stride = 1;
   a.page_size = (int)max_len;
   a.page_shift = (max_len & (max_len - 1)) == 0 ? __builtin_ctzll(max_len) : -1;
-  a.q_heads = q_heads, a.kv_heads = kv_heads, a.splits = splits, a.fused = 1, a.p16 = 0;
+  a.q_heads = q_heads, a.kv_heads = kv_heads, a.splits = splits, a.fused = fused, a.p16 = 0;
   a.sm_scale = sm_scale, a.soft_cap = 0.f;
   a.deep = (long long)batch * kv_heads * ((q_heads / kv_heads + 15) / 16) * splits > 2ll * num_cus_cached() ? 1 : 0;
   a.qkv = (const uint16_t*)qkv, a.qkv_stride = qkv_stride;

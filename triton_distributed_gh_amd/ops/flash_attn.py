@@ -140,7 +140,8 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, cache_seqlens=N
         # one "page" per sequence: page size = max_len
         kc = k_cache.view(B, max_len, Hkv, D)
         vc = v_cache.view(B, max_len, Hkv, D)
-        o = flash_decode.gqa_fwd_batch_decode_persistent(q[:, 0], kc, vc, None, None, total, table, scale)
+        # two launches (split, head-parallel merge): ahead of the single-launch form inside a HIP graph
+        o = flash_decode.gqa_fwd_batch_decode(q[:, 0], kc, vc, None, None, total, table, scale)
         return o.view(B, 1, Hq, D)
     if native and D in (64, 128):
         # the cache rows of sequence b live at b * max_len + [0, total_b): express as varlen over the cache

@@ -21,6 +21,7 @@ import torch
 from .. import _lib
 
 _TICKETS = {}
+ONE_LAUNCH = os.environ.get("TDIST_DECODE_ONE_LAUNCH", "0") != "0"      # decode_step_from_qkv: in-kernel merge
 
 
 def _tickets(device, n: int) -> torch.Tensor:
@@ -36,27 +37,26 @@ def _tickets(device, n: int) -> torch.Tensor:
 
 def auto_kv_splits(batch: int, q_heads: int, kv_heads: int, max_kv_len: int, num_cus: int = 256,
                    fused: bool = False) -> int:
-    """Number of KV splits of a decode launch.
+    """Number of KV splits of a decode launch (the grid; with an automatic count every sequence then uses as many
+    of them as its own length calls for, see ``DecodeArgs::adaptive``).
 
-    Two launches (split, then a merge kernel that is parallel over heads): enough workgroups for ~2 waves of the
-    chip, but at least 256 tokens of KV per split - or 64 when even that many splits leave most CUs idle.
+    A workgroup holds a CU by itself at head_dim 128 (232 - 256 VGPRs), so the workgroups should fit ONE round of
+    the chip: at most ``num_cus / (batch * kv_heads * head_blocks)`` splits.  Inside that bound, measured on
+    MI355X with cold K / V (scripts/dev/probe_decode_splits.py, 32 / 8 heads, HIP graph):
 
-    ``fused`` (one launch; the last workgroup of a (sequence, head block) merges its splits, so the merge grows with
-    the number of splits and the workgroups - one per CU at head_dim 128 - should fit ONE round of the chip):
-    streaming costs ~ L / s and merging ~ s, which puts the optimum at s ~ sqrt(L / 32); measured on MI355X with
-    cold K / V (scripts/dev/probe_decode_splits.py, 32 / 8 heads): batch 1 - 4 splits at 512-1024 tokens, 8 at 4096,
-    16 at 8192, 32 at 32768; batch 4 x 8192 - 8 (one round) 39.8 us against 46.7 at 16; batch 8 x 2048 - 4: 24.0
-    against 32.0 at 8; batch 16 x 4096 - 2."""
+    * two launches (split kernel, then a merge kernel that is parallel over heads): at least 128 tokens per split,
+      at most 32 splits - batch 1: 15.2 us at 2048 tokens (16 splits), 18.1 at 4096 (16), 43.6 at 32768 (32);
+    * ``fused`` (one launch; the last workgroup of a (sequence, head block) merges its splits): streaming costs
+      ~ L / s and the merge ~ s, optimum s ~ sqrt(L / 32) - batch 1: 17.0 us at 2048 (8 splits), 22.1 at 4096 (11),
+      54.1 at 32768 (32).  The two-launch form is ahead at every shape with fewer than ~64 (sequence, kv head) pairs
+      once the launches sit in a HIP graph."""
     group = q_heads // kv_heads
     base = batch * kv_heads * ((group + 15) // 16)
+    one_round = max(1, num_cus // base)
     if fused:
         want = max(1, int(round(math.sqrt(max_kv_len / 32.0))))
-        return int(max(1, min(want, max(1, num_cus // base), max(1, max_kv_len // 64), 64)))
-    want = max(1, (2 * num_cus + base - 1) // base)
-    cap = max(1, max_kv_len // 256)
-    if base * cap < num_cus:
-        cap = max(1, max_kv_len // 64)
-    return int(max(1, min(want, cap, 64)))
+        return int(max(1, min(want, one_round, max(1, max_kv_len // 64), 64)))
+    return int(max(1, min(one_round, max(1, max_kv_len // 128), 32)))
 
 
 def _dt(q: torch.Tensor) -> int:
@@ -157,7 +157,7 @@ def gqa_fwd_batch_decode(q, k_cache, v_cache, workspace, q_lens, kv_lens, block_
     part = _partial(q, splits, output_split)
     out = output_combine if (output_combine is not None and output_combine.dtype == q.dtype) else \
         torch.empty((batch, q_heads, D), dtype=q.dtype, device=q.device)
-    _launch(q, k_cache, v_cache, kv_lens, block_table, scale, soft_cap, splits, 0, part, None)
+    _launch(q, k_cache, v_cache, kv_lens, block_table, scale, soft_cap, splits, 0 if _splits_forced(kv_split) else 4, part, None)
     _combine(part, (D + 1, q_heads * splits * (D + 1), splits * (D + 1)), splits, batch, q_heads, D, None, out, 1, _dt(q))
     return out
 
@@ -177,7 +177,7 @@ def gqa_fwd_batch_decode_intra_rank(q, k_cache, v_cache, workspace, q_lens, kv_l
     # two launches: at small batch the split workgroups are so short that the in-kernel hand-off
     # of the fused form (drain + ticket per workgroup) costs more than the kernel boundary it
     # saves (batch 1, 32k tokens: 40 us vs 65 us on MI355X)
-    _launch(q, k_cache, v_cache, kv_lens, block_table, scale, soft_cap, splits, 0, part, None)
+    _launch(q, k_cache, v_cache, kv_lens, block_table, scale, soft_cap, splits, 0 if _splits_forced(kv_split) else 4, part, None)
     _combine(part, (D + 1, q_heads * splits * (D + 1), splits * (D + 1)), splits, batch, q_heads, D, None, out, 2, _dt(q))
     return out
 
@@ -215,16 +215,19 @@ def decode_step_from_qkv(qkv: torch.Tensor, q_w: Optional[torch.Tensor], k_w: Op
                          k_eps: float, position_ids: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
                          k_cache: torch.Tensor, v_cache: torch.Tensor, kv_offset: torch.Tensor, total_out: torch.Tensor,
                          num_q_heads: int, num_kv_heads: int, seq_table: Optional[torch.Tensor] = None,
-                         scale: Optional[float] = None, kv_split: int = -1) -> torch.Tensor:
-    """One launch from the QKV projection of a decode step to the attention output.
+                         scale: Optional[float] = None, kv_split: int = -1,
+                         one_launch: Optional[bool] = None) -> torch.Tensor:
+    """From the QKV projection of a decode step to the attention output without a launch for the projection's epilogue.
 
     ``qkv [B, 1, (Hq + 2 Hkv) * 128]``: q / k heads get their optional per-head RMSNorm and the neox rotation at
     ``position_ids [B, 1]``, K / V of the new token go to slot ``kv_offset[b]`` of ``k_cache / v_cache
     [B, max_len, Hkv, 128]``, ``total_out[b] = kv_offset[b] + 1`` and the token attends over those tokens.
     Returns ``[B, Hq, 128]``.  The same arithmetic as ``elementwise.qkv_prep`` followed by
     ``gqa_fwd_batch_decode_persistent`` - the workgroups of the attention kernel prepare their own heads
-    (csrc/include/tdist/flash_decode_device.hpp, PREP) - without the launch in between.  Call
-    ``decode_step_from_qkv_supported`` first."""
+    (csrc/include/tdist/flash_decode_device.hpp, PREP) - without the launch in between.  The splits are merged by
+    a second, head-parallel launch (default; ahead of the in-kernel merge at every measured shape once the step
+    sits in a HIP graph) or by the last workgroup of each head block (``one_launch`` / TDIST_DECODE_ONE_LAUNCH=1).
+    Call ``decode_step_from_qkv_supported`` first."""
     B, D = qkv.shape[0], 128
     max_len = k_cache.shape[1]
     assert kv_offset.dtype == torch.int32 and total_out.dtype == torch.int32 and kv_offset.numel() >= B
@@ -238,11 +241,12 @@ def decode_step_from_qkv(qkv: torch.Tensor, q_w: Optional[torch.Tensor], k_w: Op
     assert seq_table.dtype == torch.int32 and seq_table.numel() >= B
     for w in (q_w, k_w):
         assert w is None or (w.dtype == torch.bfloat16 and w.numel() == D and w.is_contiguous())
+    fused = ONE_LAUNCH if one_launch is None else bool(one_launch)
     splits = int(kv_split) if kv_split and kv_split > 0 else \
-        int(os.environ.get("TDIST_DECODE_KV_SPLITS", "0")) or auto_kv_splits(B, num_q_heads, num_kv_heads, max_len, fused=True)
+        int(os.environ.get("TDIST_DECODE_KV_SPLITS", "0")) or auto_kv_splits(B, num_q_heads, num_kv_heads, max_len, fused=fused)
     part = torch.empty((B, num_q_heads, splits, D + 1), dtype=torch.float32, device=qkv.device)
     out = torch.empty((B, num_q_heads, D), dtype=qkv.dtype, device=qkv.device)
-    tick = _tickets(qkv.device, B * num_kv_heads * ((num_q_heads // num_kv_heads + 15) // 16))
+    tick = _tickets(qkv.device, B * num_kv_heads * ((num_q_heads // num_kv_heads + 15) // 16)) if fused else None
     _lib.check(
         _lib.hip().tdist_flash_decode_prep(
             _lib.ptr(qkv), ctypes.c_longlong(qkv.stride(0)), _lib.ptr(q_w), _lib.ptr(k_w), ctypes.c_float(q_eps),
@@ -250,7 +254,9 @@ def decode_step_from_qkv(qkv: torch.Tensor, q_w: Optional[torch.Tensor], k_w: Op
             _lib.ptr(kv_offset), _lib.ptr(total_out), _lib.ptr(seq_table), _lib.ptr(part), _lib.ptr(out), _lib.ptr(tick),
             B, num_q_heads, num_kv_heads, ctypes.c_longlong(max_len), splits, ctypes.c_longlong(out.stride(0)),
             ctypes.c_longlong(out.stride(1)), ctypes.c_float(scale if scale is not None else 1.0 / math.sqrt(D)),
-            0 if _splits_forced(kv_split) else 1, _lib.stream_handle()), "tdist_flash_decode_prep")
+            0 if _splits_forced(kv_split) else 1, 1 if fused else 0, _lib.stream_handle()), "tdist_flash_decode_prep")
+    if not fused:
+        _combine(part, (D + 1, num_q_heads * splits * (D + 1), splits * (D + 1)), splits, B, num_q_heads, D, None, out, 1, 0)
     return out
 
 
