@@ -8,6 +8,8 @@
 // and my_lab/benchmark/layer.py:20-64 (y = x W^T).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "tdist/common.hpp"
 #include "tdist/gemm_gfx950.hpp"
 #include "tdist/wg_trace.hpp"
@@ -283,24 +285,52 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const uint16_t*
   // (Walking K from a per-workgroup rotated start, against power-of-two row strides all starting on
   // the same HBM channel, was measured: no gain at N x K = 12800 x 8192, 3-6 % slower at 32768 x 4096.)
   const int nfull = (ks1 - ks0) / U;
-  // The pre-pass holds workgroup barriers: every wave runs it exactly once - behind its first batch of weight
-  // loads when it has a full batch, in front of the loop otherwise.
-  if (nfull == 0) norm_prepass();
-  for (int bi = 0; bi < nfull; ++bi) {
-    const int ks = ks0 + bi * U;
-    u32x4 wv[U][WN], xv[U];
+  // Full batches of U K-steps run as a rolling window of two halves: when a half has been multiplied, its slots
+  // are reloaded for the next batch at once, so U / 2 .. U K-steps of weight loads stay in flight from the first
+  // batch to the last (issuing a whole batch only after the previous one was consumed drained the memory pipe
+  // between batches).  The norm pre-pass holds workgroup barriers: every wave runs it exactly once - behind its
+  // first batch of weight loads when it has a full batch, in front of the tail loop otherwise.
+  constexpr int H = U / 2;
+  u32x4 wv[U][WN], xv[U];
+  auto issue = [&](int ks, auto u0c) {
+    constexpr int u0 = decltype(u0c)::value;
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+    for (int u = u0; u < u0 + H; ++u)
 #pragma unroll
       for (int j = 0; j < WN; ++j) wv[u][j] = __builtin_nontemporal_load((const u32x4*)(wr[j] + (ks + u) * 32));
-    if (bi == 0) norm_prepass();
+    if constexpr (!NORM) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) xv[u] = load_x(ks + u);
+      for (int u = u0; u < u0 + H; ++u) xv[u] = load_x(ks + u);
+    }
+  };
+  auto consume = [&](int ks, auto u0c) {
+    constexpr int u0 = decltype(u0c)::value;
+    if constexpr (NORM) {
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+      for (int u = u0; u < u0 + H; ++u) xv[u] = load_x(ks + u);
+    }
+#pragma unroll
+    for (int u = u0; u < u0 + H; ++u)
 #pragma unroll
       for (int j = 0; j < WN; ++j)
         acc[j] = F::mfma(__builtin_bit_cast(VT, xv[u]), __builtin_bit_cast(VT, wv[u][j]), acc[j]);
+  };
+  using C0 = std::integral_constant<int, 0>;
+  using CH = std::integral_constant<int, H>;
+  if (nfull == 0) {
+    norm_prepass();
+  } else {
+    issue(ks0, C0{});
+    issue(ks0, CH{});
+    norm_prepass();
+    for (int bi = 0; bi < nfull; ++bi) {
+      const int ks = ks0 + bi * U;
+      const bool more = bi + 1 < nfull;
+      consume(ks, C0{});
+      if (more) issue(ks + U, C0{});
+      consume(ks, CH{});
+      if (more) issue(ks + U, CH{});
+    }
   }
   for (int ks = ks0 + nfull * U; ks < ks1; ++ks) {
     const u32x4 xv = load_x(ks);
