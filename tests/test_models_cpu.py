@@ -85,3 +85,25 @@ def test_sample_token_top_p_and_argmax():
         assert sample_token(logits, temperature=0.5, top_p=0.5).tolist() == [[1], [0]]
     tok = sample_token(torch.zeros(3, 16), temperature=1.0, top_p=1.0, top_k=4)
     assert tok.shape == (3, 1) and int(tok.max()) < 16
+
+
+def test_moe_golden_without_expert_loop_matches_the_loop():
+    """TP_MoE.torch_fwd_no_loop (gathered expert weights, one batched product, no host synchronisation - the form a
+    decode step can capture) against the loop over experts, fp32 on the CPU."""
+    from types import SimpleNamespace
+
+    from triton_distributed_gh_amd.layers import TP_MoE
+
+    torch.manual_seed(3)
+    H, I, E, topk, T = 64, 96, 8, 2, 10
+    lin = lambda o, i: SimpleNamespace(weight=(torch.rand(o, i) * 2 - 1) * 0.2, bias=None)   # noqa: E731
+    tree = SimpleNamespace(num_experts=E, top_k=topk, norm_topk_prob=True, gate=lin(E, H),
+                           experts=[SimpleNamespace(gate_proj=lin(I, H), up_proj=lin(I, H), down_proj=lin(H, I),
+                                                    act_fn=torch.nn.functional.silu) for _ in range(E)])
+    moe = TP_MoE(rank=0, world_size=1)
+    moe._init_parameters(tree)
+    x = torch.rand(2, T // 2, H) * 2 - 1
+    ref = moe.torch_fwd(x)
+    got = moe.torch_fwd_no_loop(x)
+    assert got.shape == x.shape
+    torch.testing.assert_close(got, ref, atol=1e-5, rtol=1e-4)

@@ -107,3 +107,30 @@ def test_moe_reduce_rs(w, ntokens, hidden, K, E, topk, n_chunks):
                                          magnitude=mag[r * tpr:(r + 1) * tpr])
     finally:
         vc.close()
+
+
+@pytest.mark.parametrize("n,H,I,E,topk", [(1, 2048, 768, 128, 8), (4, 2048, 768, 128, 8), (16, 512, 256, 16, 2),
+                                          (3, 4096, 1536, 32, 8), (2, 1024, 96, 8, 3), (5, 512, 256, 16, 10)])
+def test_moe_decode_kernels_match_fp32_reference(n, H, I, E, topk):
+    """The two decode launches (per-pair decode GEMM with SiLU; down projection with the routing weights and the
+    top-k sum folded into the reduction over waves) against fp32 PyTorch, element by element."""
+    from triton_distributed_gh_amd.ops.moe import moe_decode_fwd, moe_decode_supported
+
+    torch.manual_seed(n * 100 + topk)
+    dev, bf = "cuda", torch.bfloat16
+    x = (torch.rand(n, H, device=dev) * 2 - 1).to(bf)
+    gate_up = ((torch.rand(E, 2 * I, H, device=dev) * 2 - 1) * 0.05).to(bf)
+    down = ((torch.rand(E, H, I, device=dev) * 2 - 1) * 0.05).to(bf)
+    ids = torch.stack([torch.randperm(E, device=dev)[:topk] for _ in range(n)])
+    wts = torch.rand(n, topk, device=dev) + 0.1
+    wts = wts / wts.sum(-1, keepdim=True)
+    assert moe_decode_supported(x, gate_up, down, topk)
+    out = moe_decode_fwd(x, ids, wts, gate_up, down)
+    ref = torch.zeros(n, H, device=dev)
+    for t in range(n):
+        for k in range(topk):
+            e = int(ids[t, k])
+            gu = gate_up[e].float() @ x[t].float()
+            h = (torch.nn.functional.silu(gu[:I].to(bf).float()) * gu[I:].to(bf).float()).to(bf).float()
+            ref[t] += wts[t, k] * (down[e].float() @ h)
+    torch.testing.assert_close(out.float(), ref, atol=2e-2 * ref.abs().max().item(), rtol=2e-2)

@@ -211,8 +211,18 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const uint16_t*
                                                              long long ldx, long long ldw, long long ldc,
                                                              const uint16_t* __restrict__ R = nullptr,
                                                              const uint16_t* __restrict__ G = nullptr,
-                                                             uint16_t* __restrict__ Hout = nullptr, float eps = 0.f) {
+                                                             uint16_t* __restrict__ Hout = nullptr, float eps = 0.f,
+                                                             const int* __restrict__ gid = nullptr, int gdiv = 1,
+                                                             long long gstride = 0) {
   static_assert(!NORM || IS_BF16, "the fused norm is built for bf16");
+  // Grouped form (MoE decode): blockIdx.y = (token, expert) pair p; the pair multiplies row p / gdiv of X with the
+  // weights of expert gid[p] (gstride elements apart) into row p of C.
+  if (gid) {
+    const int p = blockIdx.y;
+    W += (long long)gid[p] * gstride;
+    X += (long long)(p / gdiv) * ldx;
+    C += (long long)p * ldc;
+  }
   using F = Frag<IS_BF16>;
   using VT = typename F::T;
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -460,6 +470,97 @@ TDIST_API int tdist_gemm_nt_norm(const void* X, const void* R, const void* G, fl
       hipLaunchKernelGGL((gemm_nt_skinny_kernel<true, 1, 4, false, true>), grid, dim3(256), (size_t)lds, s, x, w, c, M, N, K, ldx,
                          ldw, ldc, r, g, h, eps);
   }
+  TDIST_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// MoE decode, second half: out[t, :] = sum_k wts[t, k] * down[ids[t, k]] @ h[t * topk + k, :]  (bf16).
+// One workgroup per (16 output columns, token); wave k streams the 16 rows of expert ids[t, k] (Ip long) through
+// 16x16x32 MFMAs whose M dimension holds the single activation row, scales its partial sums by the routing weight
+// and the waves are summed through LDS: the top-k reduction costs nothing extra and no [pairs, H] intermediate
+// exists.  Loads run as a rolling window of two 8-K-step buffers.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void moe_decode_down_kernel(const uint16_t* __restrict__ hbuf,
+                                                                  const int* __restrict__ ids,
+                                                                  const float* __restrict__ wts,
+                                                                  const uint16_t* __restrict__ down,
+                                                                  uint16_t* __restrict__ out, int topk, int H, int Ip) {
+  using F = Frag<true>;
+  using VT = typename F::T;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  __shared__ float red[NW * 16];
+  const int t = blockIdx.y, n0 = blockIdx.x * 16;
+  const int wk = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int li = lane & 15, lg = lane >> 4;
+  const int ksteps = Ip / 32;
+  float part = 0.f;
+  for (int kk = wk; kk < topk; kk += NW) {
+    const int p = t * topk + kk;
+    const int e = ids[p];
+    const float wgt = wts[p];
+    const uint16_t* wr = down + ((long long)e * H + min(n0 + li, H - 1)) * Ip + lg * 8;
+    const uint16_t* xr = hbuf + (long long)p * Ip + lg * 8;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    u32x4 wa[8], wb[8];
+    auto ld = [&](u32x4(&w)[8], int ks0) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        w[u] = u32x4{0, 0, 0, 0};
+        if (ks0 + u < ksteps) w[u] = __builtin_nontemporal_load((const u32x4*)(wr + (ks0 + u) * 32));
+      }
+    };
+    auto mm = [&](const u32x4(&w)[8], int ks0) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (ks0 + u < ksteps) {
+          const u32x4 x = li == 0 ? *(const u32x4*)(xr + (ks0 + u) * 32) : u32x4{0, 0, 0, 0};
+          acc = F::mfma(__builtin_bit_cast(VT, x), __builtin_bit_cast(VT, w[u]), acc);
+        }
+      }
+    };
+    ld(wa, 0);
+    for (int ks0 = 0; ks0 < ksteps; ks0 += 16) {
+      ld(wb, ks0 + 8);
+      mm(wa, ks0);
+      ld(wa, ks0 + 16);
+      mm(wb, ks0 + 8);
+    }
+    part += wgt * acc[0];          // accumulator row 0 (the token) lives in lanes lg == 0, column li
+  }
+  if (lg == 0) red[wk * 16 + li] = part;
+  __syncthreads();
+  if (threadIdx.x < 16 && n0 + (int)threadIdx.x < H) {
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) sum += red[q * 16 + threadIdx.x];
+    out[(long long)t * H + n0 + threadIdx.x] = __builtin_bit_cast(uint16_t, (__bf16)sum);
+  }
+}
+
+// MoE decode, first half: hbuf[p, :] = silu(x[t] @ gate[e]^T) * (x[t] @ up[e]^T) for every (token t, expert
+// e = ids[p]) pair p = t * topk + k.  gate_up [E, 2 Ip, H] (gate rows first), x [tokens, H], hbuf [pairs, Ip]; bf16.
+// The decode GEMM with its fused activation, one grid row per pair.
+TDIST_API int tdist_moe_decode_gate_up(const void* x, const int* ids, const void* gate_up, void* hbuf, int tokens,
+                                       int topk, int Ip, int H, void* stream) {
+  TDIST_REQUIRE(tokens > 0 && topk > 0 && (long long)tokens * topk <= 65535, "bad token / top-k count");
+  TDIST_REQUIRE(H >= 128 && H % 32 == 0 && Ip > 0 && Ip % 16 == 0, "H must be a multiple of 32 (>= 128), Ip of 16");
+  TDIST_REQUIRE((((uintptr_t)x | (uintptr_t)gate_up) & 15) == 0 && (((uintptr_t)hbuf) & 3) == 0 && ids, "operands must be aligned");
+  hipLaunchKernelGGL((gemm_nt_skinny_kernel<true, 2, 4, true>), dim3(Ip / 16, tokens * topk), dim3(256), 0,
+                     (hipStream_t)stream, (const uint16_t*)x, (const uint16_t*)gate_up, (uint16_t*)hbuf, 1, Ip, H,
+                     (long long)H, (long long)H, (long long)Ip, (const uint16_t*)nullptr, (const uint16_t*)nullptr,
+                     (uint16_t*)nullptr, 0.f, ids, topk, (long long)2 * Ip * H);
+  TDIST_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// out [tokens, H] = sum over the top-k experts of wts * down[e] @ hbuf[pair] (see moe_decode_down_kernel).
+TDIST_API int tdist_moe_decode_down(const void* hbuf, const int* ids, const float* wts, const void* down, void* out,
+                                    int tokens, int topk, int H, int Ip, void* stream) {
+  TDIST_REQUIRE(tokens > 0 && tokens <= 65535 && topk > 0, "bad token / top-k count");
+  TDIST_REQUIRE(Ip >= 32 && Ip % 32 == 0 && H > 0, "Ip must be a multiple of 32");
+  TDIST_REQUIRE((((uintptr_t)hbuf | (uintptr_t)down) & 15) == 0 && ids && wts && out, "operands must be aligned");
+  hipLaunchKernelGGL((moe_decode_down_kernel<8>), dim3((H + 15) / 16, tokens), dim3(512), 0, (hipStream_t)stream,
+                     (const uint16_t*)hbuf, ids, wts, (const uint16_t*)down, (uint16_t*)out, topk, H, Ip);
   TDIST_HIP_TRY(hipGetLastError());
   return 0;
 }

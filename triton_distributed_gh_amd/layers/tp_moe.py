@@ -18,7 +18,8 @@ import torch
 
 from ..ops import elementwise
 from ..ops.allgather import create_fast_allgather_context, fast_allgather
-from ..ops.moe import ag_group_gemm, create_ag_group_gemm_context, create_moe_rs_context, run_moe_reduce_rs
+from ..ops.moe import (ag_group_gemm, create_ag_group_gemm_context, create_moe_rs_context, moe_decode_fwd,
+                       moe_decode_supported, run_moe_reduce_rs)
 from ..utils.distributed import get_env
 from .tp_mlp import shard_local
 
@@ -113,9 +114,14 @@ class TP_MoE:
 
     @torch.inference_mode()
     def torch_fwd(self, x):
-        """Golden: loop over experts, x replicated [bsz, seq, H]; output all-reduced."""
+        """Golden: loop over experts, x replicated [bsz, seq, H]; output all-reduced.  A call made while a HIP graph
+        is being captured, where the loop's ``torch.where`` would have to synchronise, takes ``torch_fwd_no_loop``
+        (same arithmetic up to the order of the top-k sum; a randomly initialised MoE model amplifies even that
+        through flipped routing decisions, so eager goldens stay on the loop)."""
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
+        if x.is_cuda and torch.cuda.is_current_stream_capturing():
+            return self.torch_fwd_no_loop(x)
         wts, ids = self._route(x2)
         wts = wts.to(x.dtype)
         Ip = self.inter_padded
@@ -132,7 +138,28 @@ class TP_MoE:
             torch.distributed.all_reduce(out, torch.distributed.ReduceOp.SUM, group=self.group)
         return out.view(shape)
 
-    torch_fwd_no_loop = torch_fwd
+    @torch.inference_mode()
+    def torch_fwd_no_loop(self, x):
+        """The same result without a loop over experts and without a host synchronisation (reference:
+        layers/nvidia/tp_moe.py torch_fwd_no_loop): the weights of every (token, expert) pair are gathered and
+        multiplied as one batch, 3 x I x H x 2 bytes per pair, so this is for decode-sized inputs."""
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1])
+        wts, ids = self._route(x2)
+        n, k = ids.shape
+        Ip = self.inter_padded
+        flat = ids.reshape(-1)
+        xk = x2.repeat_interleave(k, 0).unsqueeze(2)                       # [n k, H, 1]
+        h = torch.bmm(self.gate_up_proj[flat], xk).squeeze(2)               # [n k, 2 Ip]
+        h = torch.nn.functional.silu(h[:, :Ip]) * h[:, Ip:]
+        o = torch.bmm(self.down_proj[flat], h.unsqueeze(2)).squeeze(2)      # [n k, H]
+        o = o.view(n, k, -1) * wts.to(x.dtype).unsqueeze(-1)                # rounded like the loop's products
+        out = o[:, 0]
+        for j in range(1, k):
+            out = out + o[:, j]
+        if self.world_size > 1 and torch.distributed.is_initialized():
+            torch.distributed.all_reduce(out, torch.distributed.ReduceOp.SUM, group=self.group)
+        return out.view(shape)
 
     def _gather_meta(self, wts: torch.Tensor, ids: torch.Tensor):
         w = self.world_size
@@ -156,6 +183,9 @@ class TP_MoE:
         shape = x.shape
         x2 = x.reshape(-1, shape[-1]).contiguous()
         wts, ids = self._route(x2)
+        if self.world_size == 1 and moe_decode_supported(x2, self.gate_up_proj, self.down_proj, self.top_k):
+            # a decode step: two weight-streaming launches over the tokens' own experts (ops/moe.py: moe_decode_fwd)
+            return moe_decode_fwd(x2, ids, wts, self.gate_up_proj, self.down_proj).view(shape)
         full_w, full_ids = self._gather_meta(wts, ids)
         h = self.ag_group_gemm(x2, self.gate_up_proj, ctx=self.ag_ctx, full_topk_ids=full_ids.contiguous())
         h = self._act(h)

@@ -457,3 +457,45 @@ def run_moe_reduce_rs(x: torch.Tensor, weights: torch.Tensor, chosen_experts: to
             reduce_rs(c, c0, nc)
     main.wait_stream(side)
     return out
+
+
+# ---- decode: a handful of tokens against their top-k experts ------------------------------------------------
+MOE_DECODE_MAX_TOKENS = int(os.environ.get("TDIST_MOE_DECODE_MAX_TOKENS", "16"))
+
+
+def moe_decode_supported(x: torch.Tensor, gate_up: torch.Tensor, down: torch.Tensor, topk: int) -> bool:
+    """Shapes the two decode kernels take: bf16 on the GPU, at most ``MOE_DECODE_MAX_TOKENS`` tokens, expert weights
+    ``gate_up [E, 2 Ip, H]`` / ``down [E, H, Ip]`` contiguous, H a multiple of 32, Ip of 32."""
+    if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.bfloat16 == gate_up.dtype == down.dtype):
+        return False
+    n, H = x.shape
+    E, two_ip, H2 = gate_up.shape
+    Ip = two_ip // 2
+    return (0 < n <= MOE_DECODE_MAX_TOKENS and H2 == H and tuple(down.shape) == (E, H, Ip) and H % 32 == 0 and H >= 128
+            and Ip % 32 == 0 and gate_up.is_contiguous() and down.is_contiguous() and x.is_contiguous()
+            and n * topk <= 65535)
+
+
+def moe_decode_fwd(x: torch.Tensor, topk_ids: torch.Tensor, topk_weights: torch.Tensor, gate_up: torch.Tensor,
+                   down: torch.Tensor) -> torch.Tensor:
+    """``out[t] = sum_k w[t, k] * down[e] @ (silu(gate[e] x[t]) * (up[e] x[t]))`` with ``e = topk_ids[t, k]``.
+
+    The MoE block of a decode step as two weight-streaming launches (csrc/ops/gemm.hip): one decode GEMM with fused
+    SiLU per (token, expert) pair, then one kernel whose eight waves stream the ``down`` rows of the token's experts
+    and fold the routing weights and the top-k sum into their reduction.  Nothing is sorted, padded to tiles or
+    gathered: the grouped-GEMM path (``ag_group_gemm`` + ``run_moe_reduce_rs``) costs about 250 us per layer for
+    one token of Qwen3-30B-A3B, these two launches stream the same 75 MB of expert weights.
+    Reference role: layers/nvidia/tp_moe.py at decode sizes (it has no special case)."""
+    n, H = x.shape
+    k = topk_ids.shape[1]
+    Ip = gate_up.shape[1] // 2
+    ids = topk_ids.to(torch.int32).contiguous()
+    wts = topk_weights.to(torch.float32).contiguous()
+    hbuf = torch.empty((n * k, Ip), dtype=x.dtype, device=x.device)
+    out = torch.empty((n, H), dtype=x.dtype, device=x.device)
+    lib = _lib.hip()
+    _lib.check(lib.tdist_moe_decode_gate_up(_lib.ptr(x), _lib.ptr(ids), _lib.ptr(gate_up), _lib.ptr(hbuf), n, k, Ip, H,
+                                            _lib.stream_handle()), "tdist_moe_decode_gate_up")
+    _lib.check(lib.tdist_moe_decode_down(_lib.ptr(hbuf), _lib.ptr(ids), _lib.ptr(wts), _lib.ptr(down), _lib.ptr(out),
+                                         n, k, H, Ip, _lib.stream_handle()), "tdist_moe_decode_down")
+    return out
