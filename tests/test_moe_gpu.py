@@ -134,3 +134,35 @@ def test_moe_decode_kernels_match_fp32_reference(n, H, I, E, topk):
             h = (torch.nn.functional.silu(gu[:I].to(bf).float()) * gu[I:].to(bf).float()).to(bf).float()
             ref[t] += wts[t, k] * (down[e].float() @ h)
     torch.testing.assert_close(out.float(), ref, atol=2e-2 * ref.abs().max().item(), rtol=2e-2)
+
+
+@pytest.mark.parametrize("n,E,k,renorm", [(1, 128, 8, True), (7, 128, 8, False), (33, 8, 2, True), (4, 1000, 10, True),
+                                          (300, 64, 6, True), (2, 4, 4, True)])
+def test_router_epilogue_matches_torch_topk(n, E, k, renorm):
+    """Fused softmax + top-k + renormalisation against the torch lines it replaces, including rows full of ties
+    (bf16 logits collide often): same expert SET per token, same weight per chosen expert."""
+    from triton_distributed_gh_amd.ops.moe import moe_route, moe_route_supported
+
+    torch.manual_seed(n + E + k)
+    logits = (torch.randn(n, E, device="cuda") * 2).to(torch.bfloat16)
+    logits[0, : E // 2] = logits[0, 0]                                 # heavy ties in one row
+    if n > 1:
+        logits[1] = 0.5                                                # a row of equal logits: lowest indices win
+    assert moe_route_supported(logits, k)
+    wts, ids = moe_route(logits, k, renorm)
+    probs = torch.softmax(logits, dim=1, dtype=torch.float)
+    rw, rid = torch.topk(probs, k, dim=-1)
+    if renorm:
+        rw = rw / rw.sum(-1, keepdim=True)
+    assert ids.dtype == torch.int32 and wts.dtype == torch.float32
+    # the chosen probabilities agree position by position (descending order, ties have equal weights)
+    torch.testing.assert_close(wts, rw, atol=1e-6, rtol=1e-4)
+    for t in range(min(n, 40)):
+        got = set(ids[t].tolist())
+        assert len(got) == k
+        kth = probs[t][rid[t, -1]]
+        above = set(torch.nonzero(probs[t] > kth).flatten().tolist())
+        ties = torch.nonzero(probs[t] == kth).flatten().tolist()
+        assert above <= got and got - above == set(ties[: k - len(above)]), f"row {t}: {sorted(got)}"
+    if n > 1:
+        assert ids[1].tolist() == list(range(k))

@@ -647,3 +647,71 @@ TDIST_API int tdist_moe_topk_reduce_rs(const SymmCtx* ctx, const void* gemm_out,
   TDIST_HIP_TRY(hipGetLastError());
   return 0;
 }
+
+// ---- router epilogue: softmax over the experts, top-k, optional renormalisation ------------------------------------
+// One wave per token.  logits bf16 [tokens, E] (row stride ld) -> ids int32 [tokens, k], weights fp32 [tokens, k],
+// in descending order of probability.  Ties go to the lower expert index (the set torch.topk returns: everything
+// above the k-th value, then the k-th value's duplicates in index order).  Replaces five library launches
+// (upcast, softmax, top-k select, sort, sum, divide) of ~23 us per MoE layer at decode sizes with one of ~3 us.
+__global__ __launch_bounds__(64) void moe_route_kernel(const uint16_t* __restrict__ logits, long long ld, int E, int k,
+                                                       int renorm, int* __restrict__ ids, float* __restrict__ wts) {
+  constexpr int VPT = 16;                       // E <= 1024
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const uint16_t* row = logits + t * ld;
+  float v[VPT];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int j = 0; j < VPT; ++j) {
+    const int e = lane + 64 * j;
+    v[j] = e < E ? __builtin_bit_cast(float, (uint32_t)row[e] << 16) : -3.0e38f;
+    mx = fmaxf(mx, v[j]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float den = 0.f;
+#pragma unroll
+  for (int j = 0; j < VPT; ++j) {
+    v[j] = lane + 64 * j < E ? expf(v[j] - mx) : -1.f;      // probabilities are >= 0: -1 marks "not a candidate"
+    den += fmaxf(v[j], 0.f);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) den += __shfl_xor(den, o);
+  const float inv = 1.f / den;
+  int my_id = 0;
+  float my_w = 0.f, sum_w = 0.f;
+  for (int i = 0; i < k; ++i) {
+    float best = -2.f;
+    int bidx = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j)
+      if (v[j] > best) best = v[j], bidx = lane + 64 * j;          // ascending j: the lowest index of a lane's ties
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o);
+      const int oi = __shfl_xor(bidx, o);
+      if (ob > best || (ob == best && oi < bidx)) best = ob, bidx = oi;
+    }
+    if ((bidx & 63) == lane) {
+#pragma unroll
+      for (int j = 0; j < VPT; ++j)
+        if (j == (bidx >> 6)) v[j] = -1.f;
+    }
+    const float p = best * inv;
+    sum_w += p;
+    if (lane == i) my_id = bidx, my_w = p;
+  }
+  if (lane < k) {
+    ids[(long long)t * k + lane] = my_id;
+    wts[(long long)t * k + lane] = renorm ? my_w / sum_w : my_w;
+  }
+}
+
+TDIST_API int tdist_moe_route(const void* logits, long long ld, int tokens, int E, int k, int renorm, int* ids, float* wts,
+                              void* stream) {
+  TDIST_REQUIRE(tokens > 0 && E > 0 && E <= 1024 && k > 0 && k <= 64 && k <= E, "router: E <= 1024, k <= min(64, E)");
+  TDIST_REQUIRE(logits && ids && wts && ld >= E, "router: null argument / bad row stride");
+  hipLaunchKernelGGL(moe_route_kernel, dim3(tokens), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)logits, ld, E, k,
+                     renorm, ids, wts);
+  TDIST_HIP_TRY(hipGetLastError());
+  return 0;
+}

@@ -19,7 +19,7 @@ import torch
 from ..ops import elementwise
 from ..ops.allgather import create_fast_allgather_context, fast_allgather
 from ..ops.moe import (ag_group_gemm, create_ag_group_gemm_context, create_moe_rs_context, moe_decode_fwd,
-                       moe_decode_supported, run_moe_reduce_rs)
+                       moe_decode_supported, moe_route, moe_route_supported, run_moe_reduce_rs)
 from ..utils.distributed import get_env
 from .tp_mlp import shard_local
 
@@ -101,8 +101,10 @@ class TP_MoE:
     def finalize(self):
         self.ag_ctx = self.rs_ctx = None
 
-    def _route(self, x2: torch.Tensor):
+    def _route(self, x2: torch.Tensor, fused: bool = False):
         logits = torch.nn.functional.linear(x2, self.gate)
+        if fused and moe_route_supported(logits, self.top_k):
+            return moe_route(logits, self.top_k, self.norm_topk_prob)      # one launch (ops/moe.py)
         probs = torch.nn.functional.softmax(logits, dim=1, dtype=torch.float)
         wts, ids = torch.topk(probs, self.top_k, dim=-1)
         if self.norm_topk_prob:
@@ -182,7 +184,7 @@ class TP_MoE:
         """x token-sharded [bsz / w, seq, H] (or [tokens / w, H]) -> same shape."""
         shape = x.shape
         x2 = x.reshape(-1, shape[-1]).contiguous()
-        wts, ids = self._route(x2)
+        wts, ids = self._route(x2, fused=True)
         if self.world_size == 1 and moe_decode_supported(x2, self.gate_up_proj, self.down_proj, self.top_k):
             # a decode step: two weight-streaming launches over the tokens' own experts (ops/moe.py: moe_decode_fwd)
             return moe_decode_fwd(x2, ids, wts, self.gate_up_proj, self.down_proj).view(shape)

@@ -499,3 +499,22 @@ def moe_decode_fwd(x: torch.Tensor, topk_ids: torch.Tensor, topk_weights: torch.
     _lib.check(lib.tdist_moe_decode_down(_lib.ptr(hbuf), _lib.ptr(ids), _lib.ptr(wts), _lib.ptr(down), _lib.ptr(out),
                                          n, k, H, Ip, _lib.stream_handle()), "tdist_moe_decode_down")
     return out
+
+
+def moe_route_supported(logits: torch.Tensor, topk: int) -> bool:
+    return (logits.is_cuda and logits.dtype == torch.bfloat16 and logits.dim() == 2 and logits.stride(1) == 1
+            and logits.shape[1] <= 1024 and 0 < topk <= min(64, logits.shape[1]) and logits.shape[0] > 0)
+
+
+def moe_route(logits: torch.Tensor, topk: int, renormalize: bool = True):
+    """Router epilogue in one launch: softmax over the experts (fp32), top-k, optional renormalisation.
+    ``logits`` bf16 [tokens, E] -> (weights fp32 [tokens, k], ids int32 [tokens, k]), descending; ties go to the
+    lower expert index, the set ``torch.topk`` returns.  Reference: the softmax / topk / normalise lines of
+    layers/nvidia/tp_moe.py (five library launches here, ~23 us per MoE layer at decode sizes)."""
+    n = logits.shape[0]
+    ids = torch.empty((n, topk), dtype=torch.int32, device=logits.device)
+    wts = torch.empty((n, topk), dtype=torch.float32, device=logits.device)
+    _lib.check(_lib.hip().tdist_moe_route(_lib.ptr(logits), ctypes.c_longlong(logits.stride(0)), n, logits.shape[1], topk,
+                                          1 if renormalize else 0, _lib.ptr(ids), _lib.ptr(wts), _lib.stream_handle()),
+               "tdist_moe_route")
+    return wts, ids
