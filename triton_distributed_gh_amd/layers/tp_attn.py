@@ -200,13 +200,15 @@ class TP_Attn:
         """RMSNorm(x [+ residual]) -> this block: (block output, x + residual).  Decode-sized inputs of the modes
         whose QKV projection is a local GEMM run the norm inside that GEMM's launch (``gemm_nt_norm``)."""
         fn = getattr(self.fwd, "__func__", None)
-        if fn in (TP_Attn.dist_triton_AR_fwd, TP_Attn.dist_triton_gemm_ar_fwd):
+        # (on ONE rank the AG + GEMM / GEMM + RS mode is local GEMMs too: it takes the all-reduce form, minus the reduce)
+        solo = fn is TP_Attn.dist_triton_fwd and self.world_size == 1
+        if fn in (TP_Attn.dist_triton_AR_fwd, TP_Attn.dist_triton_gemm_ar_fwd) or solo:
             x2 = x.reshape(-1, x.shape[-1])
             r2 = residual.reshape(x2.shape) if residual is not None else None
             if norm_gemm_supported(x2, self.wqkv, norm_w, r2):
                 qkv, hidden = gemm_nt_norm(x2, norm_w, eps, self.wqkv, residual=r2)
                 shape = residual.shape if residual is not None else x.shape
-                out = self.fwd(x.reshape(shape), position_ids, cos_sin_cache, kv_cache, layer_idx,
-                               qkv=qkv.view(*shape[:-1], -1))
+                fwd = self.dist_triton_AR_fwd if solo else self.fwd
+                out = fwd(x.reshape(shape), position_ids, cos_sin_cache, kv_cache, layer_idx, qkv=qkv.view(*shape[:-1], -1))
                 return out, hidden.view(shape)
         return prenorm_generic(self, x, residual, norm_w, eps, position_ids, cos_sin_cache, kv_cache, layer_idx)

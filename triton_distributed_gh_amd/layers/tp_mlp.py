@@ -186,13 +186,15 @@ class TP_MLP:
         """RMSNorm(x [+ residual]) -> this block: (block output, x + residual).  Decode-sized inputs of the modes
         whose first projection is a local GEMM run the norm inside that GEMM's launch (``gemm_nt_norm``)."""
         fn = getattr(self.fwd, "__func__", None)
-        if fn in (TP_MLP.dist_triton_AR_fwd, TP_MLP.dist_triton_gemm_ar_fwd) and self._is_silu():
+        solo = fn is TP_MLP.dist_triton_fwd and self.world_size == 1      # one rank: local GEMMs, like the all-reduce form
+        if (fn in (TP_MLP.dist_triton_AR_fwd, TP_MLP.dist_triton_gemm_ar_fwd) or solo) and self._is_silu():
             x2 = x.reshape(-1, x.shape[-1])
             r2 = residual.reshape(x2.shape) if residual is not None else None
             if norm_gemm_supported(x2, self.gate_up_proj, norm_w, r2):
                 act, hidden = gemm_nt_norm(x2, norm_w, eps, self.gate_up_proj, residual=r2, silu=True)
                 shape = residual.shape if residual is not None else x.shape
-                return self.fwd(x.reshape(shape), act=act.view(*shape[:-1], -1)), hidden.view(shape)
+                fwd = self.dist_triton_AR_fwd if solo else self.fwd
+                return fwd(x.reshape(shape), act=act.view(*shape[:-1], -1)), hidden.view(shape)
         return prenorm_generic(self, x, residual, norm_w, eps)
 
     # ---- single-op helpers (used by the per-op tests / benchmarks) --------------------------------
