@@ -191,6 +191,80 @@ def test_tp_moe_matches_expert_loop(w, T, H, I, E, topk):
         vc.close()
 
 
+@pytest.mark.parametrize("w,T,H,I,E,topk", [(2, 8, 512, 512, 8, 2), (4, 16, 1024, 1024, 16, 4), (2, 2, 512, 512, 8, 8)])
+def test_tp_moe_decode_path_on_several_ranks(w, T, H, I, E, topk):
+    """A decode-sized batch on a tensor-parallel MoE layer: rows all-gathered, every rank runs all tokens against its
+    slice of the experts with the two decode launches, partial sums all-reduced - eagerly and replayed from a graph,
+    with a larger (grouped-GEMM) call in between."""
+    from triton_distributed_gh_amd.ops import moe as moe_ops
+
+    torch.manual_seed(5)
+    tree = SimpleNamespace(num_experts=E, top_k=topk, norm_topk_prob=True, gate=_lin(E, H, 1.0),
+                           experts=[_mlp_tree(H, I) for _ in range(E)])
+
+    def reference(x):
+        logits = x @ tree.gate.weight.t()
+        wts, ids = torch.topk(torch.softmax(logits, 1, dtype=torch.float), topk, dim=-1)
+        wts = wts / wts.sum(-1, keepdim=True)
+        ref = torch.zeros(x.shape[0], H, device="cuda")
+        for e in range(E):
+            tok, k = torch.where(ids == e)
+            if tok.numel():
+                ref.index_add_(0, tok, _mlp_ref(x[tok], tree.experts[e]) * wts[tok, k, None])
+        return ref
+
+    calls = {"n": 0}
+    real = moe_ops.moe_decode_fwd
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    vc = VirtualCluster(w, heap_bytes=1 << 28)
+    try:
+        import triton_distributed_gh_amd.layers.tp_moe as tp_moe_mod
+        tp_moe_mod.moe_decode_fwd = counted
+        moes = [TP_MoE(rank=r, world_size=w, env=vc.envs[r]) for r in range(w)]
+        for m in moes:
+            m._init_parameters(tree)
+        vc.collective(lambda r, env: moes[r]._init_ctx(256, ag_streams=[vc.side_streams[r]]))
+        per = T // w
+        xs = [torch.zeros(per, H, device="cuda", dtype=BF) for _ in range(w)]
+
+        def fill():
+            x = (torch.rand(T, H, device="cuda") * 2 - 1).to(BF)
+            for r in range(w):
+                xs[r].copy_(x[r * per:(r + 1) * per])
+            torch.cuda.synchronize()
+            return x
+
+        for it in range(3):
+            x = fill()
+            outs = vc.run(lambda r, env: moes[r].dist_triton_fwd(xs[r]))
+            assert _rel(torch.cat(outs), reference(x)) < 4e-2, f"eager {it}"
+        assert calls["n"] == 3 * w, "the decode launches ran on every rank"
+        # a prefill-sized call (grouped GEMM pair) between decode calls
+        big = (torch.rand(256, H, device="cuda") * 2 - 1).to(BF)
+        torch.cuda.synchronize()
+        outs = vc.run(lambda r, env: moes[r].dist_triton_fwd(big[r * (256 // w):(r + 1) * (256 // w)].contiguous()))
+        assert _rel(torch.cat(outs), reference(big)) < 4e-2
+        graphs, static = [], [None] * w
+        for r in range(w):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=vc.streams[r]):
+                static[r] = moes[r].dist_triton_fwd(xs[r])
+            graphs.append(g)
+        for it in range(4):
+            x = fill()
+            vc.run(lambda r, env: graphs[r].replay())
+            for m in moes:
+                m.dec_ar_ctx.check_error()
+            assert _rel(torch.cat(static), reference(x)) < 4e-2, f"replay {it}"
+    finally:
+        tp_moe_mod.moe_decode_fwd = real
+        vc.close()
+
+
 @pytest.mark.parametrize("w,T,H,I,E,topk", [(2, 256, 512, 512, 8, 2), (4, 64, 512, 512, 8, 2)])
 def test_tp_moe_replays_from_graph(w, T, H, I, E, topk):
     """The whole tensor-parallel MoE layer - router, low-latency all-gather of the routing data, AG + grouped

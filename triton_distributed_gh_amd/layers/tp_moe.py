@@ -18,7 +18,8 @@ import torch
 
 from ..ops import elementwise
 from ..ops.allgather import create_fast_allgather_context, fast_allgather
-from ..ops.moe import (ag_group_gemm, create_ag_group_gemm_context, create_moe_rs_context, moe_decode_fwd,
+from ..ops.allreduce import all_reduce, create_allreduce_ctx
+from ..ops.moe import (ag_group_gemm, create_ag_group_gemm_context, create_moe_rs_context, MOE_DECODE_MAX_TOKENS, moe_decode_fwd,
                        moe_decode_supported, moe_route, moe_route_supported, run_moe_reduce_rs)
 from ..utils.distributed import get_env
 from .tp_mlp import shard_local
@@ -97,6 +98,18 @@ class TP_MoE:
         self.meta_ctx = create_fast_allgather_context(self.rank, max_buffer_size=self.meta_bytes, env=self.env)
         self.meta_buf = env.heap.create_tensor([2, w, self.meta_bytes // 4], torch.int32)
         self.meta_state = {"calls": 0}     # shared by every layer that shares this context
+        # decode path on several ranks (``_decode_fwd_tp``): the tokens' rows are all-gathered (low-latency form),
+        # every rank runs ALL tokens against its slice of the experts' intermediate dimension, partial sums are
+        # all-reduced
+        self.dec_per = max(1, MOE_DECODE_MAX_TOKENS // w)
+        self.dec_x_ctx = self.dec_x_buf = self.dec_ar_ctx = None
+        if w > 1 and env.backend == "hip":
+            xb = self.dec_per * self.hidden_size * self.dtype.itemsize
+            self.dec_x_ctx = create_fast_allgather_context(self.rank, max_buffer_size=xb, env=self.env)
+            self.dec_x_buf = env.heap.create_tensor([2, w, xb // 4], torch.int32)
+            self.dec_ar_ctx = create_allreduce_ctx(workspace_nbytes=max(self.dec_per * w * self.hidden_size * self.dtype.itemsize,
+                                                                        1 << 16) * 2,
+                                                   rank=self.rank, world_size=w, local_world_size=w, env=self.env)
 
     def finalize(self):
         self.ag_ctx = self.rs_ctx = None
@@ -179,11 +192,30 @@ class TP_MoE:
         wts_full = full[:, n * k: 2 * n * k].view(torch.float32).reshape(w * n, k)
         return wts_full, ids_full
 
+    def _decode_fwd_tp(self, x2: torch.Tensor):
+        """At most ``MOE_DECODE_MAX_TOKENS`` tokens over all ranks, ``x2`` = this rank's rows: gather the rows, route
+        and run every token here against the local slice of the experts (``moe_decode_fwd``), all-reduce, keep the
+        own rows.  Every rank computes the same routing from the same gathered rows."""
+        w, n_local, H = self.world_size, x2.shape[0], x2.shape[1]
+        words = n_local * H * x2.element_size() // 4
+        full = self.dec_x_buf[self.meta_state["calls"] & 1]       # [w, words of dec_per rows]; parity as for meta_buf
+        self.meta_state["calls"] += 1
+        full[self.rank][:words].copy_(x2.view(torch.int32).reshape(-1))
+        fast_allgather(full, self.dec_x_ctx, mode="push_2d_ll")
+        xall = full[:, :words].reshape(-1).view(x2.dtype).view(w * n_local, H)
+        wts, ids = self._route(xall, fused=True)
+        part = moe_decode_fwd(xall, ids, wts, self.gate_up_proj, self.down_proj)
+        tot = all_reduce(part, ctx=self.dec_ar_ctx, output=torch.empty_like(part))
+        return tot[self.rank * n_local:(self.rank + 1) * n_local]
+
     @torch.inference_mode()
     def dist_triton_fwd(self, x: torch.Tensor):
         """x token-sharded [bsz / w, seq, H] (or [tokens / w, H]) -> same shape."""
         shape = x.shape
         x2 = x.reshape(-1, shape[-1]).contiguous()
+        if (self.world_size > 1 and getattr(self, "dec_x_buf", None) is not None and x2.shape[0] <= self.dec_per
+                and x2.shape[1] % 2 == 0 and moe_decode_supported(x2, self.gate_up_proj, self.down_proj, self.top_k)):
+            return self._decode_fwd_tp(x2).reshape(shape)
         wts, ids = self._route(x2, fused=True)
         if self.world_size == 1 and moe_decode_supported(x2, self.gate_up_proj, self.down_proj, self.top_k):
             # a decode step: two weight-streaming launches over the tokens' own experts (ops/moe.py: moe_decode_fwd)

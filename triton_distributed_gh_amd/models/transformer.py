@@ -158,7 +158,7 @@ class TPTransformer:
         if self.model_type == "moe":
             first.mlp._init_ctx(M=max_M)
             self._share(("ag_ctx", "rs_ctx"), ("ag_ctx", "rs_ctx", "meta_ctx", "meta_buf", "meta_bytes", "meta_state",
-                                               "max_M"))
+                                               "max_M", "dec_per", "dec_x_ctx", "dec_x_buf", "dec_ar_ctx"))
         else:
             first.mlp._init_ctx(max_M=max_M)
             self._share(("ag_ctx", "rs_ctx"), ("ag_ctx", "rs_ctx"))
