@@ -501,29 +501,31 @@ __global__ __launch_bounds__(64 * NW) void moe_decode_down_kernel(const uint16_t
     const uint16_t* wr = down + ((long long)e * H + min(n0 + li, H - 1)) * Ip + lg * 8;
     const uint16_t* xr = hbuf + (long long)p * Ip + lg * 8;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    u32x4 wa[8], wb[8];
-    auto ld = [&](u32x4(&w)[8], int ks0) {
+    // (the activation fragments are loaded WITH the weights they meet: fetched at multiply time, each group of
+    // eight paid an L2 round trip after its weights had already arrived)
+    u32x4 wa[8], wb[8], xa[8], xb[8];
+    auto ld = [&](u32x4(&w)[8], u32x4(&x)[8], int ks0) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         w[u] = u32x4{0, 0, 0, 0};
-        if (ks0 + u < ksteps) w[u] = __builtin_nontemporal_load((const u32x4*)(wr + (ks0 + u) * 32));
-      }
-    };
-    auto mm = [&](const u32x4(&w)[8], int ks0) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
+        x[u] = u32x4{0, 0, 0, 0};
         if (ks0 + u < ksteps) {
-          const u32x4 x = li == 0 ? *(const u32x4*)(xr + (ks0 + u) * 32) : u32x4{0, 0, 0, 0};
-          acc = F::mfma(__builtin_bit_cast(VT, x), __builtin_bit_cast(VT, w[u]), acc);
+          w[u] = __builtin_nontemporal_load((const u32x4*)(wr + (ks0 + u) * 32));
+          if (li == 0) x[u] = *(const u32x4*)(xr + (ks0 + u) * 32);
         }
       }
     };
-    ld(wa, 0);
+    auto mm = [&](const u32x4(&w)[8], const u32x4(&x)[8], int ks0) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (ks0 + u < ksteps) acc = F::mfma(__builtin_bit_cast(VT, x[u]), __builtin_bit_cast(VT, w[u]), acc);
+    };
+    ld(wa, xa, 0);
     for (int ks0 = 0; ks0 < ksteps; ks0 += 16) {
-      ld(wb, ks0 + 8);
-      mm(wa, ks0);
-      ld(wa, ks0 + 16);
-      mm(wb, ks0 + 8);
+      ld(wb, xb, ks0 + 8);
+      mm(wa, xa, ks0);
+      ld(wa, xa, ks0 + 16);
+      mm(wb, xb, ks0 + 8);
     }
     part += wgt * acc[0];          // accumulator row 0 (the token) lives in lanes lg == 0, column li
   }
