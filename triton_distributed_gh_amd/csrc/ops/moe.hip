@@ -653,9 +653,9 @@ TDIST_API int tdist_moe_topk_reduce_rs(const SymmCtx* ctx, const void* gemm_out,
 // in descending order of probability.  Ties go to the lower expert index (the set torch.topk returns: everything
 // above the k-th value, then the k-th value's duplicates in index order).  Replaces five library launches
 // (upcast, softmax, top-k select, sort, sum, divide) of ~23 us per MoE layer at decode sizes with one of ~3 us.
+template <int VPT>                              // values per lane: E <= 64 * VPT
 __global__ __launch_bounds__(64) void moe_route_kernel(const uint16_t* __restrict__ logits, long long ld, int E, int k,
                                                        int renorm, int* __restrict__ ids, float* __restrict__ wts) {
-  constexpr int VPT = 16;                       // E <= 1024
   const int t = blockIdx.x, lane = threadIdx.x;
   const uint16_t* row = logits + t * ld;
   float v[VPT];
@@ -710,8 +710,14 @@ TDIST_API int tdist_moe_route(const void* logits, long long ld, int tokens, int 
                               void* stream) {
   TDIST_REQUIRE(tokens > 0 && E > 0 && E <= 1024 && k > 0 && k <= 64 && k <= E, "router: E <= 1024, k <= min(64, E)");
   TDIST_REQUIRE(logits && ids && wts && ld >= E, "router: null argument / bad row stride");
-  hipLaunchKernelGGL(moe_route_kernel, dim3(tokens), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)logits, ld, E, k,
-                     renorm, ids, wts);
+  auto launch = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3(tokens), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)logits, ld, E, k, renorm,
+                       ids, wts);
+  };
+  if (E <= 128) launch(moe_route_kernel<2>);
+  else if (E <= 256) launch(moe_route_kernel<4>);
+  else if (E <= 512) launch(moe_route_kernel<8>);
+  else launch(moe_route_kernel<16>);
   TDIST_HIP_TRY(hipGetLastError());
   return 0;
 }
