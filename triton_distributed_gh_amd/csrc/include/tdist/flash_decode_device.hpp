@@ -51,7 +51,7 @@ struct DecodeArgs {
   // 1 (the grid was sized from the cache CAPACITY): a sequence uses as many of the `splits` as its own length calls
   // for - fused launches min(splits, ~sqrt(kv_len / 32)), the optimum of streaming ~ L / s against merging ~ s in one
   // workgroup, and the workgroups of later splits leave at once; launches with a separate merge kernel
-  // min(splits, kv_len / 128), and later splits write empty partial rows
+  // min(splits, ~sqrt(kv_len / 16), kv_len / 128), and later splits write empty partial rows
   int adaptive = 0;
 };
 
@@ -336,7 +336,8 @@ __device__ __forceinline__ int decode_split_body(const DecodeArgs& a, const int 
   }
   int nsplit = a.splits;
   if (a.adaptive) {
-    nsplit = min(nsplit, max(1, a.fused ? (int)(__builtin_sqrtf((float)kv_len * (1.f / 32.f)) + 0.5f) : kv_len >> 7));
+    nsplit = min(nsplit, max(1, (int)(__builtin_sqrtf((float)kv_len * (a.fused ? 1.f / 32.f : 1.f / 16.f)) + 0.5f)));
+    if (!a.fused) nsplit = min(nsplit, max(1, kv_len >> 7));
     if (a.fused && z >= nsplit) return nsplit;
   }
   const int per = (((kv_len + nsplit - 1) / nsplit) + 31) & ~31;

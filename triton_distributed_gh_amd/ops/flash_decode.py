@@ -44,8 +44,9 @@ def auto_kv_splits(batch: int, q_heads: int, kv_heads: int, max_kv_len: int, num
     the chip: at most ``num_cus / (batch * kv_heads * head_blocks)`` splits.  Inside that bound, measured on
     MI355X with cold K / V (scripts/dev/probe_decode_splits.py, 32 / 8 heads, HIP graph):
 
-    * two launches (split kernel, then a merge kernel that is parallel over heads): at least 128 tokens per split,
-      at most 32 splits - batch 1: 15.2 us at 2048 tokens (16 splits), 18.1 at 4096 (16), 43.6 at 32768 (32);
+    * two launches (split kernel, then a merge kernel that is parallel over heads): s ~ sqrt(L / 16), at least 128
+      tokens per split, at most 32 splits - batch 1: 15.2 us at 2048 tokens (16 splits; rule: 11), 18.1 at 4096
+      (16; 20.2 at 32), 23.3 at 8192 (16; 24.5 at 32; rule: 23), 43.6 at 32768 (32);
     * ``fused`` (one launch; the last workgroup of a (sequence, head block) merges its splits): streaming costs
       ~ L / s and the merge ~ s, optimum s ~ sqrt(L / 32) - batch 1: 17.0 us at 2048 (8 splits), 22.1 at 4096 (11),
       54.1 at 32768 (32).  The two-launch form is ahead at every shape with fewer than ~64 (sequence, kv head) pairs
@@ -56,7 +57,8 @@ def auto_kv_splits(batch: int, q_heads: int, kv_heads: int, max_kv_len: int, num
     if fused:
         want = max(1, int(round(math.sqrt(max_kv_len / 32.0))))
         return int(max(1, min(want, one_round, max(1, max_kv_len // 64), 64)))
-    return int(max(1, min(one_round, max(1, max_kv_len // 128), 32)))
+    want = max(1, int(round(math.sqrt(max_kv_len / 16.0))))
+    return int(max(1, min(want, one_round, max(1, max_kv_len // 128), 32)))
 
 
 def _dt(q: torch.Tensor) -> int:
