@@ -478,7 +478,7 @@ TDIST_API int tdist_gemm_nt_norm(const void* X, const void* R, const void* G, fl
 // One workgroup per (16 output columns, token); wave k streams the 16 rows of expert ids[t, k] (Ip long) through
 // 16x16x32 MFMAs whose M dimension holds the single activation row, scales its partial sums by the routing weight
 // and the waves are summed through LDS: the top-k reduction costs nothing extra and no [pairs, H] intermediate
-// exists.  Loads run as a rolling window of two 8-K-step buffers.
+// exists.  Loads run as a rolling window of three 8-K-step buffers.
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void moe_decode_down_kernel(const uint16_t* __restrict__ hbuf,
                                                                   const int* __restrict__ ids,
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(64 * NW) void moe_decode_down_kernel(const uint16_t
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     // (the activation fragments are loaded WITH the weights they meet: fetched at multiply time, each group of
     // eight paid an L2 round trip after its weights had already arrived)
-    u32x4 wa[8], wb[8], xa[8], xb[8];
+    u32x4 wa[8], wb[8], wc[8], xa[8], xb[8], xc[8];
     auto ld = [&](u32x4(&w)[8], u32x4(&x)[8], int ks0) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -520,12 +520,17 @@ __global__ __launch_bounds__(64 * NW) void moe_decode_down_kernel(const uint16_t
       for (int u = 0; u < 8; ++u)
         if (ks0 + u < ksteps) acc = F::mfma(__builtin_bit_cast(VT, x[u]), __builtin_bit_cast(VT, w[u]), acc);
     };
+    // three buffers of eight K-steps: an expert slice of up to 768 columns is requested in one go
     ld(wa, xa, 0);
-    for (int ks0 = 0; ks0 < ksteps; ks0 += 16) {
-      ld(wb, xb, ks0 + 8);
+    ld(wb, xb, 8);
+    ld(wc, xc, 16);
+    for (int ks0 = 0; ks0 < ksteps; ks0 += 24) {
       mm(wa, xa, ks0);
-      ld(wa, xa, ks0 + 16);
+      ld(wa, xa, ks0 + 24);
       mm(wb, xb, ks0 + 8);
+      ld(wb, xb, ks0 + 32);
+      mm(wc, xc, ks0 + 16);
+      ld(wc, xc, ks0 + 40);
     }
     part += wgt * acc[0];          // accumulator row 0 (the token) lives in lanes lg == 0, column li
   }
