@@ -52,11 +52,26 @@ constexpr int LDS_BYTES = BM * C_STRIDE;      // 135168 >= 2 * BUF_BYTES
 #define TDIST_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define TDIST_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
-template <bool IS_BF16>
+// Operand types of the tile engine.  The two 16-bit types keep the values the `IS_BF16` template
+// parameters of the kernels convert to (false = f16, true = bf16); the 8-bit types are new:
+// OCP fp8 e4m3 / e5m2 on v_mfma_scale_f32_16x16x128_f8f6f4 (unit scales: twice the bf16 rate per clock)
+// and int8 on v_mfma_i32_16x16x64_i8 (int32 accumulate, twice the bf16 rate).  An 8-bit operand matrix is
+// handed to the engine as a 16-bit matrix with half as many columns - K, lda, ldb in TileArgs count
+// 16-bit units - so staging, LDS image and fragment reads are byte for byte those of the 16-bit types;
+// only the MFMA that consumes the fragments differs (reference: the dtype-generic `tl.dot` of
+// python/triton_dist/kernels/amd/all_gather_gemm.py:173,211-221 with int32 accumulators for int8).
+enum : int { DT_F16 = 0, DT_BF16 = 1, DT_FP8 = 2, DT_BF8 = 3, DT_I8 = 4 };
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+template <int DT>
 struct Frag;
 template <>
-struct Frag<true> {
+struct Frag<DT_BF16> {
   using T = bf16x8;
+  static constexpr bool K128 = false;
+  static __device__ __forceinline__ float val(float raw) { return raw; }
+  static __device__ __forceinline__ f32x4 add(f32x4 a, f32x4 b) { return a + b; }
   static __device__ __forceinline__ f32x4 mfma(T a, T b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   }
@@ -72,8 +87,11 @@ struct Frag<true> {
   }
 };
 template <>
-struct Frag<false> {
+struct Frag<DT_F16> {
   using T = f16x8;
+  static constexpr bool K128 = false;
+  static __device__ __forceinline__ float val(float raw) { return raw; }
+  static __device__ __forceinline__ f32x4 add(f32x4 a, f32x4 b) { return a + b; }
   static __device__ __forceinline__ f32x4 mfma(T a, T b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
   }
@@ -85,6 +103,43 @@ struct Frag<false> {
     f16x2 v = {(_Float16)lo, (_Float16)hi};
     return __builtin_bit_cast(uint32_t, v);
   }
+};
+
+// fp8 (FMT 0 = e4m3, 1 = e5m2): a lane's operand of the 128-deep MFMA is 32 bytes = the 16-byte fragments
+// of BOTH 64-byte k halves of a K-step; which 32 of the step's 128 k a lane group holds differs from the
+// instruction's natural order, but identically for both operands, so the dot products are the same.
+template <int FMT>
+struct FragF8 {
+  using T = i32x4;
+  static constexpr bool K128 = true;
+  static __device__ __forceinline__ f32x4 mfma2(T a0, T a1, T b0, T b1, f32x4 c) {
+    const i32x8 a = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+    const i32x8 b = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+    // scale bytes 127 = 2^0 (E8M0) for both operands
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, FMT, FMT, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+  }
+  static __device__ __forceinline__ float val(float raw) { return raw; }
+  static __device__ __forceinline__ f32x4 add(f32x4 a, f32x4 b) { return a + b; }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return Frag<DT_BF16>::pack2(lo, hi); }
+};
+template <>
+struct Frag<DT_FP8> : FragF8<0> {};
+template <>
+struct Frag<DT_BF8> : FragF8<1> {};
+
+// int8: the accumulator registers hold int32 bit patterns (f32x4 is only their register type).
+template <>
+struct Frag<DT_I8> {
+  using T = i32x4;
+  static constexpr bool K128 = false;
+  static __device__ __forceinline__ f32x4 mfma(T a, T b, f32x4 c) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, __builtin_bit_cast(i32x4, c), 0, 0, 0));
+  }
+  static __device__ __forceinline__ float val(float raw) { return (float)__builtin_bit_cast(int, raw); }
+  static __device__ __forceinline__ f32x4 add(f32x4 a, f32x4 b) {
+    return __builtin_bit_cast(f32x4, __builtin_bit_cast(i32x4, a) + __builtin_bit_cast(i32x4, b));
+  }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return Frag<DT_BF16>::pack2(val(lo), val(hi)); }
 };
 
 // Description of one 256x256 tile job.  A and B are 16-bit row-major with K contiguous.
@@ -104,7 +159,7 @@ struct TileArgs {
 
 // Accumulators of one wave: 8 (m) x 4 (n) tiles of 16x16, stored transposed (lane: m = lane&15,
 // n = 4*(lane>>4) + reg) because the MFMA is issued as B*A^T.
-template <bool IS_BF16>
+template <int DT>
 struct Acc {
   f32x4 v[8][4];
 };
@@ -1149,6 +1204,283 @@ __device__ __forceinline__ void epilogue_256_4w_direct(const Acc4<IS_BF16>& acc,
       v.z = F::pack2(acc.v[m][2 * p + 1][0], acc.v[m][2 * p + 1][1]);
       v.w = F::pack2(acc.v[m][2 * p + 1][2], acc.v[m][2 * p + 1][3]);
       store(row + m * 16, col + 32 * p, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The tile family: BM = 32 * MT rows x BN = 64 * NT columns, MT in {4, 8}, NT in {2, 4}, every operand type.
+//
+// Same eight waves (2 along M x 4 along N, wave tile 16 MT x 16 NT), same two-phase K-step, same ring of two
+// K-step buffers, same LDS sub-tile image and the same barrier / counted-wait skeleton as mainloop_256_2ph
+// (PERM_B columns, A fragments waited for block by block, no s_setprio) - only the sizes are parameters:
+//   half tiles      A0 / A1 = MT/2 sixteen-row blocks per wave row (MT * 2 KiB), B0 / B1 = NT/2 blocks per wave
+//                   column (NT * 4 KiB); a 16 KiB half is staged as two LDS-DMA pieces per wave (both k halves of
+//                   sub-tile row w), an 8 KiB half as one (sub-tile row w / 2, k half w % 2);
+//   phase 0         reads B0, B1, A0 (2 NT + MT fragments) and runs MT/2 * NT MFMA pairs, phase 1 reads A1 (MT);
+//   LDS             2 * (MT * 4 + NT * 8) KiB: 128 KiB at 256 x 256, 96 at 256 x 128 and 128 x 256, 64 at 128 x 128 -
+//                   two 128 x 128 workgroups are co-resident on a CU (64 accumulator + fragment registers per lane),
+//                   one hides its LDS-DMA issue under the other's MFMAs.
+// What the smaller tiles are for: a GEMM with fewer 256 x 256 tiles than the chip has CUs (a TP shard of a
+// projection, a short prompt) leaves CUs idle; per K-step a 256 x 128 tile streams 3/4 and a 128 x 128 tile 1/2 of
+// the bytes of a 256 x 256 tile for 1/2 and 1/4 of its MFMAs, so they fill the chip at the price of more
+// L2 -> LDS traffic per FLOP (reference: the BM {128, 256} x BN {128, 256} autotune space of
+// python/triton_dist/kernels/amd/all_gather_gemm.py:102-124 and gemm_reduce_scatter.py:39-122).
+// 8-bit operand types: see the DT_* comment at the top; fp8 consumes both k halves of a fragment pair in one
+// 128-deep MFMA.
+template <int MT, int NT>
+struct TileShape {
+  static_assert((MT == 4 || MT == 8) && (NT == 2 || NT == 4), "tile family: BM in {128, 256}, BN in {128, 256}");
+  static constexpr int BM = 32 * MT, BN = 64 * NT;
+  static constexpr int HA = MT * 2048, HB = NT * 4096;        // bytes of an A / B half tile
+  static constexpr int PA = HA / 8192, PB = HB / 8192;        // LDS-DMA pieces per wave and half tile
+  static constexpr int BUF = 2 * (HA + HB);                   // one K-step
+  static constexpr int OFF_B0 = 0, OFF_A0 = HB, OFF_B1 = HB + HA, OFF_A1 = 2 * HB + HA;
+  static constexpr int LDS = 2 * BUF;
+  static constexpr int WGS_PER_CU = LDS <= 65536 ? 2 : 1;
+};
+
+template <int MT, int NT>
+struct AccT {
+  f32x4 v[MT][NT];     // [16-row block][column tile: B0's NT/2 tiles, then B1's]
+};
+
+template <int N>
+__device__ __forceinline__ void wait_lgkm() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Column (inside the wave's 16 NT columns) that accumulator register r of lane group g stands for in the
+// column tile j of half h: a lane's registers of tiles (h, 0), (h, 1) [NT 4] or (0, 0), (1, 0) [NT 2] are eight
+// neighbouring columns - one 16-byte store of 16-bit results.
+template <int NT>
+__device__ __forceinline__ int perm_col(int h, int j, int g, int r) {
+  return NT == 4 ? 32 * h + 8 * g + 4 * j + r : 8 * g + 4 * h + r;
+}
+
+template <int DT, int MT, int NT>
+__device__ __forceinline__ void mainloop_2ph(const TileArgs& t, char* smem, AccT<MT, NT>& acc) {
+  using F = Frag<DT>;
+  using V = typename F::T;
+  using S = TileShape<MT, NT>;
+  constexpr int MH = MT / 2, NH = NT / 2;
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63;
+  const int wr = w >> 2, wc = w & 3;
+  const bool late_group = w >= 4;
+  const int i = l >> 2;                                        // row inside a staged sub-tile
+  const int kchunk = (l & 3) ^ (((l >> 5) & 1) << 1);
+  // ---- staging sources: sub-tile row `sa` / `sb` of the A / B half tiles, k half `ka` / `kb` when one piece ----
+  const int sa = S::PA == 2 ? w : (w >> 1), ka = S::PA == 2 ? 0 : (w & 1);
+  const int sb = S::PB == 2 ? w : (w >> 1), kb = S::PB == 2 ? 0 : (w & 1);
+  int arow0 = (sa / MH) * (16 * MT) + (sa % MH) * 16 + i;      // A0; A1 = + 8 MT
+  int arow1 = arow0 + 8 * MT;
+  const int bcol = (sb / NH) * (16 * NT);                      // first column of the wave column this sub-tile feeds
+  int brow0 = bcol + perm_col<NT>(0, sb % NH, i >> 2, i & 3);
+  int brow1 = bcol + perm_col<NT>(1, sb % NH, i >> 2, i & 3);
+  arow0 = arow0 < t.a_rows ? arow0 : t.a_rows - 1;
+  arow1 = arow1 < t.a_rows ? arow1 : t.a_rows - 1;
+  brow0 = brow0 < t.b_rows ? brow0 : t.b_rows - 1;
+  brow1 = brow1 < t.b_rows ? brow1 : t.b_rows - 1;
+  if (t.a_gather) {
+    const int g0 = t.a_gather[arow0], g1 = t.a_gather[arow1];
+    arow0 = g0 < 0 ? 0 : g0;
+    arow1 = g1 < 0 ? 0 : g1;
+  }
+  const uint16_t* pa0 = t.A + (long long)arow0 * t.lda + kchunk * 8 + ka * 32;
+  const uint16_t* pa1 = t.A + (long long)arow1 * t.lda + kchunk * 8 + ka * 32;
+  const uint16_t* pb0 = t.B + (long long)brow0 * t.ldb + kchunk * 8 + kb * 32;
+  const uint16_t* pb1 = t.B + (long long)brow1 * t.ldb + kchunk * 8 + kb * 32;
+  const int nt = t.K / BK;
+  const int dst_a = S::PA == 2 ? w * 2048 : w * 1024;
+  const int dst_b = S::PB == 2 ? w * 2048 : w * 1024;
+  auto stage = [&](int kt, auto kind_c) {
+    constexpr int kind = decltype(kind_c)::value;              // 0 = B0, 1 = A0, 2 = B1, 3 = A1
+    constexpr bool is_a = (kind & 1) != 0;
+    constexpr int off = kind == 0 ? S::OFF_B0 : (kind == 1 ? S::OFF_A0 : (kind == 2 ? S::OFF_B1 : S::OFF_A1));
+    if (kt < nt) {
+      const uint16_t* src = kind == 0 ? pb0 : (kind == 1 ? pa0 : (kind == 2 ? pb1 : pa1));
+      src += (long long)kt * BK;
+      char* dst = smem + (kt & 1) * S::BUF + off + (is_a ? dst_a : dst_b);
+      __builtin_amdgcn_global_load_lds(TDIST_GLB_PTR(src), TDIST_LDS_PTR(dst), 16, 0, 0);
+      if constexpr ((is_a ? S::PA : S::PB) == 2)
+        __builtin_amdgcn_global_load_lds(TDIST_GLB_PTR(src + 32), TDIST_LDS_PTR(dst + 1024), 16, 0, 0);
+    }
+  };
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+  using K2 = std::integral_constant<int, 2>;
+  using K3 = std::integral_constant<int, 3>;
+  const int lane_off = (((l & 15) * 64) + ((l >> 4) * 16)) ^ ((((l & 15) >> 3) & 1) << 5);
+  const char* a_rd = smem + wr * (S::HA / 2) + lane_off;       // + OFF_A{0,1} + (m * 2 + ks) * 1024
+  const char* b_rd = smem + wc * (S::HB / 4) + lane_off;       // + OFF_B{0,1} + (j * 2 + ks) * 1024
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc.v[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  stage(0, K0{}); stage(0, K1{}); stage(0, K2{}); stage(0, K3{});
+  stage(1, K0{}); stage(1, K2{});
+  wait_vm<2 * S::PB>();
+  __builtin_amdgcn_s_barrier();
+  if (late_group) __builtin_amdgcn_s_barrier();
+
+  V a[MH][2], b0[NH][2], b1[NH][2];
+  // MFMAs of the 16-row block m of the current half against all NT column tiles, both k halves
+  auto mfma_row = [&](int m, int mo) {
+    if constexpr (F::K128) {
+#pragma unroll
+      for (int n = 0; n < NH; ++n) acc.v[mo + m][n] = F::mfma2(b0[n][0], b0[n][1], a[m][0], a[m][1], acc.v[mo + m][n]);
+#pragma unroll
+      for (int n = 0; n < NH; ++n)
+        acc.v[mo + m][NH + n] = F::mfma2(b1[n][0], b1[n][1], a[m][0], a[m][1], acc.v[mo + m][NH + n]);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int n = 0; n < NH; ++n) acc.v[mo + m][n] = F::mfma(b0[n][ks], a[m][ks], acc.v[mo + m][n]);
+#pragma unroll
+        for (int n = 0; n < NH; ++n) acc.v[mo + m][NH + n] = F::mfma(b1[n][ks], a[m][ks], acc.v[mo + m][NH + n]);
+      }
+    }
+  };
+  for (int kt = 0; kt < nt; ++kt) {
+    const int boff = (kt & 1) * S::BUF;
+    // ---------------- phase 0: upper half of the wave tile's rows ----------------
+#pragma unroll
+    for (int n = 0; n < NH; ++n)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) b0[n][ks] = *(const V*)(b_rd + boff + S::OFF_B0 + (n * 2 + ks) * 1024);
+#pragma unroll
+    for (int n = 0; n < NH; ++n)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) b1[n][ks] = *(const V*)(b_rd + boff + S::OFF_B1 + (n * 2 + ks) * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < MH; ++m)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) a[m][ks] = *(const V*)(a_rd + boff + S::OFF_A0 + (m * 2 + ks) * 1024);
+    stage(kt + 1, K1{});
+    stage(kt + 1, K3{});
+    __builtin_amdgcn_sched_barrier(0);
+    // the B reads are retired before the barrier (phase 1 of the OTHER wave group restages their slots right
+    // behind it); the MT A0 reads are younger and are waited for block by block inside the MFMA segment
+    wait_lgkm<MT>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    wait_lgkm<MT - 2>();
+    mfma_row(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (MH > 1) {
+      wait_lgkm<MT - 4>();
+      mfma_row(1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (MH > 2) {
+      wait_lgkm<MT - 6>();
+      mfma_row(2, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_lgkm<MT - 8>();
+      mfma_row(3, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_barrier();
+    // ---------------- phase 1: lower half ----------------
+#pragma unroll
+    for (int m = 0; m < MH; ++m)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) a[m][ks] = *(const V*)(a_rd + boff + S::OFF_A1 + (m * 2 + ks) * 1024);
+    stage(kt + 2, K0{});
+    stage(kt + 2, K2{});
+    // retire A0, A1 of step kt+1 (issued in phase 0) and its B halves (issued one step ago): everything but the
+    // two B halves just issued, if they were
+    if (kt + 2 < nt) {
+      wait_vm<2 * S::PB>();
+    } else if (kt + 1 < nt) {
+      wait_vm<0>();
+    }
+    // (complete: the other wave group restages this buffer's A1 slot one barrier later)
+    wait_lgkm<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int m = 0; m < MH; ++m) mfma_row(m, MH);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  }
+  if (!late_group) __builtin_amdgcn_s_barrier();
+}
+
+// Register-direct stores of the tile family's accumulators.
+//   store16(row, col, uint4): eight 16-bit results of one row (columns col .. col + 7), scaled by
+//     sa[row] * sb[col ..] when the scale pointers are given (per-row scale of A, per-column scale of B: the
+//     de-quantisation of 8-bit operands), after Frag::val (int32 -> float for int8);
+//   store32(row, col, uint4 lo, uint4 hi): the same eight results as raw 32-bit accumulator words (int32 output
+//     of an int8 GEMM).
+template <int DT, int MT, int NT, class StoreFn>
+__device__ __forceinline__ void epilogue_direct(const AccT<MT, NT>& acc, const float* sa, const float* sb, int row0,
+                                                int col0, int mrem, int nrem, StoreFn&& store16) {
+  using F = Frag<DT>;
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, l = tid & 63;
+  const int row = (w >> 2) * (16 * MT) + (l & 15);
+  const int col = (w & 3) * (16 * NT) + (l >> 4) * 8;
+  const bool scaled = sa != nullptr || sb != nullptr;
+  float cs[NT / 2][8];
+  if (scaled) {
+#pragma unroll
+    for (int p = 0; p < NT / 2; ++p)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = col + 32 * p + e;
+        cs[p][e] = (sb && c < nrem) ? sb[col0 + c] : 1.f;
+      }
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int r = row + m * 16;
+    float rs = 1.f;
+    if (scaled && sa && r < mrem) rs = sa[row0 + r];
+#pragma unroll
+    for (int p = 0; p < NT / 2; ++p) {
+      const f32x4& x0 = NT == 4 ? acc.v[m][2 * p] : acc.v[m][0];
+      const f32x4& x1 = NT == 4 ? acc.v[m][2 * p + 1] : acc.v[m][NT - 1];
+      uint4 v;
+      if (scaled) {
+        const float* c8 = cs[p];
+        using FO = Frag<DT == DT_F16 ? DT_F16 : DT_BF16>;     // output type: f16 for f16 operands, bf16 otherwise
+        v.x = FO::pack2(F::val(x0[0]) * rs * c8[0], F::val(x0[1]) * rs * c8[1]);
+        v.y = FO::pack2(F::val(x0[2]) * rs * c8[2], F::val(x0[3]) * rs * c8[3]);
+        v.z = FO::pack2(F::val(x1[0]) * rs * c8[4], F::val(x1[1]) * rs * c8[5]);
+        v.w = FO::pack2(F::val(x1[2]) * rs * c8[6], F::val(x1[3]) * rs * c8[7]);
+      } else {
+        v.x = F::pack2(x0[0], x0[1]);
+        v.y = F::pack2(x0[2], x0[3]);
+        v.z = F::pack2(x1[0], x1[1]);
+        v.w = F::pack2(x1[2], x1[3]);
+      }
+      store16(r, col + 32 * p, v);
+    }
+  }
+}
+
+template <int MT, int NT, class StoreFn>
+__device__ __forceinline__ void epilogue_direct_raw32(const AccT<MT, NT>& acc, StoreFn&& store32) {
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, l = tid & 63;
+  const int row = (w >> 2) * (16 * MT) + (l & 15);
+  const int col = (w & 3) * (16 * NT) + (l >> 4) * 8;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int p = 0; p < NT / 2; ++p) {
+      const f32x4& x0 = NT == 4 ? acc.v[m][2 * p] : acc.v[m][0];
+      const f32x4& x1 = NT == 4 ? acc.v[m][2 * p + 1] : acc.v[m][NT - 1];
+      store32(row + m * 16, col + 32 * p, __builtin_bit_cast(uint4, x0), __builtin_bit_cast(uint4, x1));
     }
 }
 

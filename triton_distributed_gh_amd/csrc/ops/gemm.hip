@@ -184,6 +184,53 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_nt_256_4w32_kernel(const uint
   }
 }
 
+// The tile family (gemm_gfx950.hpp: mainloop_2ph<DT, MT, NT>) as a persistent plain GEMM: BM = 32 MT, BN = 64 NT,
+// 16-bit or 8-bit operands.  OUT32: the raw int32 accumulators of an int8 GEMM are stored instead of 16-bit
+// results.  sa / sb: optional per-row (A) / per-column (B) fp32 scales applied to the 16-bit output.
+// A, B, lda, ldb, K are in 16-bit units (8-bit operands: two elements per unit).
+template <int DT, int MT, int NT, bool OUT32, bool SCALED = false>
+__global__ __launch_bounds__(THREADS, (2 * TileShape<MT, NT>::WGS_PER_CU)) void gemm_nt_tile_kernel(
+    const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv, int M, int N, int K,
+    long long lda, long long ldb, long long ldc, int group_m, const float* __restrict__ sa,
+    const float* __restrict__ sb) {
+  using S = TileShape<MT, NT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int num_pid_m = (M + S::BM - 1) / S::BM;
+  const int num_pid_n = (N + S::BN - 1) / S::BN;
+  const int nwg = num_pid_m * num_pid_n;
+  for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
+    const int id = xcd_remap(vb, nwg);
+    int pid_m, pid_n;
+    tile_coords(id, num_pid_m, num_pid_n, group_m, pid_m, pid_n);
+    const int row0 = pid_m * S::BM, col0 = pid_n * S::BN;
+    TileArgs t;
+    t.A = A + (long long)row0 * lda;
+    t.B = B + (long long)col0 * ldb;
+    t.lda = lda;
+    t.ldb = ldb;
+    t.a_rows = M - row0;
+    t.b_rows = N - col0;
+    t.K = K;
+    AccT<MT, NT> acc;
+    mainloop_2ph<DT, MT, NT>(t, smem, acc);
+    const int mrem = M - row0, nrem = N - col0;
+    if constexpr (OUT32) {
+      uint32_t* cbase = (uint32_t*)Cv + (long long)row0 * ldc + col0;
+      epilogue_direct_raw32<MT, NT>(acc, [&](int r, int c, const uint4& lo, const uint4& hi) {
+        if (r < mrem && c < nrem) {
+          *(uint4*)(cbase + (long long)r * ldc + c) = lo;
+          *(uint4*)(cbase + (long long)r * ldc + c + 4) = hi;
+        }
+      });
+    } else {
+      uint16_t* cbase = (uint16_t*)Cv + (long long)row0 * ldc + col0;
+      epilogue_direct<DT, MT, NT>(acc, SCALED ? sa : nullptr, SCALED ? sb : nullptr, row0, col0, mrem, nrem, [&](int r, int c, const uint4& v) {
+        if (r < mrem && c < nrem) *(uint4*)(cbase + (long long)r * ldc + c) = v;
+      });
+    }
+  }
+}
+
 // Decode-shaped GEMM (M <= 16): the weights are streamed exactly once with non-temporal 16-byte
 // loads and feed 16x16x32 MFMAs whose M dimension is the zero-padded batch.  A workgroup of four
 // (or eight, NW) waves covers BN = 16 * WN output columns (WN = 1 / 2 / 4); wave k owns the k-th slice
@@ -693,6 +740,126 @@ TDIST_API int tdist_gemm_nt(const void* A, const void* B, void* C, int M, int N,
   kern_t k = table[dtype == 0 ? 0 : 1][v == 2 ? 1 : (v >= 5 && v <= 10 ? v - 3 : 0)];
   hipLaunchKernelGGL(k, dim3(tiles), dim3(THREADS), LDS_BYTES, (hipStream_t)stream, (const uint16_t*)A,
                      (const uint16_t*)B, (uint16_t*)C, M, N, K, lda, ldb, ldc, group_m, variant >> 8);
+  TDIST_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+
+// Tile choice for a plain GEMM of the tile family.  Cost model: a workgroup's time for one tile is
+// ksteps * step_ns(shape) + fixed; the launch takes ceil(tiles / slots) rounds of it (slots = CUs x co-resident
+// workgroups).  step_ns are measured on MI355X, bf16, random operands, chip full (scripts/dev/probe_tile_family.py).
+struct TilePick {
+  int mt, nt;
+};
+static double tile_step_ns(int mt, int nt, int wgs_on_cu) {
+  // per 64-deep K-step (128 bytes per row) of ONE workgroup
+  if (mt == 8 && nt == 4) return 1430.0;
+  if (mt == 8 || nt == 4) return wgs_on_cu > 1 ? 1500.0 : 820.0;
+  return wgs_on_cu > 1 ? 820.0 : 480.0;
+}
+static TilePick pick_tile(int M, int N, int K16, int cus) {
+  static const int forced = getenv("TDIST_GEMM_TILE") ? atoi(getenv("TDIST_GEMM_TILE")) : 0;   // e.g. 84 = MT 8, NT 4
+  if (forced) return TilePick{forced / 10, forced % 10};
+  const TilePick cand[4] = {{8, 4}, {8, 2}, {4, 4}, {4, 2}};
+  double best = 1e30;
+  TilePick pick = cand[0];
+  for (const TilePick& c : cand) {
+    const int bm = 32 * c.mt, bn = 64 * c.nt;
+    const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    const int per_cu = (c.mt == 4 && c.nt == 2) ? 2 : 1;
+    const long long slots = (long long)cus * per_cu;
+    const long long rounds = (tiles + slots - 1) / slots;
+    const int co = tiles > cus ? per_cu : 1;
+    // padding waste is in `tiles`; a partial last round costs a full one
+    const double tns = (K16 / 64) * tile_step_ns(c.mt, c.nt, co) + 4000.0;
+    const double total = rounds * tns;
+    if (total < best * 0.97) {     // prefer the larger tile on a near tie (less L2 traffic)
+      best = total;
+      pick = c;
+    }
+  }
+  return pick;
+}
+
+// dtype: 0 = bf16, 1 = fp16, 2 = fp8 e4m3 (OCP), 3 = fp8 e5m2, 4 = int8.  out_kind: 0 = 16-bit output (the input type
+// for 16-bit inputs, bf16 for 8-bit inputs), 1 = int32 (int8 inputs only).  K, lda, ldb in ELEMENTS of the input
+// type; ldc in elements of the output type.  scale_a [M] / scale_b [N]: optional fp32 scales of the 16-bit output.
+// bm / bn: 128 or 256, 0 = chosen by the cost model.
+TDIST_API int tdist_gemm_nt_ex(const void* A, const void* B, void* C, int M, int N, int K, long long lda, long long ldb,
+                               long long ldc, int dtype, int out_kind, const float* scale_a, const float* scale_b, int bm,
+                               int bn, int group_m, void* stream) {
+  TDIST_REQUIRE(M > 0 && N > 0, "empty GEMM");
+  TDIST_REQUIRE(dtype >= 0 && dtype <= 4, "dtype must be 0..4");
+  const int eb = dtype >= 2 ? 1 : 2;                       // bytes per input element
+  const int per16 = 2 / eb;
+  TDIST_REQUIRE(K % (64 * per16) == 0 && K >= 128 * per16, "K must be a multiple of 64 (16-bit) / 128 (8-bit) and two steps deep");
+  TDIST_REQUIRE(lda % (8 * per16) == 0 && ldb % (8 * per16) == 0, "operand rows must be 16-byte aligned");
+  TDIST_REQUIRE(out_kind == 0 || (out_kind == 1 && dtype == 4), "int32 output needs int8 inputs");
+  TDIST_REQUIRE(N % 8 == 0 && ldc % (out_kind == 1 ? 4 : 8) == 0, "N must be a multiple of 8, output rows 16-byte aligned");
+  TDIST_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0, "operands must be 16-byte aligned");
+  TDIST_REQUIRE((bm == 0 || bm == 128 || bm == 256) && (bn == 0 || bn == 128 || bn == 256), "bm / bn must be 0, 128 or 256");
+  static int num_cus = 0;
+  if (!num_cus) {
+    int dev = 0;
+    TDIST_HIP_TRY(hipGetDevice(&dev));
+    TDIST_HIP_TRY(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  const int K16 = K / per16;
+  TilePick pk = pick_tile(M, N, K16, num_cus);
+  if (bm) pk.mt = bm / 32;
+  if (bn) pk.nt = bn / 64;
+  if (group_m <= 0) group_m = 8;
+  typedef void (*kern_t)(const uint16_t*, const uint16_t*, void*, int, int, int, long long, long long, long long, int,
+                         const float*, const float*);
+  // [dtype][shape: 84, 82, 44, 42]
+  static const kern_t table[5][4] = {
+      {gemm_nt_tile_kernel<DT_BF16, 8, 4, false>, gemm_nt_tile_kernel<DT_BF16, 8, 2, false>,
+       gemm_nt_tile_kernel<DT_BF16, 4, 4, false>, gemm_nt_tile_kernel<DT_BF16, 4, 2, false>},
+      {gemm_nt_tile_kernel<DT_F16, 8, 4, false>, gemm_nt_tile_kernel<DT_F16, 8, 2, false>,
+       gemm_nt_tile_kernel<DT_F16, 4, 4, false>, gemm_nt_tile_kernel<DT_F16, 4, 2, false>},
+      {gemm_nt_tile_kernel<DT_FP8, 8, 4, false>, gemm_nt_tile_kernel<DT_FP8, 8, 2, false>,
+       gemm_nt_tile_kernel<DT_FP8, 4, 4, false>, gemm_nt_tile_kernel<DT_FP8, 4, 2, false>},
+      {gemm_nt_tile_kernel<DT_BF8, 8, 4, false>, gemm_nt_tile_kernel<DT_BF8, 8, 2, false>,
+       gemm_nt_tile_kernel<DT_BF8, 4, 4, false>, gemm_nt_tile_kernel<DT_BF8, 4, 2, false>},
+      {gemm_nt_tile_kernel<DT_I8, 8, 4, false>, gemm_nt_tile_kernel<DT_I8, 8, 2, false>,
+       gemm_nt_tile_kernel<DT_I8, 4, 4, false>, gemm_nt_tile_kernel<DT_I8, 4, 2, false>}};
+  static const kern_t table32[4] = {gemm_nt_tile_kernel<DT_I8, 8, 4, true>, gemm_nt_tile_kernel<DT_I8, 8, 2, true>,
+                                    gemm_nt_tile_kernel<DT_I8, 4, 4, true>, gemm_nt_tile_kernel<DT_I8, 4, 2, true>};
+  // 16-bit output with scales (8-bit inputs; the 16-bit input types take scales too, through the same instances)
+  static const kern_t table_sc[5][4] = {
+      {gemm_nt_tile_kernel<DT_BF16, 8, 4, false, true>, gemm_nt_tile_kernel<DT_BF16, 8, 2, false, true>,
+       gemm_nt_tile_kernel<DT_BF16, 4, 4, false, true>, gemm_nt_tile_kernel<DT_BF16, 4, 2, false, true>},
+      {gemm_nt_tile_kernel<DT_F16, 8, 4, false, true>, gemm_nt_tile_kernel<DT_F16, 8, 2, false, true>,
+       gemm_nt_tile_kernel<DT_F16, 4, 4, false, true>, gemm_nt_tile_kernel<DT_F16, 4, 2, false, true>},
+      {gemm_nt_tile_kernel<DT_FP8, 8, 4, false, true>, gemm_nt_tile_kernel<DT_FP8, 8, 2, false, true>,
+       gemm_nt_tile_kernel<DT_FP8, 4, 4, false, true>, gemm_nt_tile_kernel<DT_FP8, 4, 2, false, true>},
+      {gemm_nt_tile_kernel<DT_BF8, 8, 4, false, true>, gemm_nt_tile_kernel<DT_BF8, 8, 2, false, true>,
+       gemm_nt_tile_kernel<DT_BF8, 4, 4, false, true>, gemm_nt_tile_kernel<DT_BF8, 4, 2, false, true>},
+      {gemm_nt_tile_kernel<DT_I8, 8, 4, false, true>, gemm_nt_tile_kernel<DT_I8, 8, 2, false, true>,
+       gemm_nt_tile_kernel<DT_I8, 4, 4, false, true>, gemm_nt_tile_kernel<DT_I8, 4, 2, false, true>}};
+  static const int lds_of[4] = {TileShape<8, 4>::LDS, TileShape<8, 2>::LDS, TileShape<4, 4>::LDS, TileShape<4, 2>::LDS};
+  static bool attr_set = false;
+  if (!attr_set) {
+    for (int s = 0; s < 4; ++s) {
+      for (int d = 0; d < 5; ++d)
+      {
+        TDIST_HIP_TRY(hipFuncSetAttribute((const void*)table[d][s], hipFuncAttributeMaxDynamicSharedMemorySize, lds_of[s]));
+        TDIST_HIP_TRY(hipFuncSetAttribute((const void*)table_sc[d][s], hipFuncAttributeMaxDynamicSharedMemorySize, lds_of[s]));
+      }
+      TDIST_HIP_TRY(hipFuncSetAttribute((const void*)table32[s], hipFuncAttributeMaxDynamicSharedMemorySize, lds_of[s]));
+    }
+    attr_set = true;
+  }
+  const int si = pk.mt == 8 ? (pk.nt == 4 ? 0 : 1) : (pk.nt == 4 ? 2 : 3);
+  const int bmv = 32 * pk.mt, bnv = 64 * pk.nt;
+  const long long tiles = (long long)((M + bmv - 1) / bmv) * ((N + bnv - 1) / bnv);
+  const int per_cu = si == 3 ? 2 : 1;
+  long long grid = (long long)(num_cus & ~7) * per_cu;
+  if (grid < 8) grid = 8;
+  if (tiles < grid) grid = tiles;
+  const kern_t k = out_kind == 1 ? table32[si] : ((scale_a || scale_b) ? table_sc[dtype][si] : table[dtype][si]);
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(THREADS), lds_of[si], (hipStream_t)stream, (const uint16_t*)A,
+                     (const uint16_t*)B, C, M, N, K16, lda / per16, ldb / per16, ldc, group_m, scale_a, scale_b);
   TDIST_HIP_TRY(hipGetLastError());
   return 0;
 }

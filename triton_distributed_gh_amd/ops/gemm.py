@@ -106,8 +106,10 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
             return gemm_nt_mid(a, b, out)
         if FEW_TILES_GEMM == "splitk" and K >= 1024:
             return gemm_nt_splitk(a, b, out)
-        torch.matmul(a, b.t(), out=out)
-        return out
+        if FEW_TILES_GEMM == "lib":
+            torch.matmul(a, b.t(), out=out)
+            return out
+        return gemm_nt_tiles(a, b, out, group_m=group_m)      # 256x128 / 128x256 / 128x128 tiles by cost model
     lib = _lib.hip()
     _lib.check(
         lib.tdist_gemm_nt(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), M, N, K, ctypes.c_longlong(a.stride(0)),
@@ -116,7 +118,69 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     return out
 
 
-FEW_TILES_GEMM = os.environ.get("TDIST_FEW_TILES_GEMM", "lib")
+FEW_TILES_GEMM = os.environ.get("TDIST_FEW_TILES_GEMM", "tiles")
+
+# operand types of the tile family (csrc/include/tdist/gemm_gfx950.hpp: DT_*; C ABI numbering)
+_DT_EX = {torch.bfloat16: 0, torch.float16: 1, torch.float8_e4m3fn: 2, torch.float8_e5m2: 3, torch.int8: 4}
+
+
+def gemm_tiles_supported(a: torch.Tensor, b: torch.Tensor) -> bool:
+    """Shapes / types ``gemm_nt_tiles`` takes: K-contiguous 2-D operands of one of the five operand types, K a
+    multiple of 64 (16-bit) or 128 (8-bit) and at least two such steps, N a multiple of 8, 16-byte aligned rows."""
+    if not (a.is_cuda and b.is_cuda) or a.dtype not in _DT_EX or a.dtype != b.dtype:
+        return False
+    if a.dim() != 2 or b.dim() != 2 or a.stride(1) != 1 or b.stride(1) != 1:
+        return False
+    M, K = a.shape
+    N = b.shape[0]
+    per16 = 2 // a.element_size()
+    return (M > 0 and N > 0 and N % 8 == 0 and K % (64 * per16) == 0 and K >= 128 * per16
+            and a.stride(0) % (8 * per16) == 0 and b.stride(0) % (8 * per16) == 0
+            and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
+
+
+def gemm_nt_tiles(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None,
+                  scale_a: Optional[torch.Tensor] = None, scale_b: Optional[torch.Tensor] = None,
+                  out_dtype: Optional[torch.dtype] = None, bm: int = 0, bn: int = 0,
+                  group_m: Optional[int] = None) -> torch.Tensor:
+    """``a @ b^T`` on the tile family (csrc/ops/gemm.hip: gemm_nt_tile_kernel): 256x256, 256x128, 128x256 or 128x128
+    macro-tiles (``bm`` / ``bn``; 0 = cost model), bf16 / fp16 / fp8 (OCP e4m3, e5m2) / int8 operands.
+
+    Output: the input type for 16-bit inputs; bf16 for 8-bit inputs (``out_dtype`` None or bf16), optionally
+    multiplied by ``scale_a`` [M] (per row of a) and ``scale_b`` [N] (per row of b) fp32 scales in the epilogue -
+    the de-quantisation of per-token / per-channel quantised operands; ``out_dtype=torch.int32`` returns the exact
+    int32 accumulators of an int8 GEMM.  fp8 runs on the 128-deep MFMA (twice the bf16 rate), int8 on the 64-deep one.
+
+    Role in the reference: the dtype-generic consumer GEMM of kernels/amd/all_gather_gemm.py:127-245 (``--dtype
+    float8_e4m3fn | float8_e5m2 | s8`` of test/amd/test_ag_gemm_intra_node.py:122-136) and its BM / BN autotune space."""
+    assert a.shape[1] == b.shape[1], f"K mismatch: {tuple(a.shape)} vs {tuple(b.shape)}"
+    if not gemm_tiles_supported(a, b):
+        raise ValueError("shape / dtype not supported by the gfx950 tile family")
+    M, K = a.shape
+    N = b.shape[0]
+    eight = a.element_size() == 1
+    if out_dtype is None:
+        out_dtype = torch.bfloat16 if eight else a.dtype
+    want32 = out_dtype == torch.int32
+    if want32 and a.dtype != torch.int8:
+        raise ValueError("int32 output needs int8 operands")
+    if not want32 and out_dtype != (torch.bfloat16 if eight else a.dtype):
+        raise ValueError(f"unsupported output type {out_dtype} for {a.dtype} operands")
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    assert out.dtype == out_dtype and out.shape == (M, N) and out.stride(1) == 1
+    assert out.stride(0) % (4 if want32 else 8) == 0 and out.data_ptr() % 16 == 0
+    for sc, n in ((scale_a, M), (scale_b, N)):
+        assert sc is None or (sc.dtype == torch.float32 and sc.is_contiguous() and sc.numel() == n and not want32)
+    if group_m is None:
+        group_m = tuning.get("gemm.group_m", 8)
+    _lib.check(
+        _lib.hip().tdist_gemm_nt_ex(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), M, N, K, ctypes.c_longlong(a.stride(0)),
+                                    ctypes.c_longlong(b.stride(0)), ctypes.c_longlong(out.stride(0)), _DT_EX[a.dtype],
+                                    1 if want32 else 0, _lib.ptr(scale_a) if scale_a is not None else ctypes.c_void_p(0),
+                                    _lib.ptr(scale_b) if scale_b is not None else ctypes.c_void_p(0), bm, bn, group_m,
+                                    _lib.stream_handle()), "tdist_gemm_nt_ex")
+    return out
 _CUS = {}
 _SPLITK_WS = {}   # (device index, stream) -> (counters, fp32 partial tiles)
 
