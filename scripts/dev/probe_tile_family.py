@@ -85,6 +85,24 @@ def check():
                 if not ok:
                     bad += 1
                 print(f"{str(dt):22s} {M:5d} {N:5d} {K:5d} tile {bm}x{bn}: {'ok' if ok else 'BAD'} ({err:.3g})", flush=True)
+    # split-K: every shape, 2..4 ranges, ragged edges, all types (K deep enough for the split)
+    for dt in (torch.bfloat16, torch.float8_e4m3fn, torch.int8):
+        for (M, N, K) in [(300, 520, 4096), (512, 256, 2048)]:
+            a, b = make(M, N, K, dt)
+            ref = (a.double() @ b.double().t())
+            for bm, bn in SHAPES:
+                for sk in (2, 3, 4):
+                    for rep in range(2):        # twice: the second launch depends on the counters being re-armed
+                        if dt == torch.int8:
+                            o = G.gemm_nt_tiles(a, b, out_dtype=torch.int32, bm=bm, bn=bn, split_k=sk)
+                            ok = bool((o.double() == ref).all())
+                        else:
+                            o = G.gemm_nt_tiles(a, b, bm=bm, bn=bn, split_k=sk)
+                            e = (o.double() - ref).abs()
+                            ok = bool((e <= 2.0 ** -7 * ref.abs() + 1e-3 * (K ** 0.5)).all())
+                        if not ok:
+                            bad += 1
+                        print(f"{str(dt):22s} {M:5d} {N:5d} {K:5d} tile {bm}x{bn} split {sk} #{rep}: {'ok' if ok else 'BAD'}", flush=True)
     print("check:", "all ok" if bad == 0 else f"{bad} BAD")
     return bad
 
@@ -109,18 +127,27 @@ def time_steps():
 def few():
     dt = torch.bfloat16
     rows = []
+    variants = [(256, 256, 1), (256, 128, 1), (128, 256, 1), (128, 128, 1), (256, 256, 2), (256, 128, 2), (128, 256, 2),
+                (128, 128, 2), (256, 128, 4), (128, 256, 4), (128, 256, 3)]
     for M, N, K in [(2048, 2048, 8192), (2048, 4096, 4096), (2048, 1024, 8192), (1536, 4096, 4096), (4096, 1024, 8192),
                     (2048, 6144, 4096), (3072, 2048, 2048), (4096, 2048, 8192), (4096, 8192, 1024), (4096, 8192, 2048)]:
         a, b = make(M, N, K, dt)
         o = torch.empty(M, N, device="cuda", dtype=dt)
-        fns = [lambda bm=bm, bn=bn: G.gemm_nt_tiles(a, b, o, bm=bm, bn=bn) for bm, bn in SHAPES]
+        fns, names = [], []
+        for bm, bn, sk in variants:
+            tiles = -(-M // bm) * -(-N // bn)
+            if sk > 1 and tiles * sk > 256 * (2 if (bm, bn) == (128, 128) else 1):
+                continue
+            fns.append(lambda bm=bm, bn=bn, sk=sk: G.gemm_nt_tiles(a, b, o, bm=bm, bn=bn, split_k=sk))
+            names.append(f"{bm}x{bn}/{sk}")
         fns.append(lambda: G.gemm_nt_tiles(a, b, o))
         fns.append(lambda: torch.matmul(a, b.t(), out=o))
         ts = bench_interleaved(fns)
         rows.append((M, N, K, ts))
-        print(f"{M:5d} {N:5d} {K:5d} | " + " ".join(f"{bm}x{bn} {t:6.1f}" for (bm, bn), t in zip(SHAPES, ts[:4])) +
-              f" | model pick {ts[4]:6.1f} | hipBLASLt {ts[5]:6.1f}", flush=True)
-    wins = sum(1 for r in rows[:7] if r[3][4] <= r[3][5])
+        best = min(range(len(names)), key=lambda i: ts[i])
+        print(f"{M:5d} {N:5d} {K:5d} | " + " ".join(f"{n} {t:.1f}" for n, t in zip(names, ts)) +
+              f" | best {names[best]} {ts[best]:.1f} | model pick {ts[-2]:6.1f} | hipBLASLt {ts[-1]:6.1f}", flush=True)
+    wins = sum(1 for r in rows[:7] if r[3][-2] <= r[3][-1])
     print(f"cost-model pick <= library on {wins} of 7 table rows")
 
 

@@ -10,6 +10,8 @@
 
 #include <type_traits>
 
+#include "tdist/atomics.hpp"
+#include "tdist/cache_policy.hpp"
 #include "tdist/common.hpp"
 #include "tdist/gemm_gfx950.hpp"
 #include "tdist/wg_trace.hpp"
@@ -188,31 +190,79 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_nt_256_4w32_kernel(const uint
 // 16-bit or 8-bit operands.  OUT32: the raw int32 accumulators of an int8 GEMM are stored instead of 16-bit
 // results.  sa / sb: optional per-row (A) / per-column (B) fp32 scales applied to the 16-bit output.
 // A, B, lda, ldb, K are in 16-bit units (8-bit operands: two elements per unit).
+//
+// split_k > 1: K is cut into split_k ranges and the work items are (K range, tile) pairs, K range slowest, so the
+// workgroups running at any moment cover all tiles of one K range.  Wait-free join: an item parks its fp32
+// accumulators (register layout, write-through stores), drains, and counts itself on the tile's arrival word; the
+// item that counts last adds the others' partials to its live accumulators, re-arms the word and stores the tile.
+// `partial`: tiles * split_k slots of BM * BN * 4 bytes; `counters`: one int per tile, zero at launch.
 template <int DT, int MT, int NT, bool OUT32, bool SCALED = false>
 __global__ __launch_bounds__(THREADS, (2 * TileShape<MT, NT>::WGS_PER_CU)) void gemm_nt_tile_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv, int M, int N, int K,
     long long lda, long long ldb, long long ldc, int group_m, const float* __restrict__ sa,
-    const float* __restrict__ sb) {
+    const float* __restrict__ sb, int split_k, float* __restrict__ partial, int* __restrict__ counters) {
   using S = TileShape<MT, NT>;
+  using F = Frag<DT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int num_pid_m = (M + S::BM - 1) / S::BM;
   const int num_pid_n = (N + S::BN - 1) / S::BN;
   const int nwg = num_pid_m * num_pid_n;
-  for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
+  const int ksteps = K / BK;
+  for (int item = blockIdx.x; item < nwg * split_k; item += gridDim.x) {
+    const int ks = item / nwg, vb = item - ks * nwg;
     const int id = xcd_remap(vb, nwg);
     int pid_m, pid_n;
     tile_coords(id, num_pid_m, num_pid_n, group_m, pid_m, pid_n);
     const int row0 = pid_m * S::BM, col0 = pid_n * S::BN;
+    const int k0 = (int)((long long)ksteps * ks / split_k) * BK;
+    const int k1 = (int)((long long)ksteps * (ks + 1) / split_k) * BK;
     TileArgs t;
-    t.A = A + (long long)row0 * lda;
-    t.B = B + (long long)col0 * ldb;
+    t.A = A + (long long)row0 * lda + k0;
+    t.B = B + (long long)col0 * ldb + k0;
     t.lda = lda;
     t.ldb = ldb;
     t.a_rows = M - row0;
     t.b_rows = N - col0;
-    t.K = K;
+    t.K = k1 - k0;
     AccT<MT, NT> acc;
     mainloop_2ph<DT, MT, NT>(t, smem, acc);
+    if (split_k > 1) {
+      constexpr int SLOT = MT * NT * THREADS;                 // f32x4 per partial tile
+      volatile int* s_arrived = (volatile int*)(smem + S::LDS);
+      f32x4* tbase = (f32x4*)partial + (long long)id * split_k * SLOT + threadIdx.x;
+      {
+        f32x4* mine = tbase + (long long)ks * SLOT;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) tdist::st_wt128_agent(mine + (m * NT + n) * THREADS, acc.v[m][n]);
+      }
+      tdist::drain_stores();
+      __syncthreads();
+      if (threadIdx.x == 0) *s_arrived = tdist::atom_add_relaxed_agent(counters + id, 1);
+      __syncthreads();
+      const int arrived = __builtin_amdgcn_readfirstlane(*s_arrived);
+      __syncthreads();                                        // (the word is rewritten by the next item)
+      if (arrived != split_k - 1) continue;
+      if (threadIdx.x < 64) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) tdist::store_relaxed_agent(counters + id, 0);     // re-armed for the next launch
+      for (int q = 0; q < split_k; ++q) {
+        if (q == ks) continue;
+        const f32x4* src = tbase + (long long)q * SLOT;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          f32x4 x[NT];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) x[n] = src[(m * NT + n) * THREADS];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc.v[m][n] = F::add(acc.v[m][n], x[n]);
+        }
+      }
+    }
     const int mrem = M - row0, nrem = N - col0;
     if constexpr (OUT32) {
       uint32_t* cbase = (uint32_t*)Cv + (long long)row0 * ldc + col0;
@@ -745,49 +795,97 @@ TDIST_API int tdist_gemm_nt(const void* A, const void* B, void* C, int M, int N,
 }
 
 
-// Tile choice for a plain GEMM of the tile family.  Cost model: a workgroup's time for one tile is
-// ksteps * step_ns(shape) + fixed; the launch takes ceil(tiles / slots) rounds of it (slots = CUs x co-resident
-// workgroups).  step_ns are measured on MI355X, bf16, random operands, chip full (scripts/dev/probe_tile_family.py).
-struct TilePick {
-  int mt, nt;
+// Plan of a plain GEMM on the tile family: tile shape and K split.  Cost model (all times in ns): one work item
+// (a tile, or one K range of it) takes steps * step_ns(shape, co-resident workgroups) + FIXED, split-K adds the
+// parking of the accumulators and, for the last arriver, the reading of the other partials; the launch takes
+// ceil(items / slots) rounds of that (slots = CUs x co-resident workgroups).  step_ns: measured on MI355X with
+// bf16 random operands (scripts/dev/probe_tile_family.py time); the 8-bit types run the same steps over twice the K.
+struct TilePlan {
+  int mt, nt, split_k;
+  long long partial_bytes;
+  int n_counters;
 };
-static double tile_step_ns(int mt, int nt, int wgs_on_cu) {
-  // per 64-deep K-step (128 bytes per row) of ONE workgroup
-  if (mt == 8 && nt == 4) return 1430.0;
-  if (mt == 8 || nt == 4) return wgs_on_cu > 1 ? 1500.0 : 820.0;
-  return wgs_on_cu > 1 ? 820.0 : 480.0;
+static double tile_step_ns(int mt, int nt, bool chip_full) {
+  if (mt == 8 && nt == 4) return chip_full ? 1430.0 : 1620.0;
+  if (mt == 8) return 900.0;
+  if (nt == 4) return 840.0;
+  return chip_full ? 950.0 : 580.0;       // 128 x 128: two co-resident workgroups share the CU when the chip is full
 }
-static TilePick pick_tile(int M, int N, int K16, int cus) {
-  static const int forced = getenv("TDIST_GEMM_TILE") ? atoi(getenv("TDIST_GEMM_TILE")) : 0;   // e.g. 84 = MT 8, NT 4
-  if (forced) return TilePick{forced / 10, forced % 10};
-  const TilePick cand[4] = {{8, 4}, {8, 2}, {4, 4}, {4, 2}};
+static TilePlan plan_tiles(int M, int N, int K16, int cus, int bm, int bn, int split_k) {
+  static const int forced = getenv("TDIST_GEMM_TILE") ? atoi(getenv("TDIST_GEMM_TILE")) : 0;   // e.g. 842 = MT 8, NT 4, split 2
+  const int cand[4][2] = {{8, 4}, {8, 2}, {4, 4}, {4, 2}};
   double best = 1e30;
-  TilePick pick = cand[0];
-  for (const TilePick& c : cand) {
-    const int bm = 32 * c.mt, bn = 64 * c.nt;
-    const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
-    const int per_cu = (c.mt == 4 && c.nt == 2) ? 2 : 1;
+  TilePlan pick{8, 4, 1, 0, 0};
+  const int ksteps = K16 / 64;
+  for (int ci = 0; ci < 4; ++ci) {
+    const int mt = cand[ci][0], nt = cand[ci][1];
+    if ((bm && bm != 32 * mt) || (bn && bn != 64 * nt)) continue;
+    if (forced && (forced / 100 != mt || (forced / 10) % 10 != nt)) continue;
+    const int tbm = 32 * mt, tbn = 64 * nt;
+    const long long tiles = (long long)((M + tbm - 1) / tbm) * ((N + tbn - 1) / tbn);
+    const int per_cu = (mt == 4 && nt == 2) ? 2 : 1;
     const long long slots = (long long)cus * per_cu;
-    const long long rounds = (tiles + slots - 1) / slots;
-    const int co = tiles > cus ? per_cu : 1;
-    // padding waste is in `tiles`; a partial last round costs a full one
-    const double tns = (K16 / 64) * tile_step_ns(c.mt, c.nt, co) + 4000.0;
-    const double total = rounds * tns;
-    if (total < best * 0.97) {     // prefer the larger tile on a near tie (less L2 traffic)
-      best = total;
-      pick = c;
+    for (int s = 1; s <= 4; ++s) {
+      if (split_k && s != split_k) continue;
+      if (forced && forced % 10 && s != forced % 10) continue;
+      if (s > 1 && (ksteps / s < 8 || tiles * s > slots)) continue;     // split only inside one round, >= 512 deep
+      const long long items = tiles * s;
+      const long long rounds = (items + slots - 1) / slots;
+      const bool full = items > cus;
+      const double tile_kb = tbm * tbn * 4 / 1024.0;
+      const double fix = s > 1 ? 2500.0 + 20.0 * tile_kb + (s - 1) * 30.0 * tile_kb : 0.0;
+      const double total = rounds * ((ksteps / s) * tile_step_ns(mt, nt, full) + 7000.0) + fix;
+      if (total < best) {
+        best = total;
+        pick = TilePlan{mt, nt, s, 0, 0};
+      }
     }
   }
+  if (pick.split_k > 1) {
+    const int tbm = 32 * pick.mt, tbn = 64 * pick.nt;
+    const long long tiles = (long long)((M + tbm - 1) / tbm) * ((N + tbn - 1) / tbn);
+    pick.partial_bytes = tiles * pick.split_k * tbm * tbn * 4;
+    pick.n_counters = (int)tiles;
+  }
   return pick;
+}
+
+static int tile_family_cus() {
+  static int num_cus = 0;
+  if (!num_cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      num_cus = 256;
+  }
+  return num_cus;
+}
+
+// The plan tdist_gemm_nt_ex will follow for this problem (K in elements of the input type): tile, K split and
+// the workspace it needs (partial_bytes of fp32 partial tiles, n_counters zero-initialised ints) when it splits.
+// bm / bn / split_k: 0 = free, otherwise forced.
+TDIST_API int tdist_gemm_nt_ex_plan(int M, int N, int K, int dtype, int bm, int bn, int split_k, int* out_bm,
+                                    int* out_bn, int* out_split_k, long long* partial_bytes, int* n_counters) {
+  TDIST_REQUIRE(dtype >= 0 && dtype <= 4 && M > 0 && N > 0 && K > 0, "bad problem");
+  const int per16 = dtype >= 2 ? 2 : 1;
+  const TilePlan pl = plan_tiles(M, N, K / per16, tile_family_cus(), bm, bn, split_k);
+  *out_bm = 32 * pl.mt;
+  *out_bn = 64 * pl.nt;
+  *out_split_k = pl.split_k;
+  *partial_bytes = pl.partial_bytes;
+  *n_counters = pl.n_counters;
+  return 0;
 }
 
 // dtype: 0 = bf16, 1 = fp16, 2 = fp8 e4m3 (OCP), 3 = fp8 e5m2, 4 = int8.  out_kind: 0 = 16-bit output (the input type
 // for 16-bit inputs, bf16 for 8-bit inputs), 1 = int32 (int8 inputs only).  K, lda, ldb in ELEMENTS of the input
 // type; ldc in elements of the output type.  scale_a [M] / scale_b [N]: optional fp32 scales of the 16-bit output.
-// bm / bn: 128 or 256, 0 = chosen by the cost model.
+// bm / bn: 128 or 256, split_k 1..4; 0 = chosen by the cost model (a split is only chosen when `partial` /
+// `counters` are large enough for it: see tdist_gemm_nt_ex_plan).
 TDIST_API int tdist_gemm_nt_ex(const void* A, const void* B, void* C, int M, int N, int K, long long lda, long long ldb,
                                long long ldc, int dtype, int out_kind, const float* scale_a, const float* scale_b, int bm,
-                               int bn, int group_m, void* stream) {
+                               int bn, int split_k, void* partial, long long partial_bytes, int* counters,
+                               int n_counters, int group_m, void* stream) {
   TDIST_REQUIRE(M > 0 && N > 0, "empty GEMM");
   TDIST_REQUIRE(dtype >= 0 && dtype <= 4, "dtype must be 0..4");
   const int eb = dtype >= 2 ? 1 : 2;                       // bytes per input element
@@ -798,19 +896,17 @@ TDIST_API int tdist_gemm_nt_ex(const void* A, const void* B, void* C, int M, int
   TDIST_REQUIRE(N % 8 == 0 && ldc % (out_kind == 1 ? 4 : 8) == 0, "N must be a multiple of 8, output rows 16-byte aligned");
   TDIST_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0, "operands must be 16-byte aligned");
   TDIST_REQUIRE((bm == 0 || bm == 128 || bm == 256) && (bn == 0 || bn == 128 || bn == 256), "bm / bn must be 0, 128 or 256");
-  static int num_cus = 0;
-  if (!num_cus) {
-    int dev = 0;
-    TDIST_HIP_TRY(hipGetDevice(&dev));
-    TDIST_HIP_TRY(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
-  }
+  TDIST_REQUIRE(split_k >= 0 && split_k <= 4, "split_k must be 0..4");
+  const int num_cus = tile_family_cus();
   const int K16 = K / per16;
-  TilePick pk = pick_tile(M, N, K16, num_cus);
-  if (bm) pk.mt = bm / 32;
-  if (bn) pk.nt = bn / 64;
+  TilePlan pk = plan_tiles(M, N, K16, num_cus, bm, bn, split_k);
+  if (pk.split_k > 1 && (!partial || !counters || partial_bytes < pk.partial_bytes || n_counters < pk.n_counters)) {
+    TDIST_REQUIRE(split_k <= 1, "split-K workspace too small");
+    pk = plan_tiles(M, N, K16, num_cus, bm, bn, 1);
+  }
   if (group_m <= 0) group_m = 8;
   typedef void (*kern_t)(const uint16_t*, const uint16_t*, void*, int, int, int, long long, long long, long long, int,
-                         const float*, const float*);
+                         const float*, const float*, int, float*, int*);
   // [dtype][shape: 84, 82, 44, 42]
   static const kern_t table[5][4] = {
       {gemm_nt_tile_kernel<DT_BF16, 8, 4, false>, gemm_nt_tile_kernel<DT_BF16, 8, 2, false>,
@@ -843,23 +939,24 @@ TDIST_API int tdist_gemm_nt_ex(const void* A, const void* B, void* C, int M, int
     for (int s = 0; s < 4; ++s) {
       for (int d = 0; d < 5; ++d)
       {
-        TDIST_HIP_TRY(hipFuncSetAttribute((const void*)table[d][s], hipFuncAttributeMaxDynamicSharedMemorySize, lds_of[s]));
-        TDIST_HIP_TRY(hipFuncSetAttribute((const void*)table_sc[d][s], hipFuncAttributeMaxDynamicSharedMemorySize, lds_of[s]));
+        TDIST_HIP_TRY(hipFuncSetAttribute((const void*)table[d][s], hipFuncAttributeMaxDynamicSharedMemorySize, lds_of[s] + 16));
+        TDIST_HIP_TRY(hipFuncSetAttribute((const void*)table_sc[d][s], hipFuncAttributeMaxDynamicSharedMemorySize, lds_of[s] + 16));
       }
-      TDIST_HIP_TRY(hipFuncSetAttribute((const void*)table32[s], hipFuncAttributeMaxDynamicSharedMemorySize, lds_of[s]));
+      TDIST_HIP_TRY(hipFuncSetAttribute((const void*)table32[s], hipFuncAttributeMaxDynamicSharedMemorySize, lds_of[s] + 16));
     }
     attr_set = true;
   }
   const int si = pk.mt == 8 ? (pk.nt == 4 ? 0 : 1) : (pk.nt == 4 ? 2 : 3);
   const int bmv = 32 * pk.mt, bnv = 64 * pk.nt;
-  const long long tiles = (long long)((M + bmv - 1) / bmv) * ((N + bnv - 1) / bnv);
+  const long long items = (long long)((M + bmv - 1) / bmv) * ((N + bnv - 1) / bnv) * pk.split_k;
   const int per_cu = si == 3 ? 2 : 1;
   long long grid = (long long)(num_cus & ~7) * per_cu;
   if (grid < 8) grid = 8;
-  if (tiles < grid) grid = tiles;
+  if (items < grid) grid = items;
   const kern_t k = out_kind == 1 ? table32[si] : ((scale_a || scale_b) ? table_sc[dtype][si] : table[dtype][si]);
-  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(THREADS), lds_of[si], (hipStream_t)stream, (const uint16_t*)A,
-                     (const uint16_t*)B, C, M, N, K16, lda / per16, ldb / per16, ldc, group_m, scale_a, scale_b);
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(THREADS), lds_of[si] + 16, (hipStream_t)stream, (const uint16_t*)A,
+                     (const uint16_t*)B, C, M, N, K16, lda / per16, ldb / per16, ldc, group_m, scale_a, scale_b,
+                     pk.split_k, (float*)partial, counters);
   TDIST_HIP_TRY(hipGetLastError());
   return 0;
 }

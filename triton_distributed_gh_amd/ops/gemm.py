@@ -141,10 +141,11 @@ def gemm_tiles_supported(a: torch.Tensor, b: torch.Tensor) -> bool:
 
 def gemm_nt_tiles(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None,
                   scale_a: Optional[torch.Tensor] = None, scale_b: Optional[torch.Tensor] = None,
-                  out_dtype: Optional[torch.dtype] = None, bm: int = 0, bn: int = 0,
+                  out_dtype: Optional[torch.dtype] = None, bm: int = 0, bn: int = 0, split_k: int = 0,
                   group_m: Optional[int] = None) -> torch.Tensor:
     """``a @ b^T`` on the tile family (csrc/ops/gemm.hip: gemm_nt_tile_kernel): 256x256, 256x128, 128x256 or 128x128
-    macro-tiles (``bm`` / ``bn``; 0 = cost model), bf16 / fp16 / fp8 (OCP e4m3, e5m2) / int8 operands.
+    macro-tiles (``bm`` / ``bn``; 0 = cost model), optionally with K cut into ``split_k`` ranges joined wait-free
+    inside the launch (0 = cost model), bf16 / fp16 / fp8 (OCP e4m3, e5m2) / int8 operands.
 
     Output: the input type for 16-bit inputs; bf16 for 8-bit inputs (``out_dtype`` None or bf16), optionally
     multiplied by ``scale_a`` [M] (per row of a) and ``scale_b`` [N] (per row of b) fp32 scales in the epilogue -
@@ -174,14 +175,51 @@ def gemm_nt_tiles(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] 
         assert sc is None or (sc.dtype == torch.float32 and sc.is_contiguous() and sc.numel() == n and not want32)
     if group_m is None:
         group_m = tuning.get("gemm.group_m", 8)
+    lib = _lib.hip()
+    pbm, pbn, ps = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    pbytes, ncnt = ctypes.c_longlong(), ctypes.c_int()
+    _lib.check(lib.tdist_gemm_nt_ex_plan(M, N, K, _DT_EX[a.dtype], bm, bn, split_k or tuning.get("gemm.TILE_SPLIT_K", 0),
+                                         ctypes.byref(pbm), ctypes.byref(pbn), ctypes.byref(ps), ctypes.byref(pbytes),
+                                         ctypes.byref(ncnt)), "tdist_gemm_nt_ex_plan")
+    ws = _tile_workspace(a.device, pbytes.value, ncnt.value) if ps.value > 1 else None
     _lib.check(
-        _lib.hip().tdist_gemm_nt_ex(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), M, N, K, ctypes.c_longlong(a.stride(0)),
-                                    ctypes.c_longlong(b.stride(0)), ctypes.c_longlong(out.stride(0)), _DT_EX[a.dtype],
-                                    1 if want32 else 0, _lib.ptr(scale_a) if scale_a is not None else ctypes.c_void_p(0),
-                                    _lib.ptr(scale_b) if scale_b is not None else ctypes.c_void_p(0), bm, bn, group_m,
-                                    _lib.stream_handle()), "tdist_gemm_nt_ex")
+        lib.tdist_gemm_nt_ex(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), M, N, K, ctypes.c_longlong(a.stride(0)),
+                             ctypes.c_longlong(b.stride(0)), ctypes.c_longlong(out.stride(0)), _DT_EX[a.dtype],
+                             1 if want32 else 0, _lib.ptr(scale_a) if scale_a is not None else ctypes.c_void_p(0),
+                             _lib.ptr(scale_b) if scale_b is not None else ctypes.c_void_p(0), pbm.value, pbn.value,
+                             ps.value, _lib.ptr(ws[0]) if ws else ctypes.c_void_p(0),
+                             ctypes.c_longlong(ws[0].numel() if ws else 0), _lib.ptr(ws[1]) if ws else ctypes.c_void_p(0),
+                             ws[1].numel() if ws else 0, group_m, _lib.stream_handle()), "tdist_gemm_nt_ex")
     return out
-_CUS = {}
+
+
+_TILE_WS = {}     # (device index, stream) or (device index, "capture", id) -> (fp32 partial tiles, arrival counters)
+
+
+def _tile_workspace(device, pbytes: int, ncnt: int):
+    """Split-K workspace of ``gemm_nt_tiles``: one per device and stream (launches on a stream run in order and each
+    leaves its counters zero); under stream capture one per capture, from the graph's pool (as ``gemm_nt_mid``)."""
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    if torch.cuda.is_current_stream_capturing():
+        cid = ctypes.c_ulonglong()
+        _lib.check(_lib.hip().tdist_stream_capture_id(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream),
+                                                      ctypes.byref(cid)), "stream_capture_id")
+        key = (dev, "capture", cid.value)
+        for k in [k for k in _TILE_WS if len(k) == 3 and k[0] == dev and k[2] != cid.value]:
+            del _TILE_WS[k]
+    else:
+        key = (dev, torch.cuda.current_stream().cuda_stream)
+    ws = _TILE_WS.get(key)
+    if ws is None or ws[0].numel() < pbytes or ws[1].numel() < ncnt:
+        if ws is not None and len(key) == 3:
+            raise RuntimeError("gemm_nt_tiles: a later call of this capture needs a larger split-K workspace than the "
+                               "first one allocated; run the largest shape first")
+        ws = (torch.empty(max(pbytes, 32 << 20, ws[0].numel() if ws else 0), dtype=torch.uint8, device=device),
+              torch.zeros(max(ncnt, 4096, ws[1].numel() if ws else 0), dtype=torch.int32, device=device))
+        _TILE_WS[key] = ws
+    return ws
+
+
 _SPLITK_WS = {}   # (device index, stream) -> (counters, fp32 partial tiles)
 
 
