@@ -40,6 +40,7 @@
 #include "tdist/primitives.hpp"
 #include "tdist/race_debug.hpp"
 #include "tdist/shmem_device.hpp"
+#include "tdist/tile_plan.hpp"
 #include "tdist/ag_push.hpp"
 #include "tdist/wg_trace.hpp"
 #include "tdist/work_queue.hpp"
@@ -72,10 +73,13 @@ struct AgGemmParams {
   int split_k;               // K is cut into split_k ranges, one work item each
   int qn;                    // tile queues: qn column bands x (8 / qn) row-block residues
   int race_debug;            // tdist/race_debug.hpp
+  int push_store;            // producer stores: 0 = write-through system scope, 1 = write-through agent scope, 2 = plain + release fence
   WgTrace trace;             // tdist/wg_trace.hpp (off unless the host armed a sink)
   // Device-side call numbering (tdist/call_state.hpp).  When `state` is set, ws / flags / epoch above
   // are ignored by the host and resolved on the device from the call number: the launch is then the
   // same every time and can be replayed from a HIP graph.
+  const float* scale_a;      // optional fp32 scale per gathered row [M] / per output column [N_local] (8-bit operands)
+  const float* scale_b;
   int* state;
   uint16_t *ws0, *ws1;        // (separate fields selected with ?: - indexing an array member with the runtime
   int *flags0, *flags1;       //  parity would push the whole argument block into scratch memory)
@@ -90,13 +94,19 @@ struct AgCall {
   int epoch;
 };
 
-constexpr int TICKET_SLOT = LDS_BYTES;  // 16 bytes after the tile staging area: [0] ticket, [1] split-K arrival, [2] call number
+// 16 bytes of LDS behind the tile staging area (TileShape::LDS): [0] ticket, [1] split-K arrival, [2] call number, [3] ticket
 
 // SPLIT: false = every tile is one item (split_k == 1; no fix-up code in the kernel at all), true = split-K.
-template <bool IS_BF16, bool SPLIT>
+// DT: operand type, MT x NT: macro-tile of the tile family (gemm_gfx950.hpp; BM = 32 MT, BN = 64 NT) - chosen on the
+// host by plan_ag() so that the consumers' share of the chip is filled in one round where possible.
+template <int DT, int MT, int NT, bool SPLIT>
 __global__ __launch_bounds__(THREADS, 2) void ag_gemm_consumer_kernel(AgGemmParams p) {
+  using TS = TileShape<MT, NT>;
+  using F = Frag<DT>;
+  constexpr int BM = TS::BM, BN = TS::BN;
+  constexpr int SLOT_BYTES = MT * NT * THREADS * 16;          // one parked fp32 tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  volatile int* s_ticket = (volatile int*)(smem + TICKET_SLOT);
+  volatile int* s_ticket = (volatile int*)(smem + TS::LDS);
   const int w = p.world;
   const int M = p.M_per_rank * w;
   const int num_pid_n = (p.N_local + BN - 1) / BN;
@@ -221,10 +231,10 @@ __global__ __launch_bounds__(THREADS, 2) void ag_gemm_consumer_kernel(AgGemmPara
     t.a_rows = rows;
     t.b_rows = p.N_local - pid_n * BN;
     t.K = k1 - k0;
-    Acc<IS_BF16> acc;
-    // accumulator columns permuted (PERM_B) so the epilogue stores 16-byte pieces straight from registers:
+    AccT<MT, NT> acc;
+    // accumulator columns permuted so the epilogue stores 16-byte pieces straight from registers:
     // no LDS staging, no barrier, and the next item's first loads go out right behind the stores
-    mainloop_256_2ph<IS_BF16, true, 3>(t, smem, acc);
+    mainloop_2ph<DT, MT, NT>(t, smem, acc);
     wg_trace(tr, 4, tile);
     // The next item is looked up HERE, before this tile is written out: the main loop ends with every load
     // drained and all waves in step, so collecting the ticket and the barrier that broadcasts it cost
@@ -242,7 +252,7 @@ __global__ __launch_bounds__(THREADS, 2) void ag_gemm_consumer_kernel(AgGemmPara
       if (r < rows && c < nrem) *(uint4*)(cbase + (long long)r * ldc + c) = v;
     };
     if constexpr (!SPLIT) {
-      epilogue_256_direct<IS_BF16>(acc, store_c);
+      epilogue_direct<DT, MT, NT>(acc, DT >= DT_FP8 ? p.scale_a : nullptr, DT >= DT_FP8 ? p.scale_b : nullptr, g0, pid_n * BN, rows, nrem, store_c);
       wg_trace(tr, 5, tile);
     } else {
     // Split-K fix-up, wait-free: every item parks its fp32 accumulators (register layout, so both
@@ -251,13 +261,13 @@ __global__ __launch_bounds__(THREADS, 2) void ag_gemm_consumer_kernel(AgGemmPara
     // it is not hoisted out of the persistent loop (it would stay live across the main loop).
     unsigned voff = threadIdx.x * 16u;
     asm volatile("" : "+v"(voff));
-    char* tbase = (char*)p.partial + (long long)tile * S * (32 * THREADS * 16);
+    char* tbase = (char*)p.partial + (long long)tile * S * SLOT_BYTES;
     {
-      char* mine = tbase + (long long)ks * (32 * THREADS * 16);
+      char* mine = tbase + (long long)ks * SLOT_BYTES;
 #pragma unroll
-      for (int m = 0; m < 8; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) st_wt128_agent(mine + (voff + (unsigned)((m * 4 + n) * THREADS * 16)), acc.v[m][n]);
+        for (int n = 0; n < NT; ++n) st_wt128_agent(mine + (voff + (unsigned)((m * NT + n) * THREADS * 16)), acc.v[m][n]);
     }
     // write-through stores: drain, barrier, count - no release fence
     drain_stores();
@@ -276,17 +286,17 @@ __global__ __launch_bounds__(THREADS, 2) void ag_gemm_consumer_kernel(AgGemmPara
       // to it (loads only, so they pipeline freely) and store the tile straight from registers.
       for (int qq = 0; qq < S; ++qq) {
         if (qq == ks) continue;
-        const char* src = tbase + (long long)qq * (32 * THREADS * 16);
+        const char* src = tbase + (long long)qq * SLOT_BYTES;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-          f32x4 x[4];
+        for (int m = 0; m < MT; ++m) {
+          f32x4 x[NT];
 #pragma unroll
-          for (int n = 0; n < 4; ++n) x[n] = *(const f32x4*)(src + (voff + (unsigned)((m * 4 + n) * THREADS * 16)));
+          for (int n = 0; n < NT; ++n) x[n] = *(const f32x4*)(src + (voff + (unsigned)((m * NT + n) * THREADS * 16)));
 #pragma unroll
-          for (int n = 0; n < 4; ++n) acc.v[m][n] += x[n];
+          for (int n = 0; n < NT; ++n) acc.v[m][n] = F::add(acc.v[m][n], x[n]);
         }
       }
-      epilogue_256_direct<IS_BF16>(acc, store_c);
+      epilogue_direct<DT, MT, NT>(acc, DT >= DT_FP8 ? p.scale_a : nullptr, DT >= DT_FP8 ? p.scale_b : nullptr, g0, pid_n * BN, rows, nrem, store_c);
     }
     wg_trace(tr, 5, tile);
     }
@@ -350,11 +360,85 @@ __global__ __launch_bounds__(512) void ag_push_kernel(AgPushParams p) {
   }
 }
 
-static int check_common(const void* B, const void* C, int N_local, int K, long long ldb, long long ldc) {
-  TDIST_REQUIRE(K >= 128 && K % 64 == 0, "K must be a multiple of 64 and >= 128");
-  TDIST_REQUIRE(N_local % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0, "N_local/ldb/ldc must be multiples of 8");
+static int check_common(const void* B, const void* C, int N_local, int K16, long long ldb16, long long ldc) {
+  TDIST_REQUIRE(K16 >= 128 && K16 % 64 == 0, "K must be a multiple of 64 (16-bit) / 128 (8-bit) and >= two such steps");
+  TDIST_REQUIRE(N_local % 8 == 0 && ldb16 % 8 == 0 && ldc % 8 == 0, "N_local/ldb/ldc must keep 16-byte row alignment");
   TDIST_REQUIRE((((uintptr_t)B | (uintptr_t)C) & 15) == 0, "B and C must be 16-byte aligned");
   return 0;
+}
+
+// Tile shape and K split of the consumer for one call.  `consumers`: workgroups that compute from the start (the
+// grid minus the dedicated producers).  The cost model is the plain GEMM's (tdist/tile_plan.hpp) over the rank's
+// row blocks: a macro-tile never spans two ranks' rows unless M_per_rank is not a multiple of BM (straddle mode,
+// tiles walk the whole gathered operand).  A split is only taken while all items fit one round of consumers.
+struct AgPlan {
+  int mt, nt, split_k, straddle, tiles;
+};
+static AgPlan plan_ag(int M_per_rank, int world, int N_local, int K16, int consumers, int bm, int bn, int split_k) {
+  const int cand[3][2] = {{8, 4}, {8, 2}, {4, 4}};
+  const int ksteps = K16 / 64;
+  double best = 1e30;
+  AgPlan pick{8, 4, 1, 0, 0};
+  bool any = false;
+  for (int ci = 0; ci < 3; ++ci) {
+    const int mt = cand[ci][0], nt = cand[ci][1];
+    if ((bm && bm != 32 * mt) || (bn && bn != 64 * nt)) continue;
+    const int tbm = 32 * mt, tbn = 64 * nt;
+    const int straddle = (world > 1 && M_per_rank % tbm != 0) ? 1 : 0;
+    const int mb = straddle ? (M_per_rank * world + tbm - 1) / tbm : ((M_per_rank + tbm - 1) / tbm) * world;
+    const long long tiles = (long long)mb * ((N_local + tbn - 1) / tbn);
+    for (int s = 1; s <= 4; ++s) {
+      if (split_k && s != split_k) continue;
+      if (s > 1 && (ksteps < 2 * s || (!split_k && (ksteps / s < 8 || tiles * s > consumers)))) continue;
+      const long long items = tiles * s;
+      const long long rounds = (items + consumers - 1) / consumers;
+      const double tile_kb = tbm * tbn * 4 / 1024.0;
+      const double fix = s > 1 ? 2500.0 + 20.0 * tile_kb + (s - 1) * 30.0 * tile_kb : 0.0;
+      // a straddling walk costs the own rows a pass through the workspace; prefer aligned shapes on a near tie
+      const double total = rounds * ((ksteps / s) * gemm::tile_step_ns(mt, nt, items > consumers / 2) + 7000.0) + fix +
+                           (straddle ? 3000.0 : 0.0);
+      if (total < best) {
+        best = total;
+        pick = AgPlan{mt, nt, s, straddle, (int)tiles};
+        any = true;
+      }
+    }
+  }
+  if (!any) pick = AgPlan{8, 4, 1, (world > 1 && M_per_rank % 256 != 0) ? 1 : 0, 0};
+  return pick;
+}
+
+// What tdist_ag_gemm_consumer will do for this call (K in ELEMENTS of the operand type; dtype as tdist_gemm_nt_ex;
+// bm / bn / split_k: 0 = free): tile, split, whether tiles straddle ranks, number of tiles, bytes of fp32 partial
+// tiles the split needs, and the ints of scratch ([16 + chunks_per_rank + tiles], see below).
+TDIST_API int tdist_ag_gemm_plan(int M_per_rank, int world, int N_local, int K, int dtype, int consumers, int bm, int bn,
+                                 int split_k, int* out_bm, int* out_bn, int* out_split_k, int* out_straddle,
+                                 int* out_tiles, long long* partial_bytes) {
+  TDIST_REQUIRE(dtype >= 0 && dtype <= 4 && M_per_rank > 0 && world >= 1 && N_local > 0 && K > 0 && consumers > 0, "bad problem");
+  const int per16 = dtype >= 2 ? 2 : 1;
+  const AgPlan pl = plan_ag(M_per_rank, world, N_local, K / per16, consumers, bm, bn, split_k);
+  const int tbm = 32 * pl.mt, tbn = 64 * pl.nt;
+  const int mb = pl.straddle ? (M_per_rank * world + tbm - 1) / tbm : ((M_per_rank + tbm - 1) / tbm) * world;
+  *out_bm = tbm;
+  *out_bn = tbn;
+  *out_split_k = pl.split_k;
+  *out_straddle = pl.straddle;
+  *out_tiles = mb * ((N_local + tbn - 1) / tbn);
+  *partial_bytes = pl.split_k > 1 ? (long long)(*out_tiles) * pl.split_k * tbm * tbn * 4 : 0;
+  return 0;
+}
+
+typedef void (*ag_kern_t)(AgGemmParams);
+template <int DT>
+static ag_kern_t ag_kernel_of(int shape, bool split) {
+  switch (shape * 2 + (split ? 1 : 0)) {
+    case 0: return ag_gemm_consumer_kernel<DT, 8, 4, false>;
+    case 1: return ag_gemm_consumer_kernel<DT, 8, 4, true>;
+    case 2: return ag_gemm_consumer_kernel<DT, 8, 2, false>;
+    case 3: return ag_gemm_consumer_kernel<DT, 8, 2, true>;
+    case 4: return ag_gemm_consumer_kernel<DT, 4, 4, false>;
+    default: return ag_gemm_consumer_kernel<DT, 4, 4, true>;
+  }
 }
 
 // scratch layout (int32): [0] error word (sticky, never cleared here), [1] finished-workgroup counter,
@@ -363,30 +447,45 @@ static int check_common(const void* B, const void* C, int N_local, int K, long l
 // it zero again (call_state.hpp).
 // `state` != nullptr: device-side call numbering; ws / flags are then parity 0 and ws1 / flags1 parity 1,
 // and `epoch` is ignored.
+// dtype: 0 = bf16, 1 = fp16, 2 = fp8 e4m3, 3 = fp8 e5m2, 4 = int8 (8-bit operands: bf16 output, optional fp32
+// scale_a [M] per gathered row and scale_b [N_local] per column).  K, lda_local, ld_ws, ldb in ELEMENTS of the
+// operand type.  bm / bn / split_k / straddle: as returned by tdist_ag_gemm_plan for this call.
 TDIST_API int tdist_ag_gemm_consumer(const tdist::SymmCtx* ctx, const void* a_local, void* ws, const void* B, void* C,
                                      int* flags, int* scratch, long long scratch_ints, void* partial,
                                      long long partial_bytes, long long lda_local, long long ld_ws, long long ldb,
                                      long long ldc, int M_per_rank, int N_local, int K, int rows_per_chunk, int epoch,
                                      int straddle, int push_wgs, int split_k, int num_ctas, int dtype, void* stream,
-                                     int* state, void* ws1, int* flags1) {
+                                     int* state, void* ws1, int* flags1, int bm, int bn, const float* scale_a,
+                                     const float* scale_b) {
+  TDIST_REQUIRE(dtype >= 0 && dtype <= 4, "dtype must be 0..4");
+  const int per16 = dtype >= 2 ? 2 : 1;
+  TDIST_REQUIRE(K % per16 == 0 && lda_local % per16 == 0 && ld_ws % per16 == 0 && ldb % per16 == 0, "odd 8-bit strides");
+  K /= per16;                 // from here on in 16-bit units
+  lda_local /= per16;
+  ld_ws /= per16;
+  ldb /= per16;
   if (check_common(B, C, N_local, K, ldb, ldc)) return -1;
   TDIST_REQUIRE(!state || (ws1 && flags1 && (((uintptr_t)ws1) & 15) == 0), "device-side call numbering needs both parities");
   const int world = ctx->num_ranks, rank = ctx->rank;
   TDIST_REQUIRE(world >= 1 && world <= TDIST_MAX_RANKS && rank >= 0 && rank < world, "bad rank/world");
   TDIST_REQUIRE(M_per_rank > 0 && rows_per_chunk > 0 && M_per_rank % rows_per_chunk == 0,
                 "M_per_rank must be a positive multiple of rows_per_chunk");
-  TDIST_REQUIRE(lda_local % 8 == 0 && ld_ws % 8 == 0, "lda must be a multiple of 8");
+  TDIST_REQUIRE(lda_local % 8 == 0 && ld_ws % 8 == 0, "lda must keep 16-byte row alignment");
   TDIST_REQUIRE((((uintptr_t)a_local | (uintptr_t)ws) & 15) == 0, "A operands must be 16-byte aligned");
-  TDIST_REQUIRE(push_wgs >= 0 && push_wgs <= 64, "push_wgs must be in [0, 64]");
+  TDIST_REQUIRE(push_wgs >= 0 && push_wgs <= 128, "push_wgs must be in [0, 128]");
   TDIST_REQUIRE(push_wgs == 0 || ld_ws == K, "the in-kernel producer needs a dense [M, K] workspace");
+  if (bm == 0) bm = 256;
+  if (bn == 0) bn = 256;
+  TDIST_REQUIRE((bm == 256 && (bn == 256 || bn == 128)) || (bm == 128 && bn == 256), "tile must be 256x256, 256x128 or 128x256");
   TDIST_REQUIRE(split_k >= 1 && split_k <= 4 && K / BK >= 2 * split_k, "split_k must be in [1, 4] with >= 128 of K each");
+  TDIST_REQUIRE(straddle || world == 1 || M_per_rank % bm == 0, "tiles that cross ranks need straddle mode");
   const int M = M_per_rank * world;
   const int cpr = M_per_rank / rows_per_chunk;
-  const int total_mb = straddle ? (M + BM - 1) / BM : ((M_per_rank + BM - 1) / BM) * world;
-  const int tiles = total_mb * ((N_local + BN - 1) / BN);
+  const int total_mb = straddle ? (M + bm - 1) / bm : ((M_per_rank + bm - 1) / bm) * world;
+  const int tiles = total_mb * ((N_local + bn - 1) / bn);
   const long long need_ints = 16 + cpr + (split_k > 1 ? tiles : 0);
   TDIST_REQUIRE(scratch_ints >= ((need_ints + 3) & ~3ll), "scratch too small");
-  TDIST_REQUIRE(split_k == 1 || (partial && partial_bytes >= (long long)tiles * split_k * 32 * THREADS * 16),
+  TDIST_REQUIRE(split_k == 1 || (partial && partial_bytes >= (long long)tiles * split_k * bm * bn * 4),
                 "split-K partial buffer too small");
   AgGemmParams p;
   p.ctx = *ctx;
@@ -418,13 +517,19 @@ TDIST_API int tdist_ag_gemm_consumer(const tdist::SymmCtx* ctx, const void* a_lo
   p.split_k = split_k;
   {
     // column bands first (B panels are the larger operand to share), row-block residues for the rest
-    const int npn = (N_local + BN - 1) / BN;
+    const int npn = (N_local + bn - 1) / bn;
     int qn = 1;
     while (qn < 8 && qn * 2 <= npn) qn *= 2;
     p.qn = qn;
   }
   p.race_debug = race_debug_enabled();
+  {
+    static const int ps = getenv("TDIST_PUSH_STORE") ? atoi(getenv("TDIST_PUSH_STORE")) : 0;
+    p.push_store = ps;
+  }
   p.trace = wg_trace_sink();
+  p.scale_a = scale_a;
+  p.scale_b = scale_b;
   p.state = state;
   p.ws0 = (uint16_t*)ws;
   p.ws1 = (uint16_t*)ws1;
@@ -447,28 +552,28 @@ TDIST_API int tdist_ag_gemm_consumer(const tdist::SymmCtx* ctx, const void* a_lo
   if (trace)
     fprintf(stderr,
             "[tdist] ag_gemm rank %d/%d a=%p ws0=%p ws1=%p B=%p C=%p flags0=%p flags1=%p scratch=%p(%lld ints) "
-            "partial=%p(%lld B) state=%p Mr=%d N=%d K=%d rpc=%d straddle=%d push=%d splitk=%d grid=%d total=%d\n",
+            "partial=%p(%lld B) state=%p Mr=%d N=%d K16=%d rpc=%d straddle=%d push=%d splitk=%d tile=%dx%d grid=%d total=%d\n",
             rank, world, a_local, ws, ws1, B, C, (void*)flags, (void*)flags1, (void*)scratch, scratch_ints, partial,
-            partial_bytes, (void*)state, M_per_rank, N_local, K, rows_per_chunk, straddle, p.push_wgs, split_k, grid,
-            total);
-  static bool attr_set = false;
-  if (!attr_set) {
-    typedef void (*kern_t)(AgGemmParams);
-    const kern_t all[4] = {ag_gemm_consumer_kernel<true, false>, ag_gemm_consumer_kernel<true, true>,
-                           ag_gemm_consumer_kernel<false, false>, ag_gemm_consumer_kernel<false, true>};
-    for (int i = 0; i < 4; ++i)
-      TDIST_HIP_TRY(hipFuncSetAttribute((const void*)all[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 16));
-    attr_set = true;
+            partial_bytes, (void*)state, M_per_rank, N_local, K, rows_per_chunk, straddle, p.push_wgs, split_k, bm, bn,
+            grid, total);
+  const int shape = bm == 256 ? (bn == 256 ? 0 : 1) : 2;
+  const bool split = split_k > 1;
+  ag_kern_t kern;
+  switch (dtype) {
+    case 0: kern = ag_kernel_of<DT_BF16>(shape, split); break;
+    case 1: kern = ag_kernel_of<DT_F16>(shape, split); break;
+    case 2: kern = ag_kernel_of<DT_FP8>(shape, split); break;
+    case 3: kern = ag_kernel_of<DT_BF8>(shape, split); break;
+    default: kern = ag_kernel_of<DT_I8>(shape, split); break;
   }
-  const dim3 g(grid), b(THREADS);
-  if (dtype == 0 && split_k == 1)
-    hipLaunchKernelGGL((ag_gemm_consumer_kernel<true, false>), g, b, LDS_BYTES + 16, (hipStream_t)stream, p);
-  else if (dtype == 0)
-    hipLaunchKernelGGL((ag_gemm_consumer_kernel<true, true>), g, b, LDS_BYTES + 16, (hipStream_t)stream, p);
-  else if (split_k == 1)
-    hipLaunchKernelGGL((ag_gemm_consumer_kernel<false, false>), g, b, LDS_BYTES + 16, (hipStream_t)stream, p);
-  else
-    hipLaunchKernelGGL((ag_gemm_consumer_kernel<false, true>), g, b, LDS_BYTES + 16, (hipStream_t)stream, p);
+  static const int lds_of[3] = {TileShape<8, 4>::LDS + 16, TileShape<8, 2>::LDS + 16, TileShape<4, 4>::LDS + 16};
+  // (per kernel, once: the attribute call is cheap but not free)
+  static bool attr_set[5][3][2] = {};
+  if (!attr_set[dtype][shape][split]) {
+    TDIST_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_of[shape]));
+    attr_set[dtype][shape][split] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds_of[shape], (hipStream_t)stream, p);
   TDIST_HIP_TRY(hipGetLastError());
   return 0;
 }

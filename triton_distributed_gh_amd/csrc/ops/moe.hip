@@ -193,6 +193,7 @@ struct GroupGemmParams {
   int* push_flags;            // = flags, as the symmetric pointer the producers store through
   int* push_done;
   int M_per_rank, rows_per_chunk, rank, world, push_wgs, straddle, race_debug;
+  int push_store = 0;       // see ag_push.hpp
   WgTrace trace;              // tdist/wg_trace.hpp (off unless the host armed a sink)
   // Device-side call numbering (tdist/call_state.hpp).  With `state` set, A / ws / flags / epoch above are
   // ignored: parity and flag value come from the call number on the device (ws, flags = parity 0; ws1, flags1 =

@@ -32,7 +32,7 @@ from .. import _lib
 from ..autotuner import tuning
 from ..utils.distributed import default_num_ctas, forbid_graph_capture, get_env
 from . import tp_ll
-from .gemm import _DT, gemm_nt
+from .gemm import _DT_EX, gemm_nt
 
 EPOCH_MOD = 4093
 _BM = 256
@@ -193,7 +193,7 @@ def _push_kernel(ctx, a, parity, epoch, rpc, include_self, stream):
                                  1 if include_self else 0, _lib.stream_handle(stream)), "tdist_ag_push_kernel")
 
 
-def ag_gemm_intra_node_op(a, b, c, ctx: AllGatherGEMMTensorParallelContext):
+def ag_gemm_intra_node_op(a, b, c, ctx: AllGatherGEMMTensorParallelContext, scale_a=None, scale_b=None):
     env = ctx.env
     w, rank = ctx.num_ranks, ctx.rank
     M_per_rank, K = a.shape
@@ -202,6 +202,9 @@ def ag_gemm_intra_node_op(a, b, c, ctx: AllGatherGEMMTensorParallelContext):
     assert M_per_rank * w <= ctx.max_M, "M exceeds the context's max_M"
     assert a.dtype == b.dtype == ctx.dtype
     if w == 1 and os.environ.get("TDIST_FORCE_FUSED", "0") != "1":
+        if a.element_size() == 1 or scale_a is not None or scale_b is not None:
+            from .gemm import gemm_nt_tiles
+            return gemm_nt_tiles(a, b, out=c, scale_a=scale_a, scale_b=scale_b)
         gemm_nt(a, b, out=c)
         return c
     if w > 1 and tp_ll.ll_applies(ctx.ll, M_per_rank * w, N_local, K, a, b) and not DEBUG_RACES:
@@ -219,28 +222,35 @@ def ag_gemm_intra_node_op(a, b, c, ctx: AllGatherGEMMTensorParallelContext):
     epoch = ctx.call_count % EPOCH_MOD + 1
     ctx.call_count += 1
     rpc = _rows_per_chunk(M_per_rank, tuning.get("ag_gemm.M_PER_CHUNK", ctx.M_PER_CHUNK))
-    straddle = M_per_rank % _BM != 0
 
     if ctx.backend == "host":
-        return _ag_gemm_host(a, b, c, ctx, parity, epoch, rpc)
+        return _ag_gemm_host(a, b, c, ctx, parity, epoch, rpc, scale_a, scale_b)
 
     lib = _lib.hip()
     cur = torch.cuda.current_stream()
-    used = []
+    grid = ctx.num_ctas or _num_cus()
     push_wgs = 0
-    if w > 1:
-        if ctx.producer == "none":
-            pass    # the caller gathers (copy engines, another op) and raises the flags itself
-        elif ctx.producer == "kernel":
-            # producer work items ride in the consumer launch (see csrc/ops/ag_gemm.hip)
-            # one workgroup moves ~12-16 GB/s; 8 per outgoing xGMI link keeps every link saturated
-            push_wgs = tuning.get("ag_gemm.PUSH_WGS", 0) or max(8, min(32, 8 * (w - 1)))
-        else:
-            for s in ctx.ag_streams:
-                s.wait_stream(cur)
-            _push_copy_engine(ctx, a, parity, epoch, rpc, straddle)
-            used = ctx.ag_streams
-        if ctx.serial and used:
+    if w > 1 and ctx.producer == "kernel":
+        # producer work items ride in the consumer launch (see csrc/ops/ag_gemm.hip)
+        # one workgroup moves ~12-20 GB/s; 8 per outgoing xGMI link keeps every link saturated
+        push_wgs = tuning.get("ag_gemm.PUSH_WGS", 0) or max(8, min(32, 8 * (w - 1)))
+    plan = _plan(ctx, M_per_rank, w, N_local, K, a.dtype, grid - push_wgs)
+    bm, bn, split_k, tiles = plan.bm, plan.bn, plan.split_k, plan.tiles
+    straddle = bool(plan.straddle) and w > 1
+    if push_wgs and not tuning.get("ag_gemm.PUSH_WGS", 0):
+        # CUs that the consumers' single round leaves idle push as well (up to 64 producers): the shard is out
+        # sooner and nobody who could compute is taken away
+        idle = grid - push_wgs - tiles * split_k
+        if idle > 0:
+            push_wgs = min(64, push_wgs + idle)
+    used = []
+    if w > 1 and ctx.producer not in ("kernel", "none"):
+        # ("none": the caller gathers - copy engines, another op - and raises the flags itself)
+        for s in ctx.ag_streams:
+            s.wait_stream(cur)
+        _push_copy_engine(ctx, a, parity, epoch, rpc, straddle)
+        used = ctx.ag_streams
+        if ctx.serial:
             for s in used:
                 cur.wait_stream(s)
             torch.cuda.synchronize()
@@ -249,9 +259,6 @@ def ag_gemm_intra_node_op(a, b, c, ctx: AllGatherGEMMTensorParallelContext):
 
     ws = ctx.workspaces[0 if device_calls else parity][rank]
     fl = ctx.flags[0 if device_calls else parity][rank]
-    straddle = straddle and w > 1
-    tiles = _num_tiles(M_per_rank, w, N_local, straddle)
-    split_k = _pick_split_k(tiles, K, (ctx.num_ctas or _num_cus()) - push_wgs)
     cpr = M_per_rank // rpc
     need = (16 + cpr + (tiles if split_k > 1 else 0) + 3) & ~3
     capturing = torch.cuda.is_current_stream_capturing()
@@ -263,7 +270,7 @@ def ag_gemm_intra_node_op(a, b, c, ctx: AllGatherGEMMTensorParallelContext):
         ctx.scratch = torch.zeros(need, dtype=torch.int32, device=env.device)
     partial, partial_bytes = None, 0
     if split_k > 1:
-        partial_bytes = tiles * split_k * _BM * _BM * 4
+        partial_bytes = plan.partial_bytes
         if ctx.partial is None or ctx.partial.numel() < partial_bytes:
             _may_grow(ctx, capturing, "split-K partial buffer")
             if ctx.partial is not None:
@@ -281,11 +288,13 @@ def ag_gemm_intra_node_op(a, b, c, ctx: AllGatherGEMMTensorParallelContext):
                                    ctypes.c_longlong(partial_bytes), ctypes.c_longlong(a.stride(0)),
                                    ctypes.c_longlong(ws.stride(0)), ctypes.c_longlong(b.stride(0)),
                                    ctypes.c_longlong(c.stride(0)), M_per_rank, N_local, K, rpc, epoch,
-                                   1 if straddle else 0, push_wgs, split_k, ctx.num_ctas, _DT[a.dtype],
+                                   1 if straddle else 0, push_wgs, split_k, ctx.num_ctas, _DT_EX[a.dtype],
                                    _lib.stream_handle(cur),
                                    _lib.ptr(ctx.state) if device_calls else ctypes.c_void_p(0),
                                    _lib.ptr(ctx.workspaces[1][rank]) if device_calls else ctypes.c_void_p(0),
-                                   _lib.ptr(ctx.flags[1][rank]) if device_calls else ctypes.c_void_p(0)),
+                                   _lib.ptr(ctx.flags[1][rank]) if device_calls else ctypes.c_void_p(0), bm, bn,
+                                   _lib.ptr(scale_a) if scale_a is not None else ctypes.c_void_p(0),
+                                   _lib.ptr(scale_b) if scale_b is not None else ctypes.c_void_p(0)),
                "tdist_ag_gemm_consumer")
     # `a` is read by the copy-engine streams; joining them keeps the caller free to reuse it in stream order
     for s in used:
@@ -300,7 +309,7 @@ def ag_gemm_intra_node_op(a, b, c, ctx: AllGatherGEMMTensorParallelContext):
 def _scratch_ints(max_M: int, w: int, N_local: int, max_chunks: int) -> int:
     """[0] error word, [1] finished workgroups, [4] push ticket, [8:16] tile-queue tickets, [16:] push counters +
     split-K arrival counters (layout of csrc/ops/ag_gemm.hip)."""
-    max_tiles = (-(-max_M // _BM) + w) * -(-N_local // _BM)
+    max_tiles = (-(-max_M // 128) + w) * -(-N_local // 128)       # the smallest macro-tile edge of the tile family
     return (16 + max_chunks + max_tiles + 3) & ~3
 
 
@@ -311,9 +320,31 @@ def _may_grow(ctx, capturing: bool, what: str) -> None:
                            "context with the largest shape (max_M, N) or run the largest shape once before capturing")
 
 
-def _num_tiles(M_per_rank: int, w: int, N_local: int, straddle: bool) -> int:
-    mb = -(-(M_per_rank * w) // _BM) if straddle else -(-M_per_rank // _BM) * w
-    return mb * -(-N_local // _BM)
+@dataclasses.dataclass
+class _AgPlan:
+    bm: int
+    bn: int
+    split_k: int
+    straddle: int
+    tiles: int
+    partial_bytes: int
+
+
+def _plan(ctx, M_per_rank: int, w: int, N_local: int, K: int, dtype, consumers: int) -> _AgPlan:
+    """Tile shape and K split of the consumer kernel for this call (csrc/ops/ag_gemm.hip: plan_ag): the macro-tile
+    of the tile family (256x256, 256x128, 128x256) and the split that fill the consumers' share of the chip in one
+    round.  ``ag_gemm.SPLIT_K`` / TDIST_AG_SPLIT_K and ``ag_gemm.TILE`` / TDIST_AG_TILE (e.g. "128x256") override."""
+    forced = int(os.environ.get("TDIST_AG_SPLIT_K", "0")) or tuning.get("ag_gemm.SPLIT_K", 0)
+    tile = os.environ.get("TDIST_AG_TILE", "") or tuning.get("ag_gemm.TILE", "")
+    fbm, fbn = (int(x) for x in tile.split("x")) if tile else (0, 0)
+    if ctx is not None and (ctx.BLOCK_M, ctx.BLOCK_N) != (256, 256) and not tile:
+        fbm, fbn = ctx.BLOCK_M, ctx.BLOCK_N          # a context created with an explicit tile keeps it
+    bm, bn, sk, st, tiles = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    pb = ctypes.c_longlong()
+    _lib.check(_lib.hip().tdist_ag_gemm_plan(M_per_rank, w, N_local, K, _DT_EX[dtype], max(consumers, 1), fbm, fbn, forced,
+                                             ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(sk), ctypes.byref(st),
+                                             ctypes.byref(tiles), ctypes.byref(pb)), "tdist_ag_gemm_plan")
+    return _AgPlan(bm.value, bn.value, sk.value, st.value, tiles.value, pb.value)
 
 
 _NUM_CUS = 0
@@ -324,17 +355,6 @@ def _num_cus() -> int:
     if not _NUM_CUS:
         _NUM_CUS = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
     return _NUM_CUS
-
-
-def _pick_split_k(tiles: int, K: int, grid: int) -> int:
-    """Cut K when there are fewer tiles than consumer workgroups (large TP degree): up to 4 ranges, each at
-    least 512 deep.  ``grid`` is the number of workgroups that compute from the start (the grid minus the
-    dedicated producers): all items then run in ONE round - with one item per workgroup of the whole grid,
-    the producers' items would form a second round behind their pushes.
-    ``ag_gemm.SPLIT_K`` (tuning knob / TDIST_AG_SPLIT_K) overrides."""
-    forced = int(os.environ.get("TDIST_AG_SPLIT_K", "0")) or tuning.get("ag_gemm.SPLIT_K", 0)
-    s = forced if forced else max(1, min(4, grid // max(tiles, 1), K // 512))
-    return max(1, min(s, 4, K // 128))
 
 
 def _all_gather_host(a, ctx, parity, epoch, rpc):
@@ -364,20 +384,50 @@ def _all_gather_host(a, ctx, parity, epoch, rpc):
     return blocks
 
 
-def _ag_gemm_host(a, b, c, ctx, parity, epoch, rpc):
+def _ag_gemm_host(a, b, c, ctx, parity, epoch, rpc, scale_a=None, scale_b=None):
     M_per_rank = a.shape[0]
     for s, src in enumerate(_all_gather_host(a, ctx, parity, epoch, rpc)):
-        c[s * M_per_rank:(s + 1) * M_per_rank] = (src.float() @ b.float().t()).to(c.dtype)
+        blk = src.float() @ b.float().t()
+        if scale_a is not None:
+            blk = blk * scale_a[s * M_per_rank:(s + 1) * M_per_rank, None]
+        if scale_b is not None:
+            blk = blk * scale_b[None, :]
+        c[s * M_per_rank:(s + 1) * M_per_rank] = blk.to(c.dtype)
     return c
 
 
-def ag_gemm_intra_node(a, b, transe_b=False, ctx: Optional[AllGatherGEMMTensorParallelContext] = None):
-    """a: [M_per_rank, K], b: [N_per_rank, K] (``transe_b=False``).  Returns [M, N_per_rank]."""
+_TRANSPOSED = {}     # (data_ptr, shape, strides, dtype, version) -> K-contiguous copy of a [K, N] weight
+
+
+def k_contiguous_weight(b: torch.Tensor) -> torch.Tensor:
+    """``b`` is a [K, N] weight (``transe_b=True`` of the reference's ops): the [N, K] K-contiguous form the tile
+    engine streams, made once per weight and kept (keyed by storage, layout and version counter, so an in-place
+    update of the weight makes a new copy) instead of a 100+ MB transpose in front of every call."""
+    if b.stride(0) == 1 and b.dim() == 2:
+        return b.t()                           # already K-contiguous underneath: a view
+    key = (b.data_ptr(), tuple(b.shape), tuple(b.stride()), b.dtype, b._version)
+    hit = _TRANSPOSED.get(key)
+    if hit is None:
+        if len(_TRANSPOSED) >= 64:
+            _TRANSPOSED.clear()
+        hit = b.t().contiguous()
+        _TRANSPOSED[key] = hit
+    return hit
+
+
+def ag_gemm_intra_node(a, b, transe_b=False, ctx: Optional[AllGatherGEMMTensorParallelContext] = None,
+                       scale_a: Optional[torch.Tensor] = None, scale_b: Optional[torch.Tensor] = None):
+    """a: [M_per_rank, K], b: [N_per_rank, K] (``transe_b=False``).  Returns [M, N_per_rank].
+
+    Operand types: bf16 / fp16 (output of the same type) and fp8 e4m3 / e5m2 / int8 (bf16 output; the all-gather
+    then moves half the bytes per xGMI link).  ``scale_a`` [M] (fp32, one per GATHERED row - every rank passes the
+    same full vector) and ``scale_b`` [N_per_rank] de-quantise the output in the epilogue."""
     if ctx is None:
         raise RuntimeError("ag_gemm_intra_node requires a context (symmetric workspaces)")
     if transe_b:
-        b = b.t().contiguous()
+        b = k_contiguous_weight(b)
     M_per_rank = a.shape[0]
     N_local = b.shape[0]
-    c = torch.empty([ctx.num_ranks * M_per_rank, N_local], dtype=a.dtype, device=a.device)
-    return ag_gemm_intra_node_op(a, b, c, ctx)
+    out_dtype = torch.bfloat16 if a.element_size() == 1 else a.dtype
+    c = torch.empty([ctx.num_ranks * M_per_rank, N_local], dtype=out_dtype, device=a.device)
+    return ag_gemm_intra_node_op(a, b, c, ctx, scale_a=scale_a, scale_b=scale_b)

@@ -220,7 +220,7 @@ def _tile_workspace(device, pbytes: int, ncnt: int):
     return ws
 
 
-_SPLITK_WS = {}   # (device index, stream) -> (counters, fp32 partial tiles)
+_CUS = {}
 
 
 def _num_cus(device) -> int:
@@ -231,54 +231,17 @@ def _num_cus(device) -> int:
 
 
 def gemm_nt_splitk(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, split_k: int = 0) -> torch.Tensor:
-    """``a @ b^T`` with K cut into ``split_k`` (default: as many as fill the chip, at most 4, each >= 512 deep)
-    ranges per 256x256 tile.  Runs the AG + GEMM consumer kernel (csrc/ops/ag_gemm.hip) as a single rank: its
-    work items are (tile, K range) pairs drawn from per-XCD queues, every item parks its fp32 accumulators
-    and the last one of a tile sums them and stores the tile - no second launch, nobody waits.  The kernel
-    re-arms its own counters, so the launch is one kernel node (HIP-graph capturable) and consecutive calls on
-    a stream share one workspace."""
-    from ..utils.symm import SymmCtxStruct
-
+    """``a @ b^T`` on 256x256 tiles with K cut into ``split_k`` ranges (default: as many as fill the chip, at most
+    4, each >= 512 deep), joined wait-free inside the launch (``gemm_nt_tiles`` with the tile pinned).  The kernel
+    re-arms its own counters, so the launch is one kernel node (HIP-graph capturable) and consecutive calls on a
+    stream share one workspace."""
     M, K = a.shape
     N = b.shape[0]
-    if out is None:
-        out = torch.empty((M, N), dtype=a.dtype, device=a.device)
     cus = _num_cus(a.device)
     tiles = -(-M // 256) * -(-N // 256)
     s = split_k or tuning.get("gemm.SPLIT_K", 0) or max(1, min(4, cus // tiles, K // 512))
     s = max(1, min(s, 4, K // 128))
-    dev = a.device.index if a.device.index is not None else torch.cuda.current_device()
-    need_ints = (16 + 1 + tiles + 3) & ~3
-    pbytes = tiles * s * 256 * 256 * 4 if s > 1 else 0
-    if torch.cuda.is_current_stream_capturing():
-        # one workspace per capture, from the graph's private pool (it lives as long as the graph); see gemm_nt_mid
-        cid = ctypes.c_ulonglong()
-        _lib.check(_lib.hip().tdist_stream_capture_id(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream),
-                                                      ctypes.byref(cid)), "stream_capture_id")
-        key = (dev, "capture", cid.value)
-        for k in [k for k in _SPLITK_WS if len(k) == 3 and k[0] == dev and k[2] != cid.value]:
-            del _SPLITK_WS[k]
-    else:
-        key = (dev, torch.cuda.current_stream().cuda_stream)
-    ws = _SPLITK_WS.get(key)
-    if ws is None or ws[0].numel() < need_ints or ws[1].numel() < pbytes:
-        if ws is not None and len(key) == 3:
-            raise RuntimeError("gemm_nt_splitk: a later call of this capture needs a larger workspace than the first "
-                               "one allocated; run the largest shape first")
-        ws = (torch.zeros(max(need_ints, 1024), dtype=torch.int32, device=a.device),
-              torch.empty(max(pbytes, cus * 256 * 256 * 4), dtype=torch.uint8, device=a.device))
-        _SPLITK_WS[key] = ws
-    cs = SymmCtxStruct()
-    cs.rank, cs.num_ranks = 0, 1
-    _lib.check(
-        _lib.hip().tdist_ag_gemm_consumer(ctypes.byref(cs), _lib.ptr(a), _lib.ptr(a), _lib.ptr(b), _lib.ptr(out),
-                                          ctypes.c_void_p(0), _lib.ptr(ws[0]), ctypes.c_longlong(ws[0].numel()),
-                                          _lib.ptr(ws[1]) if s > 1 else ctypes.c_void_p(0), ctypes.c_longlong(pbytes),
-                                          ctypes.c_longlong(a.stride(0)), ctypes.c_longlong(a.stride(0)),
-                                          ctypes.c_longlong(b.stride(0)), ctypes.c_longlong(out.stride(0)), M, N, K, M, 1,
-                                          0, 0, s, 0, _DT[a.dtype], _lib.stream_handle(), ctypes.c_void_p(0),
-                                          ctypes.c_void_p(0), ctypes.c_void_p(0)), "tdist_ag_gemm_consumer (split-K GEMM)")
-    return out
+    return gemm_nt_tiles(a, b, out, bm=256, bn=256, split_k=s)
 
 
 _MID_WS = {}      # device index -> (fp32 split-K workspace, arrival counters)
