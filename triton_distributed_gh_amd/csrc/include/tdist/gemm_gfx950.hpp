@@ -359,7 +359,7 @@ __device__ __forceinline__ void mainloop_256(const TileArgs& t, char* smem, Acc<
 //       segment for the A pieces of DS 0.  Phase 0 then retires ALL its fragment reads before its first barrier
 //       (the other wave group restages the A0 slot right after that barrier).
 // OPT bit 4: issue a segment's LDS-DMA pieces before its fragment reads instead of after them.
-template <bool IS_BF16, bool PERM_B = false, int OPT = 0, int DS = 0>
+template <int IS_BF16, bool PERM_B = false, int OPT = 0, int DS = 0>
 __device__ __forceinline__ void mainloop_256_2ph(const TileArgs& t, char* smem, Acc<IS_BF16>& acc) {
   using F = Frag<IS_BF16>;
   using V = typename F::T;
@@ -431,13 +431,21 @@ __device__ __forceinline__ void mainloop_256_2ph(const TileArgs& t, char* smem, 
   V a[4][2], b0[2][2], b1[2][2];
   constexpr bool PROG = (OPT & 1) != 0, NOPRIO = (OPT & 2) != 0, DMA_FIRST = (OPT & 4) != 0;
   // MFMAs of one 16-row block m of the current 64-row half (both k halves, all four column tiles)
+  // (the IS_BF16 parameter is the operand type DT_*: 8-bit types pair the two k halves in one 128-deep MFMA)
   auto mfma_row = [&](int m, int mo) {
+    if constexpr (F::K128) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+      for (int n = 0; n < 2; ++n) acc.v[mo + m][n] = F::mfma2(b0[n][0], b0[n][1], a[m][0], a[m][1], acc.v[mo + m][n]);
 #pragma unroll
-      for (int n = 0; n < 2; ++n) acc.v[mo + m][n] = F::mfma(b0[n][ks], a[m][ks], acc.v[mo + m][n]);
+      for (int n = 0; n < 2; ++n) acc.v[mo + m][2 + n] = F::mfma2(b1[n][0], b1[n][1], a[m][0], a[m][1], acc.v[mo + m][2 + n]);
+    } else {
 #pragma unroll
-      for (int n = 0; n < 2; ++n) acc.v[mo + m][2 + n] = F::mfma(b1[n][ks], a[m][ks], acc.v[mo + m][2 + n]);
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc.v[mo + m][n] = F::mfma(b0[n][ks], a[m][ks], acc.v[mo + m][n]);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc.v[mo + m][2 + n] = F::mfma(b1[n][ks], a[m][ks], acc.v[mo + m][2 + n]);
+      }
     }
   };
   for (int kt = 0; kt < nt; ++kt) {
@@ -506,6 +514,9 @@ __device__ __forceinline__ void mainloop_256_2ph(const TileArgs& t, char* smem, 
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       mfma_row(3, 0);
+    } else if constexpr (F::K128) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) mfma_row(m, 0);
     } else {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -566,7 +577,10 @@ __device__ __forceinline__ void mainloop_256_2ph(const TileArgs& t, char* smem, 
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     if constexpr (!NOPRIO) __builtin_amdgcn_s_setprio(1);
-    {
+    if constexpr (F::K128) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) mfma_row(m, 4);
+    } else {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -589,7 +603,7 @@ __device__ __forceinline__ void mainloop_256_2ph(const TileArgs& t, char* smem, 
 // (pass*16 + tid/32) and columns (tid%32)*8.  `get(m, v)` fills v[0..3] with the calling thread's
 // fp32 values of accumulator tiles (m, 0..3) in the Acc layout.  Ends with a workgroup barrier so
 // LDS may be reused.
-template <bool IS_BF16, class GetFn, class StoreFn>
+template <int IS_BF16, class GetFn, class StoreFn>
 __device__ __forceinline__ void epilogue_256_from(GetFn&& get, char* smem, StoreFn&& store) {
   using F = Frag<IS_BF16>;
   const int tid = threadIdx.x;
@@ -659,7 +673,7 @@ __device__ __forceinline__ void epilogue_256_direct(const Acc<IS_BF16>& acc, Sto
       store);
 }
 
-template <bool IS_BF16, class StoreFn>
+template <int IS_BF16, class StoreFn>
 __device__ __forceinline__ void epilogue_256(const Acc<IS_BF16>& acc, char* smem, StoreFn&& store) {
   epilogue_256_from<IS_BF16>(
       [&](int m, f32x4(&v)[4]) {

@@ -53,9 +53,11 @@ struct GemmRsParams {
   int* err;
   uint16_t* out;         // [M_per_rank, N]
   long long lda, ldb, ldo;
-  int M_per_rank, N, K;
+  int M_per_rank, N, K;      // (8-bit operands: A, B, lda, ldb, K in 16-bit units = two elements)
   int rows_per_chunk;
   int epoch;
+  const float* scale_a;      // optional fp32 scales of the partial sums (8-bit operands): per row of A [M] ...
+  const float* scale_b;      // ... and per row of B [N]; both ranks' partials are de-quantised before the reduction
   int* dbg;               // optional progress trace: [grid][4] ints (last item, stage, items done, spare)
   // Device-side call numbering (tdist/call_state.hpp): when `state` is set, scatter / flags / epoch are
   // resolved on the device from the call number and the launch can be replayed from a HIP graph.
@@ -154,8 +156,10 @@ __device__ __forceinline__ void reduce_item(const GemmRsParams& p, const RsCall&
   }
 }
 
-template <bool IS_BF16>
+// DT: operand type (gemm_gfx950.hpp DT_*).  Partials and output are 16-bit: f16 for f16 operands, bf16 otherwise.
+template <int DT>
 __global__ __launch_bounds__(THREADS, 2) void gemm_rs_kernel(GemmRsParams p) {
+  constexpr bool IS_BF16 = DT != DT_F16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   volatile int* s_ticket = (volatile int*)(smem + RS_TICKET_SLOT);
   const int w = p.ctx.num_ranks, rank = p.ctx.rank;
@@ -253,8 +257,8 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_rs_kernel(GemmRsParams p) {
     t.a_rows = rows;
     t.b_rows = p.N - pid_n * BN;
     t.K = p.K;
-    Acc<IS_BF16> acc;
-    mainloop_256_2ph<IS_BF16, false, 3>(t, smem, acc);
+    Acc<DT> acc;
+    mainloop_256_2ph<DT, false, 3>(t, smem, acc);
     // GEMM and reduce items differ in length by 10-40x: the next item is drawn only now, under the epilogue,
     // so a workgroup does not commit to another tile while idle workgroups could take it
     wq.prefetch();
@@ -271,9 +275,35 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_rs_kernel(GemmRsParams p) {
     // barrier, count.  The tile is staged through LDS so that every row leaves as one contiguous 512-byte
     // run: write-through stores are not merged in L2, and 64-byte pieces straight from the accumulator
     // layout cost 1.5x the time in HBM (and would halve the xGMI packet size).
-    epilogue_256<IS_BF16>(acc, smem, [&](int r, int cc, const uint4& v) {
+    auto store_tile = [&](int r, int cc, const uint4& v) {
       if (r < rows && cc < nrem) st_wt128_sys(cbase + (long long)r * ldn + cc, v);
-    });
+    };
+    if (DT >= DT_FP8 && (p.scale_a || p.scale_b)) {
+      // de-quantise: accumulator tile (m, n) of this lane is row 16 m + (lane & 15) of the wave's 128 rows,
+      // columns 16 n + 4 (lane >> 4) .. + 3 of its 64 columns
+      const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+      const int rloc = (wv >> 2) * 128 + (ln & 15), cloc = (wv & 3) * 64 + (ln >> 4) * 4;
+      float cs[4][4];
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int cc = cloc + n * 16 + e;
+          cs[n][e] = (p.scale_b && cc < nrem) ? p.scale_b[pid_n * BN + cc] : 1.f;
+        }
+      epilogue_256_from<DT_BF16>(
+          [&](int m, f32x4(&v)[4]) {
+            const int rr = rloc + m * 16;
+            const float rs = (p.scale_a && rr < rows) ? p.scale_a[g0 + rr] : 1.f;
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[n][e] = Frag<DT>::val(acc.v[m][n][e]) * rs * cs[n][e];
+          },
+          smem, store_tile);
+    } else {
+      epilogue_256<DT>(acc, smem, store_tile);
+    }
     if (p.dbg && threadIdx.x == 0) p.dbg[blockIdx.x * 4 + 1] = 3;
     drain_stores();
     race_debug_delay(p.race_debug, (unsigned)i + 7u);
@@ -297,8 +327,17 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_rs_kernel(GemmRsParams p) {
 TDIST_API int tdist_gemm_rs(const tdist::SymmCtx* ctx, const void* A, const void* B, void* scatter, int* flags,
                             int* counters, int* err, void* out, long long lda, long long ldb, long long ldo,
                             int M_per_rank, int N, int K, int rows_per_chunk, int epoch, int num_ctas, int dtype,
-                            void* stream, int* dbg, int* state, void* scatter1, int* flags1) {
-  TDIST_REQUIRE(K >= 128 && K % 64 == 0, "K must be a multiple of 64 and >= 128");
+                            void* stream, int* dbg, int* state, void* scatter1, int* flags1, const float* scale_a,
+                            const float* scale_b) {
+  // dtype: 0 = bf16, 1 = fp16, 2 = fp8 e4m3, 3 = fp8 e5m2, 4 = int8 (8-bit operands: bf16 partials and output, scaled by
+  // scale_a [M] x scale_b [N] when given); K, lda, ldb in ELEMENTS of the operand type
+  TDIST_REQUIRE(dtype >= 0 && dtype <= 4, "dtype must be 0..4");
+  const int per16 = dtype >= 2 ? 2 : 1;
+  TDIST_REQUIRE(K % per16 == 0 && lda % per16 == 0 && ldb % per16 == 0, "odd 8-bit strides");
+  K /= per16;
+  lda /= per16;
+  ldb /= per16;
+  TDIST_REQUIRE(K >= 128 && K % 64 == 0, "K must be a multiple of 64 (16-bit) / 128 (8-bit) and at least two such steps");
   TDIST_REQUIRE(N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldo % 8 == 0, "N/lda/ldb/ldo must be multiples of 8");
   TDIST_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)out | (uintptr_t)scatter) & 15) == 0,
                 "operands must be 16-byte aligned");
@@ -324,6 +363,8 @@ TDIST_API int tdist_gemm_rs(const tdist::SymmCtx* ctx, const void* A, const void
   p.rows_per_chunk = rows_per_chunk;
   p.epoch = epoch;
   p.dbg = dbg;
+  p.scale_a = scale_a;
+  p.scale_b = scale_b;
   p.race_debug = race_debug_enabled();
   p.trace = wg_trace_sink();
   {
@@ -341,12 +382,13 @@ TDIST_API int tdist_gemm_rs(const tdist::SymmCtx* ctx, const void* A, const void
   p.flags1 = flags1;
   const int cpr = M_per_rank / rows_per_chunk;
   const size_t counter_bytes = (((size_t)(w * cpr + 12) * sizeof(int)) + 15) & ~(size_t)15;
+  typedef void (*rs_kern_t)(GemmRsParams);
+  static const rs_kern_t kerns[5] = {gemm_rs_kernel<DT_BF16>, gemm_rs_kernel<DT_F16>, gemm_rs_kernel<DT_FP8>,
+                                     gemm_rs_kernel<DT_BF8>, gemm_rs_kernel<DT_I8>};
   static bool attr_set = false;
   if (!attr_set) {
-    TDIST_HIP_TRY(hipFuncSetAttribute((const void*)gemm_rs_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      LDS_BYTES + 16));
-    TDIST_HIP_TRY(hipFuncSetAttribute((const void*)gemm_rs_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      LDS_BYTES + 16));
+    for (int i = 0; i < 5; ++i)
+      TDIST_HIP_TRY(hipFuncSetAttribute((const void*)kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 16));
     attr_set = true;
   }
   // The whole grid must be resident at once (reduce items spin on flags raised by this rank's and the
@@ -374,10 +416,7 @@ TDIST_API int tdist_gemm_rs(const tdist::SymmCtx* ctx, const void* A, const void
             "err=%p out=%p state=%p Mr=%d N=%d K=%d rpc=%d grid=%d\n",
             ctx->rank, w, A, B, scatter, scatter1, (void*)flags, (void*)flags1, (void*)counters, counter_bytes,
             (void*)err, out, (void*)state, M_per_rank, N, K, rows_per_chunk, grid);
-  if (dtype == 0)
-    hipLaunchKernelGGL(gemm_rs_kernel<true>, dim3(grid), dim3(THREADS), LDS_BYTES + 16, (hipStream_t)stream, p);
-  else
-    hipLaunchKernelGGL(gemm_rs_kernel<false>, dim3(grid), dim3(THREADS), LDS_BYTES + 16, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(kerns[dtype], dim3(grid), dim3(THREADS), LDS_BYTES + 16, (hipStream_t)stream, p);
   TDIST_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -24,7 +24,7 @@ from .. import _lib
 from ..autotuner import tuning
 from ..utils.distributed import default_num_ctas, forbid_graph_capture, get_env
 from . import tp_ll
-from .gemm import _DT, gemm_nt
+from .gemm import _DT_EX, gemm_nt
 
 EPOCH_MOD = 4093
 DEBUG_RACES = os.environ.get("TDIST_DEBUG_RACES", "0") == "1"      # csrc/include/tdist/race_debug.hpp
@@ -73,8 +73,8 @@ def create_gemm_rs_intra_node_context(max_M, N, output_dtype, rank, num_ranks, t
     """Collective.  ``max_M`` is the full (pre-scatter) row count, ``N`` the output width."""
     if not fuse_scatter:
         raise NotImplementedError("only the fused-scatter epilogue exists")
-    if transpose_weight:
-        raise NotImplementedError("weights are [N, K_local] (K contiguous)")
+    # transpose_weight: the caller's weights are [K_local, N]; gemm_rs_intra_node makes (and keeps) the K-contiguous
+    # form the tile engine streams (ops/ag_gemm.py: k_contiguous_weight)
     env = env or get_env()
     assert max_M % num_ranks == 0
     num_ctas = default_num_ctas(env, num_ranks, num_ctas)
@@ -110,20 +110,25 @@ def _rows_per_chunk(M_per_rank: int, want: int) -> int:
     return M_per_rank
 
 
-def gemm_rs_intra_node_op(a, b, ctx: GEMMReduceScatterTensorParallelContext, out=None):
+def gemm_rs_intra_node_op(a, b, ctx: GEMMReduceScatterTensorParallelContext, out=None, scale_a=None, scale_b=None):
     env = ctx.env
     w, rank = ctx.num_ranks, ctx.rank
     M, K_local = a.shape
     N = b.shape[0]
     assert b.shape[1] == K_local and N == ctx.N and M <= ctx.max_M and M % w == 0
-    assert a.dtype == b.dtype == ctx.output_dtype, "partials travel in the output dtype"
+    eight = a.element_size() == 1
+    assert a.dtype == b.dtype and (ctx.output_dtype == (torch.bfloat16 if eight else a.dtype)), \
+        "partials travel in the output dtype (bf16 for 8-bit operands)"
     M_per_rank = M // w
     if out is None:
         out = torch.empty((M_per_rank, N), dtype=ctx.output_dtype, device=a.device)
     if w == 1 and os.environ.get("TDIST_FORCE_FUSED", "0") != "1":
+        if eight or scale_a is not None or scale_b is not None:
+            from .gemm import gemm_nt_tiles
+            return gemm_nt_tiles(a, b, out=out, scale_a=scale_a, scale_b=scale_b)
         gemm_nt(a, b, out=out)
         return out
-    if tp_ll.ll_applies(ctx.ll, M, N, K_local, a, b) and not DEBUG_RACES and out.stride(1) == 1 \
+    if not eight and tp_ll.ll_applies(ctx.ll, M, N, K_local, a, b) and not DEBUG_RACES and out.stride(1) == 1 \
             and out.stride(0) % 8 == 0 and out.data_ptr() % 16 == 0:
         # decode-sized call: mid-M tile body, device-side call numbering, capturable (ops/tp_ll.py)
         return tp_ll.gemm_rs_ll(ctx.ll, env, rank, w, a, b, out, ctx.num_ctas)
@@ -140,7 +145,7 @@ def gemm_rs_intra_node_op(a, b, ctx: GEMMReduceScatterTensorParallelContext, out
     ctx.call_count += 1
     rpc = _rows_per_chunk(M_per_rank, tuning.get("gemm_rs.M_PER_CHUNK", ctx.M_PER_CHUNK))
     if ctx.backend == "host":
-        return _gemm_rs_host(a, b, out, ctx, parity, epoch)
+        return _gemm_rs_host(a, b, out, ctx, parity, epoch, scale_a, scale_b)
     a = a.contiguous()
     lib = _lib.hip()
     cstruct = env.heap.ctx_struct()
@@ -149,8 +154,10 @@ def gemm_rs_intra_node_op(a, b, ctx: GEMMReduceScatterTensorParallelContext, out
                           _lib.ptr(ctx.flags[0][rank]), _lib.ptr(ctx.scratch), _lib.ptr(ctx.scratch[-4:]),
                           _lib.ptr(out), ctypes.c_longlong(a.stride(0)), ctypes.c_longlong(b.stride(0)),
                           ctypes.c_longlong(out.stride(0)), M_per_rank, N, K_local, rpc, epoch, ctx.num_ctas,
-                          _DT[a.dtype], _lib.stream_handle(), _lib.ptr(getattr(ctx, "debug_trace", None)),
-                          _lib.ptr(ctx.state), _lib.ptr(ctx.scatter[1][rank]), _lib.ptr(ctx.flags[1][rank])),
+                          _DT_EX[a.dtype], _lib.stream_handle(), _lib.ptr(getattr(ctx, "debug_trace", None)),
+                          _lib.ptr(ctx.state), _lib.ptr(ctx.scatter[1][rank]), _lib.ptr(ctx.flags[1][rank]),
+                          _lib.ptr(scale_a) if scale_a is not None else ctypes.c_void_p(0),
+                          _lib.ptr(scale_b) if scale_b is not None else ctypes.c_void_p(0)),
         "tdist_gemm_rs")
     if DEBUG_RACES and not torch.cuda.is_current_stream_capturing():
         # all w partials of this call were reduced: poison them (see ops/ag_gemm.py)
@@ -158,13 +165,18 @@ def gemm_rs_intra_node_op(a, b, ctx: GEMMReduceScatterTensorParallelContext, out
     return out
 
 
-def _gemm_rs_host(a, b, out, ctx, parity, epoch):
+def _gemm_rs_host(a, b, out, ctx, parity, epoch, scale_a=None, scale_b=None):
     lib = _lib.host()
     w, rank = ctx.num_ranks, ctx.rank
     M = a.shape[0]
     N = b.shape[0]
     M_per_rank = M // w
-    partial = (a.float() @ b.float().t()).to(out.dtype)
+    partial = a.float() @ b.float().t()
+    if scale_a is not None:
+        partial = partial * scale_a[:, None]
+    if scale_b is not None:
+        partial = partial * scale_b[None, :]
+    partial = partial.to(out.dtype)
     for i in range(1, w + 1):
         d = (rank + i) % w
         seg = ctx.scatter[parity][d].view(-1)[: w * M_per_rank * N].view(w, M_per_rank, N)
@@ -178,6 +190,14 @@ def _gemm_rs_host(a, b, out, ctx, parity, epoch):
     return out
 
 
-def gemm_rs_intra_node(a, b, ctx: GEMMReduceScatterTensorParallelContext):
-    """a: [M, K_local], b: [N, K_local].  Returns [M // world_size, N]."""
-    return gemm_rs_intra_node_op(a, b, ctx)
+def gemm_rs_intra_node(a, b, ctx: GEMMReduceScatterTensorParallelContext, scale_a=None, scale_b=None):
+    """a: [M, K_local], b: [N, K_local] ([K_local, N] for a context created with ``transpose_weight=True``).
+    Returns [M // world_size, N].
+
+    Operand types: bf16 / fp16 (partials and output of that type) and fp8 e4m3 / e5m2 / int8 (bf16 partials and
+    output).  ``scale_a`` [M] / ``scale_b`` [N] (fp32) de-quantise every rank's partial sums before they are
+    scattered, so the reduction adds comparable numbers."""
+    if ctx.transpose_weight:
+        from .ag_gemm import k_contiguous_weight
+        b = k_contiguous_weight(b)
+    return gemm_rs_intra_node_op(a, b, ctx, scale_a=scale_a, scale_b=scale_b)
