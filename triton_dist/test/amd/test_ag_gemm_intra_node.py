@@ -18,7 +18,15 @@ import torch.distributed as dist
 from triton_dist.kernels.amd import ag_gemm_intra_node, create_ag_gemm_intra_node_context
 from triton_distributed_gh_amd.utils.cli import Runner, add_common_args, rel_err
 
-DTYPES = {"bfloat16": torch.bfloat16, "float16": torch.float16}
+# the reference's DTYPE_MAP (test_ag_gemm_intra_node.py:122-129); 8-bit operands give a bf16 result here
+DTYPES = {"bfloat16": torch.bfloat16, "float16": torch.float16, "float8_e4m3fn": torch.float8_e4m3fn,
+          "float8_e5m2": torch.float8_e5m2, "s8": torch.int8}
+
+
+def rand_operand(rows, cols, dt, dev):
+    if dt == torch.int8:
+        return torch.randint(-127, 128, (rows, cols), device=dev, dtype=torch.int8)
+    return (torch.rand(rows, cols, device=dev) * 2 - 1).to(dt)
 
 
 def main():
@@ -40,15 +48,17 @@ def main():
         M, N // w, K, dt, dt, r, w, env.tp_group, M_PER_CHUNK=args.chunk_m, producer=args.producer, env=env))
 
     def make():
-        return ({r: (torch.rand(M // w, K, device=dev) * 2 - 1).to(dt) for r in R.local_ranks},
-                {r: (torch.rand(N // w, K, device=dev) * 2 - 1).to(dt) for r in R.local_ranks})
+        return ({r: rand_operand(M // w, K, dt, dev) for r in R.local_ranks},
+                {r: rand_operand(N // w, K, dt, dev) for r in R.local_ranks})
 
     if args.check:
         for it in range(args.verify_iters):
             A, B = make()
             R.barrier()
             out = R.run(lambda r, env: ag_gemm_intra_node(A[r], B[r], False, ctxs[r]))
-            full = torch.cat(R.all_gather(A)).float()
+            # (8-bit tensors travel through the CPU all-gather as bytes)
+            gathered = R.all_gather({r: A[r].view(torch.uint8) if dt.itemsize == 1 else A[r] for r in A})
+            full = torch.cat([g.view(dt) if dt.itemsize == 1 else g for g in gathered]).float()
             for r in R.local_ranks:
                 ctxs[r].check_error()
                 err = rel_err(out[r], full @ B[r].float().t())
@@ -61,12 +71,16 @@ def main():
         if not R.virtual:
             env = R.envs[0]
             full = torch.empty(M, K, device=dev, dtype=dt)
+            # the library has no fp8 / int8 GEMM of this layout to compare with: its baseline multiplies in bf16
+            mm_dt = torch.bfloat16 if dt.itemsize == 1 else dt
+            Bm = {r: B[r].to(mm_dt) for r in B}
 
             def torch_ag_gemm(r, e):
                 if w > 1:
-                    dist.all_gather_into_tensor(full, A[r], group=env.tp_group)
-                    return torch.matmul(full, B[r].t())
-                return torch.matmul(A[r], B[r].t())
+                    dist.all_gather_into_tensor(full.view(torch.uint8) if dt.itemsize == 1 else full,
+                                                A[r].view(torch.uint8) if dt.itemsize == 1 else A[r], group=env.tp_group)
+                    return torch.matmul(full.to(mm_dt), Bm[r].t())
+                return torch.matmul(A[r].to(mm_dt), Bm[r].t())
 
             t_torch = R.time(torch_ag_gemm, args.warmup, args.iters)
             R.print_all(f"torch #ranks {w}: {t_torch:.4f} ms  (speed-up {t_torch / t_dist:.3f}x)")
