@@ -20,6 +20,15 @@ heap cannot be set up, a check fails or a device-side wait times out, the script
 with "value": null (the torch + RCCL times stay in it as extra fields) and exits with status 1: it
 never reports a torch + RCCL time as the result.
 
+Besides the K timed steps (the headline `value`), every op is timed against its torch (+ RCCL) counterpart in
+interleaved rounds (fused, torch, fused, torch, ... at least five rounds each, barrier + synchronize around every
+burst, max over ranks) and the MEDIANS are reported with the per-op and pair speed-ups derived from them - the
+order of measurement then cannot favour either side on a power-managed part.  At TP > 1 both AG-GEMM producers
+(push work items inside the consumer launch / SDMA copy engines) are timed in those rounds and the headline step
+runs the one with the lower median (`producer`, `producer_rule`).  `--shapes baseline` adds the reference's
+published MI308X shapes and the six m8192 chart shapes of each op as extra fields.  The JSON also carries the
+device topology as seen by the driver and the perf model's link- / MFMA-bound estimate of each op.
+
 Launch:  python bench.py --gpus 1            (single process)
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
                 --master-port P bench.py --gpus N --steps K --warmup W
@@ -66,6 +75,42 @@ def _time_steps(env, fn, steps, warmup):
     return dt * 1e6  # us per step
 
 
+def _burst_us(env, fn, iters):
+    """us per call of `iters` back-to-back calls, max over ranks (barrier + synchronize on both sides)."""
+    _sync_all(env)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    _sync_all(env)
+    dt = (time.perf_counter() - t0) / iters
+    if env.world_size > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=env.cpu_group)
+        dt = float(t[0])
+    return dt * 1e6
+
+
+def _interleaved(env, fns: dict, rounds: int, iters: int) -> dict:
+    """Median us per call of every entry of `fns`, measured A B C A B C ... for `rounds` rounds."""
+    names = list(fns)
+    for n in names:                       # one untimed pass: allocations, attribute calls, clocks
+        for _ in range(2):
+            fns[n]()
+    samples = {n: [] for n in names}
+    for _ in range(rounds):
+        for n in names:
+            samples[n].append(_burst_us(env, fns[n], iters))
+    return {n: sorted(v)[len(v) // 2] for n, v in samples.items()}
+
+
+# The reference's published AMD numbers (8 x MI308X, docs/getting-started/e2e/e2e_dense.md:44-45) and the six
+# m8192 chart shapes of docs/amd-perf.md:4,7 - global (M, N, K); AG-GEMM shards N, GEMM-RS shards K.
+BASELINE_AG = [(4096, 6400 * 8, 5120), (8192, 11008, 4096), (8192, 14336, 4096), (8192, 28672, 8192),
+               (8192, 53248, 16384), (8192, 29568, 8192)]
+BASELINE_RS = [(4096, 5120, 3200 * 8), (8192, 4096, 12288), (8192, 4096, 14336), (8192, 3584, 14336),
+               (8192, 4608, 36864), (8192, 8192, 28672), (8192, 8192, 30720)]
+
+
 def _plain_env():
     """torch.distributed only (no symmetric heap): enough to time torch.matmul + RCCL for the report
     of a run whose fused path could not even start."""
@@ -108,6 +153,77 @@ def _mismatch(got: torch.Tensor, gold: torch.Tensor, mag: torch.Tensor) -> str:
             f"{(g - gold).abs().max().item():.4e})")
 
 
+def _baseline_shapes(env, ctas, producer, baseline_on, args):
+    """Fused vs torch (+ RCCL) medians at the reference's published shapes; contexts are created per shape and
+    their symmetric buffers returned to the heap afterwards."""
+    from triton_distributed_gh_amd.ops.ag_gemm import ag_gemm_intra_node, create_ag_gemm_intra_node_context
+    from triton_distributed_gh_amd.ops.gemm_rs import create_gemm_rs_intra_node_context, gemm_rs_intra_node
+
+    w, r, dev, dt = env.world_size, env.rank, env.device, torch.bfloat16
+    rows = []
+    rounds, iters = 5, 5
+
+    def rand(shape, scale=1.0):
+        return ((torch.rand(*shape, device=dev) * 2 - 1) * scale).to(dt)
+
+    def release(ctx, lists):
+        for name in lists:
+            for parity in getattr(ctx, name):
+                env.heap.free_tensor(parity[r])
+
+    for (m, n, k) in BASELINE_AG:
+        if m % w or n % w:
+            continue
+        a, b = rand((m // w, k)), rand((n // w, k), 0.05)
+        full = torch.empty(m, k, device=dev, dtype=dt)
+        ctx = create_ag_gemm_intra_node_context(m, n // w, k, dt, dt, r, w, env.tp_group, num_ctas=ctas, producer=producer)
+
+        def t_ref():
+            if w > 1:
+                dist.all_gather_into_tensor(full, a, group=env.tp_group)
+                return torch.matmul(full, b.t())
+            return torch.matmul(a, b.t())
+
+        fns = {"fused": lambda: ag_gemm_intra_node(a, b, False, ctx)}
+        if baseline_on:
+            fns["torch"] = t_ref
+        med = _interleaved(env, fns, rounds, iters)
+        ctx.check_error()
+        rows.append({"op": "ag_gemm", "M": m, "N": n, "K": k, "fused_us": round(med["fused"], 1),
+                     "torch_us": round(med["torch"], 1) if "torch" in med else None,
+                     "speedup": round(med["torch"] / med["fused"], 3) if "torch" in med else None})
+        torch.cuda.synchronize()
+        release(ctx, ("workspaces", "flags"))
+        del ctx, a, b, full
+    for (m, n, k) in BASELINE_RS:
+        if m % w or k % w or (k // w) % 64:
+            continue
+        a, b = rand((m, k // w)), rand((n, k // w), 0.05)
+        full = torch.empty(m, n, device=dev, dtype=dt)
+        out = torch.empty(m // w, n, device=dev, dtype=dt)
+        ctx = create_gemm_rs_intra_node_context(m, n, dt, r, w, env.tp_group, num_ctas=ctas)
+
+        def t_ref():
+            torch.matmul(a, b.t(), out=full)
+            if w > 1:
+                dist.reduce_scatter_tensor(out, full, group=env.tp_group)
+                return out
+            return full
+
+        fns = {"fused": lambda: gemm_rs_intra_node(a, b, ctx)}
+        if baseline_on:
+            fns["torch"] = t_ref
+        med = _interleaved(env, fns, rounds, iters)
+        ctx.check_error()
+        rows.append({"op": "gemm_rs", "M": m, "N": n, "K": k, "fused_us": round(med["fused"], 1),
+                     "torch_us": round(med["torch"], 1) if "torch" in med else None,
+                     "speedup": round(med["torch"] / med["fused"], 3) if "torch" in med else None})
+        torch.cuda.synchronize()
+        release(ctx, ("scatter", "flags"))
+        del ctx, a, b, full, out
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,7 +234,11 @@ def main():
                     help="AG-GEMM producer: in-kernel push work items (default) or the SDMA copy engines")
     ap.add_argument("--check-iters", type=int, default=-1,
                     help="fresh-input checks before timing (default: 50 at TP > 1 on real devices, 3 otherwise)")
+    ap.add_argument("--rounds", type=int, default=7, help="interleaved fused / torch rounds per op (>= 5)")
+    ap.add_argument("--shapes", choices=("headline", "baseline"), default="headline",
+                    help="baseline: also time the reference's published shapes (extra JSON fields)")
     args = ap.parse_args()
+    args.rounds = max(5, args.rounds)
 
     from triton_distributed_gh_amd.ops.ag_gemm import ag_gemm_intra_node, create_ag_gemm_intra_node_context
     from triton_distributed_gh_amd.ops.gemm_rs import create_gemm_rs_intra_node_context, gemm_rs_intra_node
@@ -127,6 +247,7 @@ def main():
     # The symmetric heap (hipIpc mappings of every peer, proven coherent by the start-up self-test) is
     # what the fused path stands on.  If it cannot be set up there is no result to report.
     problems = []
+    notes = []                        # remarks that do not invalidate the result
     try:
         if os.environ.get("TDIST_BENCH_FORCE_PLAIN") == "1":      # exercises the failure path below
             raise RuntimeError("forced by TDIST_BENCH_FORCE_PLAIN")
@@ -147,9 +268,18 @@ def main():
     a2, w2 = fresh((M, K // w)), fresh((N, K // w), 0.05)
 
     ag_ctx = rs_ctx = None
+    ag_ctxs = {}                      # producer -> context (TP > 1: both producers where the copy engines may be used)
     if env.heap is not None:
-        ag_ctx = create_ag_gemm_intra_node_context(M, N // w, K, dt, dt, r, w, env.tp_group, M_PER_CHUNK=256,
-                                                   num_ctas=ctas, producer=args.producer)
+        want = [args.producer] if args.producer else (["kernel", "copy_engine"] if w > 1 else ["kernel"])
+        for prod in want:
+            try:
+                ag_ctxs[prod] = create_ag_gemm_intra_node_context(M, N // w, K, dt, dt, r, w, env.tp_group, M_PER_CHUNK=256,
+                                                                  num_ctas=ctas, producer=prod)
+            except RuntimeError as exc:      # (copy engines: refused when several processes share one GPU)
+                if prod == want[0]:
+                    raise
+                notes.append(f"producer {prod} not timed ({exc})")
+        ag_ctx = ag_ctxs[want[0]]
         rs_ctx = create_gemm_rs_intra_node_context(M, N, dt, r, w, env.tp_group, M_PER_CHUNK=256, num_ctas=ctas)
 
     # ---- torch + RCCL implementation of the same pair (yardstick; not available on a shared GPU) ----
@@ -172,6 +302,9 @@ def main():
 
     def fused_ag():
         return ag_gemm_intra_node(a1, w1, False, ag_ctx)
+
+    def fused_ag_with(prod):
+        return lambda: ag_gemm_intra_node(a1, w1, False, ag_ctxs[prod])
 
     def fused_rs():
         return gemm_rs_intra_node(a2, w2, rs_ctx)
@@ -214,17 +347,23 @@ def main():
         return t.view(w, -1, N)[r].to(dev), m.view(w, -1, N)[r].to(dev), sample
 
     def check_once(tag: str) -> str:
-        c1, c2 = fused_ag(), fused_rs()
+        c1s = {prod: fused_ag_with(prod)() for prod in ag_ctxs}      # every producer that will be timed
+        c2 = fused_rs()
         torch.cuda.synchronize()
-        ag_ctx.check_error()
+        for c in ag_ctxs.values():
+            c.check_error()
         rs_ctx.check_error()
         g1, i1 = gold_ag()
         g2, mag2, i2 = gold_rs()
-        m1 = _mismatch(c1 if i1 is None else c1[i1], g1, g1.abs())
+        bad = []
+        for prod, c1 in c1s.items():
+            m1 = _mismatch(c1 if i1 is None else c1[i1], g1, g1.abs())
+            if m1:
+                bad.append(f"AG-GEMM ({prod} producer) " + m1)
         m2 = _mismatch(c2 if i2 is None else c2[i2], g2, mag2)
-        if m1 or m2:
-            return f"{tag}: " + "; ".join(x for x in (("AG-GEMM " + m1) if m1 else "", ("GEMM-RS " + m2) if m2 else "") if x)
-        return ""
+        if m2:
+            bad.append("GEMM-RS " + m2)
+        return f"{tag}: " + "; ".join(bad) if bad else ""
 
     # ---- checks on fresh inputs: the timed path must produce the gold's numbers ------------------------
     n_checks = args.check_iters if args.check_iters >= 0 else (1 if w == 1 else (50 if env.has_rccl else 3))
@@ -253,19 +392,33 @@ def main():
         torch_ag_gemm()
         torch_gemm_rs()
 
-    total_us = ag_us = rs_us = None
+    total_us = None
+    med = {}
+    producer, producer_rule = (args.producer or "kernel"), "only one producer available"
+    baseline_on = (not args.no_baseline) and (env.has_rccl or w == 1)
     if fused_ok:
         # Clock settle (setup, untimed): the first back-to-back full-chip GEMMs after an idle period run
         # through a power-management transient (kernel times swing 360 -> 500 -> 360 us over ~30 ms in
-        # rocprofv3 traces); drive the chip to its steady state before the W warm-up steps.
+        # rocprofv3 traces); drive the chip to its steady state before anything is timed.
         settle_t0 = time.perf_counter()
         while time.perf_counter() - settle_t0 < 0.25:
             for _ in range(10):
                 step()
             torch.cuda.synchronize()
+        # ---- per-op medians, fused and torch interleaved -------------------------------------------------
+        fns = {f"ag_gemm[{prod}]": fused_ag_with(prod) for prod in ag_ctxs}
+        fns["gemm_rs"] = fused_rs
+        if baseline_on:
+            fns["torch_ag_gemm"] = torch_ag_gemm
+            fns["torch_gemm_rs"] = torch_gemm_rs
+        med = _interleaved(env, fns, args.rounds, max(5, args.steps // 5))
+        if len(ag_ctxs) > 1:
+            # every rank computed the same medians (max over ranks), so every rank picks the same producer
+            producer = min(ag_ctxs, key=lambda prod: (med[f"ag_gemm[{prod}]"], prod != "kernel"))
+            producer_rule = "lower median AG-GEMM time of this run (kernel on a tie)"
+            ag_ctx = ag_ctxs[producer]
+        # ---- the headline: W untimed steps, then exactly K timed steps of the pair ----------------------------
         total_us = _time_steps(env, step, args.steps, args.warmup)
-        ag_us = _time_steps(env, fused_ag, max(5, args.steps // 2), 3)
-        rs_us = _time_steps(env, fused_rs, max(5, args.steps // 2), 3)
         # The timed calls reuse the parity buffers many times over: check the LAST state too, so a number
         # is only reported for a path that was still producing the gold's values at the end.
         try:
@@ -275,26 +428,51 @@ def main():
         if not _all_agree(env, msg == ""):
             problems.append(msg or "a peer rank failed its check after the timed loop")
             fused_ok = False
+    elif baseline_on:
+        for _ in range(50):
+            base_step()
+        torch.cuda.synchronize()
+        med = _interleaved(env, {"torch_ag_gemm": torch_ag_gemm, "torch_gemm_rs": torch_gemm_rs}, args.rounds,
+                           max(5, args.steps // 5))
+    base_us = _time_steps(env, base_step, max(5, args.steps // 2), 3) if baseline_on else None
+    ag_us = med.get(f"ag_gemm[{producer}]") if fused_ok else None
+    rs_us = med.get("gemm_rs") if fused_ok else None
+    base_ag_us, base_rs_us = med.get("torch_ag_gemm"), med.get("torch_gemm_rs")
 
-    base_us = base_ag_us = base_rs_us = None
-    if not args.no_baseline and (env.has_rccl or w == 1):
-        if not fused_ok:
-            for _ in range(50):
-                base_step()
-            torch.cuda.synchronize()
-        base_us = _time_steps(env, base_step, max(5, args.steps // 2), 3)
-        base_ag_us = _time_steps(env, torch_ag_gemm, max(5, args.steps // 2), 3)
-        base_rs_us = _time_steps(env, torch_gemm_rs, max(5, args.steps // 2), 3)
+    # ---- the reference's published shapes (extra fields) ------------------------------------------------------
+    extra_shapes = []
+    if fused_ok and args.shapes == "baseline":
+        extra_shapes = _baseline_shapes(env, ctas, producer if w > 1 else "kernel", baseline_on, args)
 
     if r == 0:
+        from triton_distributed_gh_amd.utils import perf_model, topo
+
         flops = 2.0 * (2.0 * M * N * K) / w  # per GPU per step
         rnd = lambda x: None if x is None else round(x, 2)  # noqa: E731
+        ratio = lambda a, b: round(a / b, 4) if (a and b) else None  # noqa: E731
         if not fused_ok:
             timed_path = "none (fused path rejected; exit status 1)"
         elif w == 1:
             timed_path = "native gfx950 GEMM kernels (TP=1: no collective, AG-GEMM and GEMM-RS are plain GEMMs)"
         else:
             timed_path = "fused HIP kernels (AG-GEMM and GEMM-RS, one persistent launch each)"
+        try:
+            ndev = torch.cuda.device_count()
+            links = [[("self" if i == j else ("p2p" if topo.can_access_peer(i, j) else "none")) for j in range(ndev)]
+                     for i in range(min(ndev, 8))]
+            topology = {"devices": ndev, "fullmesh_xgmi": bool(topo.has_fullmesh_xgmi(max(w, 1))) if ndev > 1 else None,
+                        "peer_access": links, "xgmi_gbps_per_link_per_dir": topo.XGMI_LINK_GBPS_PER_DIR,
+                        "egress_gbps_at_this_tp": topo.get_intranode_max_speed_gbps(w) if w > 1 else 0.0}
+        except Exception as exc:  # noqa: BLE001 - informational only
+            topology = {"error": f"{type(exc).__name__}: {exc}"}
+        us = lambda d: {k.replace("_ms", "_us"): round(v * 1e3, 1) for k, v in d.items()}  # noqa: E731
+        model = {
+            # parts and total of each op as the perf model sees them (utils/perf_model.py): MFMA-bound GEMM time,
+            # link-bound collective time over the xGMI links this TP degree can use, and what cannot overlap
+            "ag_gemm": us(perf_model.estimate_ag_gemm_time_ms(M, N // w, K, w)),
+            "gemm_rs": us(perf_model.estimate_gemm_rs_time_ms(M, N, K // w, w)),
+            "gemm_sol_us_per_op": rnd(perf_model.estimate_gemm_sol_time_ms(M, N // w, K) * 1e3),
+        }
         out = {
             "metric": "intranode AG-GEMM + GEMM-RS latency (us), M=4096 N=K=8192 bf16",
             "value": rnd(total_us) if fused_ok else None,
@@ -310,20 +488,33 @@ def main():
             "data": "synthetic (uniform random activations, random-init weights)",
             "config": {"model": "TP MLP-style pair (AG-GEMM then GEMM-RS)", "M": M, "N": N, "K": K,
                        "global_batch": M, "seq_len": 1, "parallelism": f"tp{w}"},
-            "ag_gemm_us": rnd(ag_us) if fused_ok else None,
-            "gemm_rs_us": rnd(rs_us) if fused_ok else None,
+            # medians of `rounds` interleaved bursts (fused, torch, fused, torch, ...), max over ranks per burst
+            "ag_gemm_us": rnd(ag_us),
+            "gemm_rs_us": rnd(rs_us),
+            "ag_gemm_us_kernel": rnd(med.get("ag_gemm[kernel]")) if fused_ok else None,
+            "ag_gemm_us_sdma": rnd(med.get("ag_gemm[copy_engine]")) if fused_ok else None,
             "torch_ag_gemm_us": rnd(base_ag_us),
             "torch_gemm_rs_us": rnd(base_rs_us),
+            "speedup_ag_gemm": ratio(base_ag_us, ag_us),
+            "speedup_gemm_rs": ratio(base_rs_us, rs_us),
+            # pair speed-up from the per-op medians; the torch pair timed back to back is reported next to it
+            "speedup_vs_torch_rccl": ratio((base_ag_us or 0) + (base_rs_us or 0), (ag_us or 0) + (rs_us or 0))
+            if (ag_us and rs_us and base_ag_us and base_rs_us) else None,
             "torch_rccl_pair_us": rnd(base_us),
-            "speedup_vs_torch_rccl": round(base_us / total_us, 4) if (fused_ok and base_us) else None,
+            "interleaved_rounds": args.rounds,
             "tflops_per_gpu": round(flops / total_us / 1e6, 1) if fused_ok else None,
             "timed_path": timed_path,
-            "producer": (ag_ctx.producer if (ag_ctx is not None and w > 1) else "none"),
+            "producer": (producer if (ag_ctx is not None and w > 1) else "none"),
+            "producer_rule": producer_rule if w > 1 else "TP=1: nothing to gather",
+            "perf_model": model,
+            "topology": topology,
+            "baseline_shapes": extra_shapes,
             "heap_mode": env.heap_mode,
+            "safe_publish": bool(getattr(env, "safe_publish", False)),
             "heap_selftest": [f"{m}: {d}" for m, d in getattr(env, "selftest_log", ())],
             "ranks_share_one_gpu": bool(env.shared_gpu),
             "checks_passed_before_timing": checks_run,
-            "note": "; ".join(problems),
+            "note": "; ".join(problems + notes),
         }
         print(json.dumps(out), flush=True)
     if env.heap is not None:
