@@ -172,8 +172,28 @@ def fp8():
         print(f"{n:36s} {t:7.1f} us  {2.0 * M * N * K / t / 1e6:7.0f} T(FL)OP/s", flush=True)
 
 
+def tail():
+    """More tiles than CUs, not a whole number of rounds: plan (whole rounds + split last round) vs 256x256 unsplit vs library."""
+    dt = torch.bfloat16
+    for M, N, K in [(4096, 5120, 25600), (8192, 4608, 36864), (8192, 3584, 14336), (8192, 11008, 4096), (4096, 6400, 5120),
+                    (8192, 4096, 14336), (2560, 8192, 8192)]:
+        a, b = make(M, N, K, dt)
+        o = torch.empty(M, N, device="cuda", dtype=dt)
+        ref = None
+        fns = [lambda: G.gemm_nt_tiles(a, b, o), lambda: G.gemm_nt_tiles(a, b, o, bm=256, bn=256, split_k=1),
+               lambda: torch.matmul(a, b.t(), out=o)]
+        G.gemm_nt_tiles(a, b, o)
+        ref = a[:256].double() @ b.double().t()
+        ok = bool(((o[:256].double() - ref).abs() <= 2.0 ** -7 * ref.abs() + 1e-3 * K ** 0.5).all())
+        ts = bench_interleaved(fns, rounds=5, iters=5)
+        print(f"{M:5d} {N:5d} {K:5d} tiles(256) {-(-M // 256) * -(-N // 256):4d} | plan {ts[0]:7.1f} | 256x256/1 {ts[1]:7.1f} | "
+              f"hipBLASLt {ts[2]:7.1f} | first rows {'ok' if ok else 'BAD'}", flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["check", "time", "few", "fp8"]
+    if "tail" in what:
+        tail()
     rc = 0
     if "check" in what:
         rc = check()

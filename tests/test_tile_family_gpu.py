@@ -69,6 +69,17 @@ def test_split_k_join(dt, bm, bn, split):
             _close(G.gemm_nt_tiles(a, b, bm=bm, bn=bn, split_k=split), ref, K, f"{dt} {bm}x{bn} split {split}")
 
 
+def test_last_round_split_matches_fp64():
+    """More tiles than CUs and a partial last round: whole rounds unsplit + split tail, every element."""
+    M, N, K = 2560, 8192, 2048            # 320 tiles of 256x256
+    a, b = _make(M, N, K, torch.bfloat16)
+    ref = a.double() @ b.double().t()
+    for _ in range(2):
+        out = G.gemm_nt_tiles(a, b, bm=256, bn=256, split_k=4)
+        _close(out, ref, K, "last-round split")
+    _close(G.gemm_nt(a, b), ref, K, "gemm_nt through the plan")
+
+
 @pytest.mark.parametrize("dt", [torch.float8_e4m3fn, torch.int8, torch.float16], ids=lambda d: str(d).split(".")[-1])
 @pytest.mark.parametrize("bm,bn", SHAPES)
 def test_output_scales(dt, bm, bn):
@@ -107,12 +118,14 @@ def test_cost_model_picks_a_plan_and_few_tiles_gemm_is_native(monkeypatch):
 
     lib = _lib.hip()
     picks = {}
-    for M, N, K in [(2048, 1024, 8192), (2048, 4096, 4096), (4096, 8192, 8192)]:
-        bm, bn, sk, pb, nc = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong(), ctypes.c_int()
+    for M, N, K in [(2048, 1024, 8192), (2048, 4096, 4096), (4096, 8192, 8192), (4096, 5120, 25600)]:
+        bm, bn, sk, pb, nc, nf = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong(), ctypes.c_int(), ctypes.c_int()
         _lib.check(lib.tdist_gemm_nt_ex_plan(M, N, K, 0, 0, 0, 0, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(sk),
-                                             ctypes.byref(pb), ctypes.byref(nc)), "plan")
-        picks[(M, N, K)] = (bm.value, bn.value, sk.value)
-    assert picks[(4096, 8192, 8192)] == (256, 256, 1)
+                                             ctypes.byref(pb), ctypes.byref(nc), ctypes.byref(nf)), "plan")
+        picks[(M, N, K)] = (bm.value, bn.value, sk.value, nf.value)
+    assert picks[(4096, 8192, 8192)][:3] == (256, 256, 1)
+    # 320 tiles on 256 CUs: one whole round unsplit, the 64 tiles of the partial round cut along K
+    assert picks[(4096, 5120, 25600)][2] > 1 and picks[(4096, 5120, 25600)][3] == 256
     assert picks[(2048, 1024, 8192)][2] > 1                      # 32 big tiles for 256 CUs: K is split
     assert picks[(2048, 4096, 4096)][:2] != (256, 256)           # 128 big tiles: a 128-wide tile fills the chip
     called = []

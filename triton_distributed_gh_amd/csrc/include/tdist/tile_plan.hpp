@@ -16,6 +16,7 @@ struct TilePlan {
   int mt, nt, split_k;
   long long partial_bytes;
   int n_counters;
+  int n_full;        // tiles [0, n_full) run unsplit (whole rounds); only the tiles of the last, partial round are split
 };
 inline double tile_step_ns(int mt, int nt, bool chip_full) {
   if (mt == 8 && nt == 4) return chip_full ? 1430.0 : 1620.0;
@@ -30,7 +31,7 @@ inline TilePlan plan_tiles(int M, int N, int K16, int slots_1, int bm, int bn, i
   static const int forced = getenv("TDIST_GEMM_TILE") ? atoi(getenv("TDIST_GEMM_TILE")) : 0;   // e.g. 842 = MT 8, NT 4, split 2
   const int cand[4][2] = {{8, 4}, {8, 2}, {4, 4}, {4, 2}};
   double best = 1e30;
-  TilePlan pick{8, 4, 1, 0, 0};
+  TilePlan pick{8, 4, 1, 0, 0, 0};
   const int ksteps = K16 / 64;
   for (int ci = 0; ci < 4; ++ci) {
     const int mt = cand[ci][0], nt = cand[ci][1];
@@ -44,24 +45,35 @@ inline TilePlan plan_tiles(int M, int N, int K16, int slots_1, int bm, int bn, i
     for (int s = 1; s <= 4; ++s) {
       if (split_k && s != split_k) continue;
       if (forced && forced % 10 && s != forced % 10) continue;
-      if (s > 1 && (ksteps / s < 8 || tiles * s > slots)) continue;     // split only inside one round, >= 512 deep
-      const long long items = tiles * s;
-      const long long rounds = (items + slots - 1) / slots;
-      const bool full = items > cus;
+      // A split applies to the LAST round only: n_full tiles fill whole rounds unsplit, the remaining `rem` tiles
+      // (a partial round that would leave slots idle) are cut into s K ranges each, rem * s <= slots.
+      const long long full_rounds = tiles / slots, rem = tiles % slots;
+      const long long n_full = s > 1 ? full_rounds * slots : 0;
+      if (s > 1 && (rem == 0 || ksteps / s < 8 || rem * s > slots)) {
+        if (!(split_k && s == split_k && tiles * s <= slots && ksteps >= 2 * s)) continue;   // (forced small split)
+      }
+      const bool full = tiles * s > cus / 2;
       const double tile_kb = tbm * tbn * 4 / 1024.0;
-      const double fix = s > 1 ? 2500.0 + 20.0 * tile_kb + (s - 1) * 30.0 * tile_kb : 0.0;
-      const double total = rounds * ((ksteps / s) * tile_step_ns(mt, nt, full) + 7000.0) + fix;
+      const double step = tile_step_ns(mt, nt, full);
+      double total;
+      if (s == 1) {
+        const long long rounds = (tiles + slots - 1) / slots;
+        total = rounds * (ksteps * step + 7000.0);
+      } else {
+        const double fix = 2500.0 + 20.0 * tile_kb + (s - 1) * 30.0 * tile_kb;
+        total = full_rounds * (ksteps * step + 7000.0) + ((ksteps / s) * step + 7000.0) + fix;
+      }
       if (total < best) {
         best = total;
-        pick = TilePlan{mt, nt, s, 0, 0};
+        pick = TilePlan{mt, nt, s, 0, 0, (int)n_full};
       }
     }
   }
   if (pick.split_k > 1) {
     const int tbm = 32 * pick.mt, tbn = 64 * pick.nt;
     const long long tiles = (long long)((M + tbm - 1) / tbm) * ((N + tbn - 1) / tbn);
-    pick.partial_bytes = tiles * pick.split_k * tbm * tbn * 4;
-    pick.n_counters = (int)tiles;
+    pick.partial_bytes = (tiles - pick.n_full) * pick.split_k * tbm * tbn * 4;
+    pick.n_counters = (int)(tiles - pick.n_full);
   }
   return pick;
 }

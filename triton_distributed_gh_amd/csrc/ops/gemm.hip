@@ -201,7 +201,7 @@ template <int DT, int MT, int NT, bool OUT32, bool SCALED = false>
 __global__ __launch_bounds__(THREADS, (2 * TileShape<MT, NT>::WGS_PER_CU)) void gemm_nt_tile_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv, int M, int N, int K,
     long long lda, long long ldb, long long ldc, int group_m, const float* __restrict__ sa,
-    const float* __restrict__ sb, int split_k, float* __restrict__ partial, int* __restrict__ counters) {
+    const float* __restrict__ sb, int split_k, float* __restrict__ partial, int* __restrict__ counters, int n_full) {
   using S = TileShape<MT, NT>;
   using F = Frag<DT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -209,14 +209,19 @@ __global__ __launch_bounds__(THREADS, (2 * TileShape<MT, NT>::WGS_PER_CU)) void 
   const int num_pid_n = (N + S::BN - 1) / S::BN;
   const int nwg = num_pid_m * num_pid_n;
   const int ksteps = K / BK;
-  for (int item = blockIdx.x; item < nwg * split_k; item += gridDim.x) {
-    const int ks = item / nwg, vb = item - ks * nwg;
+  // tiles [0, n_full) are one item each; the rest (the last, partial round) split_k items each, K range slowest
+  const int n_tail = nwg - n_full;
+  for (int item = blockIdx.x; item < n_full + n_tail * split_k; item += gridDim.x) {
+    const bool whole = item < n_full;
+    const int ks = whole ? 0 : (item - n_full) / n_tail;
+    const int vb = whole ? item : n_full + (item - n_full) - ks * n_tail;
+    const int S_item = whole ? 1 : split_k;
     const int id = xcd_remap(vb, nwg);
     int pid_m, pid_n;
     tile_coords(id, num_pid_m, num_pid_n, group_m, pid_m, pid_n);
     const int row0 = pid_m * S::BM, col0 = pid_n * S::BN;
-    const int k0 = (int)((long long)ksteps * ks / split_k) * BK;
-    const int k1 = (int)((long long)ksteps * (ks + 1) / split_k) * BK;
+    const int k0 = (int)((long long)ksteps * ks / S_item) * BK;
+    const int k1 = (int)((long long)ksteps * (ks + 1) / S_item) * BK;
     TileArgs t;
     t.A = A + (long long)row0 * lda + k0;
     t.B = B + (long long)col0 * ldb + k0;
@@ -227,10 +232,11 @@ __global__ __launch_bounds__(THREADS, (2 * TileShape<MT, NT>::WGS_PER_CU)) void 
     t.K = k1 - k0;
     AccT<MT, NT> acc;
     mainloop_2ph<DT, MT, NT>(t, smem, acc);
-    if (split_k > 1) {
+    if (S_item > 1) {
       constexpr int SLOT = MT * NT * THREADS;                 // f32x4 per partial tile
       volatile int* s_arrived = (volatile int*)(smem + S::LDS);
-      f32x4* tbase = (f32x4*)partial + (long long)id * split_k * SLOT + threadIdx.x;
+      const int tix = vb - n_full;                            // index among the split tiles
+      f32x4* tbase = (f32x4*)partial + (long long)tix * split_k * SLOT + threadIdx.x;
       {
         f32x4* mine = tbase + (long long)ks * SLOT;
 #pragma unroll
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(THREADS, (2 * TileShape<MT, NT>::WGS_PER_CU)) void 
       }
       tdist::drain_stores();
       __syncthreads();
-      if (threadIdx.x == 0) *s_arrived = tdist::atom_add_relaxed_agent(counters + id, 1);
+      if (threadIdx.x == 0) *s_arrived = tdist::atom_add_relaxed_agent(counters + tix, 1);
       __syncthreads();
       const int arrived = __builtin_amdgcn_readfirstlane(*s_arrived);
       __syncthreads();                                        // (the word is rewritten by the next item)
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(THREADS, (2 * TileShape<MT, NT>::WGS_PER_CU)) void 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __syncthreads();
-      if (threadIdx.x == 0) tdist::store_relaxed_agent(counters + id, 0);     // re-armed for the next launch
+      if (threadIdx.x == 0) tdist::store_relaxed_agent(counters + tix, 0);    // re-armed for the next launch
       for (int q = 0; q < split_k; ++q) {
         if (q == ks) continue;
         const f32x4* src = tbase + (long long)q * SLOT;
@@ -811,7 +817,8 @@ static int tile_family_cus() {
 // the workspace it needs (partial_bytes of fp32 partial tiles, n_counters zero-initialised ints) when it splits.
 // bm / bn / split_k: 0 = free, otherwise forced.
 TDIST_API int tdist_gemm_nt_ex_plan(int M, int N, int K, int dtype, int bm, int bn, int split_k, int* out_bm,
-                                    int* out_bn, int* out_split_k, long long* partial_bytes, int* n_counters) {
+                                    int* out_bn, int* out_split_k, long long* partial_bytes, int* n_counters,
+                                    int* out_n_full) {
   TDIST_REQUIRE(dtype >= 0 && dtype <= 4 && M > 0 && N > 0 && K > 0, "bad problem");
   const int per16 = dtype >= 2 ? 2 : 1;
   const TilePlan pl = plan_tiles(M, N, K / per16, tile_family_cus(), bm, bn, split_k, true);
@@ -820,6 +827,7 @@ TDIST_API int tdist_gemm_nt_ex_plan(int M, int N, int K, int dtype, int bm, int 
   *out_split_k = pl.split_k;
   *partial_bytes = pl.partial_bytes;
   *n_counters = pl.n_counters;
+  *out_n_full = pl.n_full;
   return 0;
 }
 
@@ -852,7 +860,7 @@ TDIST_API int tdist_gemm_nt_ex(const void* A, const void* B, void* C, int M, int
   }
   if (group_m <= 0) group_m = 8;
   typedef void (*kern_t)(const uint16_t*, const uint16_t*, void*, int, int, int, long long, long long, long long, int,
-                         const float*, const float*, int, float*, int*);
+                         const float*, const float*, int, float*, int*, int);
   // [dtype][shape: 84, 82, 44, 42]
   static const kern_t table[5][4] = {
       {gemm_nt_tile_kernel<DT_BF16, 8, 4, false>, gemm_nt_tile_kernel<DT_BF16, 8, 2, false>,
@@ -894,7 +902,8 @@ TDIST_API int tdist_gemm_nt_ex(const void* A, const void* B, void* C, int M, int
   }
   const int si = pk.mt == 8 ? (pk.nt == 4 ? 0 : 1) : (pk.nt == 4 ? 2 : 3);
   const int bmv = 32 * pk.mt, bnv = 64 * pk.nt;
-  const long long items = (long long)((M + bmv - 1) / bmv) * ((N + bnv - 1) / bnv) * pk.split_k;
+  const long long tiles_all = (long long)((M + bmv - 1) / bmv) * ((N + bnv - 1) / bnv);
+  const long long items = pk.n_full + (tiles_all - pk.n_full) * pk.split_k;
   const int per_cu = si == 3 ? 2 : 1;
   long long grid = (long long)(num_cus & ~7) * per_cu;
   if (grid < 8) grid = 8;
@@ -902,7 +911,7 @@ TDIST_API int tdist_gemm_nt_ex(const void* A, const void* B, void* C, int M, int
   const kern_t k = out_kind == 1 ? table32[si] : ((scale_a || scale_b) ? table_sc[dtype][si] : table[dtype][si]);
   hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(THREADS), lds_of[si] + 16, (hipStream_t)stream, (const uint16_t*)A,
                      (const uint16_t*)B, C, M, N, K16, lda / per16, ldb / per16, ldc, group_m, scale_a, scale_b,
-                     pk.split_k, (float*)partial, counters);
+                     pk.split_k, (float*)partial, counters, pk.split_k > 1 ? pk.n_full : (int)tiles_all);
   TDIST_HIP_TRY(hipGetLastError());
   return 0;
 }

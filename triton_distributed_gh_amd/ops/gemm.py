@@ -110,6 +110,12 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
             torch.matmul(a, b.t(), out=out)
             return out
         return gemm_nt_tiles(a, b, out, group_m=group_m)      # 256x128 / 128x256 / 128x128 tiles by cost model
+    # More tiles than CUs but not a whole number of rounds (320 tiles = 1.25 rounds): the tile family's plan keeps the
+    # whole rounds on 256x256 tiles and cuts only the last round's tiles along K so it fills the chip too
+    # (csrc/include/tdist/tile_plan.hpp), or picks another macro-tile when that is cheaper.
+    if (M > 16 and variant == GEMM_VARIANT and not force_native and FEW_TILES_GEMM == "tiles"
+            and tiles > _num_cus(a.device) and tiles % _num_cus(a.device)):
+        return gemm_nt_tiles(a, b, out, group_m=group_m)
     lib = _lib.hip()
     _lib.check(
         lib.tdist_gemm_nt(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), M, N, K, ctypes.c_longlong(a.stride(0)),
@@ -177,10 +183,10 @@ def gemm_nt_tiles(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] 
         group_m = tuning.get("gemm.group_m", 8)
     lib = _lib.hip()
     pbm, pbn, ps = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-    pbytes, ncnt = ctypes.c_longlong(), ctypes.c_int()
+    pbytes, ncnt, nfull = ctypes.c_longlong(), ctypes.c_int(), ctypes.c_int()
     _lib.check(lib.tdist_gemm_nt_ex_plan(M, N, K, _DT_EX[a.dtype], bm, bn, split_k or tuning.get("gemm.TILE_SPLIT_K", 0),
                                          ctypes.byref(pbm), ctypes.byref(pbn), ctypes.byref(ps), ctypes.byref(pbytes),
-                                         ctypes.byref(ncnt)), "tdist_gemm_nt_ex_plan")
+                                         ctypes.byref(ncnt), ctypes.byref(nfull)), "tdist_gemm_nt_ex_plan")
     ws = _tile_workspace(a.device, pbytes.value, ncnt.value) if ps.value > 1 else None
     _lib.check(
         lib.tdist_gemm_nt_ex(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), M, N, K, ctypes.c_longlong(a.stride(0)),
