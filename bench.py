@@ -514,7 +514,8 @@ def main():
             "heap_selftest": [f"{m}: {d}" for m, d in getattr(env, "selftest_log", ())],
             "ranks_share_one_gpu": bool(env.shared_gpu),
             "checks_passed_before_timing": checks_run,
-            "note": "; ".join(problems + notes),
+            "note": "; ".join(problems),
+            "remarks": "; ".join(notes),
         }
         print(json.dumps(out), flush=True)
     if env.heap is not None:

@@ -1482,6 +1482,49 @@ __device__ __forceinline__ void epilogue_direct(const AccT<MT, NT>& acc, const f
   }
 }
 
+// LDS-staged stores of the tile family's accumulators: the tile is laid out row-major in LDS (BM rows of BN 16-bit
+// values + 16 bytes of padding) and handed to `store16(row, col, uint4)` in pieces such that BN / 8 neighbouring
+// threads cover one whole row - every row leaves as ONE contiguous run of 2 BN bytes.  For write-through (sc1 /
+// sc0 sc1) stores, which are not merged in L2, that is 1.3 - 1.5x faster than the 64-byte pieces of epilogue_direct.
+// Needs staged_lds_bytes<MT, NT>() of LDS (the 256 x 256 image is 4 KiB larger than the main loop's ring); begins and
+// ends with a workgroup barrier.
+template <int MT, int NT>
+constexpr int staged_lds_bytes() {
+  return 32 * MT * (2 * 64 * NT + 16) > TileShape<MT, NT>::LDS ? 32 * MT * (2 * 64 * NT + 16) : TileShape<MT, NT>::LDS;
+}
+template <int DT, int MT, int NT, class StoreFn>
+__device__ __forceinline__ void epilogue_staged(const AccT<MT, NT>& acc, char* smem, StoreFn&& store16) {
+  using F = Frag<DT>;
+  constexpr int BM_ = 32 * MT, BN_ = 64 * NT, STRIDE = 2 * BN_ + 16;
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, l = tid & 63;
+  char* base = smem + ((w >> 2) * (16 * MT) + (l & 15)) * STRIDE + ((w & 3) * (16 * NT) + (l >> 4) * 8) * 2;
+  __syncthreads();                       // (every wave is past its last fragment read)
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int p = 0; p < NT / 2; ++p) {
+      const f32x4& x0 = acc.v[m][2 * p];
+      const f32x4& x1 = acc.v[m][2 * p + 1];
+      uint4 v;
+      v.x = F::pack2(x0[0], x0[1]);
+      v.y = F::pack2(x0[2], x0[3]);
+      v.z = F::pack2(x1[0], x1[1]);
+      v.w = F::pack2(x1[2], x1[3]);
+      *(uint4*)(base + m * 16 * STRIDE + p * 64) = v;
+    }
+  __syncthreads();
+  constexpr int TPR = BN_ / 8;           // threads per row
+  constexpr int RPP = THREADS / TPR;     // rows per pass
+  const int r0 = tid / TPR, cc = tid % TPR;
+#pragma unroll 4
+  for (int pass = 0; pass < BM_ / RPP; ++pass) {
+    const int row = pass * RPP + r0;
+    store16(row, cc * 8, *(const uint4*)(smem + row * STRIDE + cc * 16));
+  }
+  __syncthreads();
+}
+
 template <int MT, int NT, class StoreFn>
 __device__ __forceinline__ void epilogue_direct_raw32(const AccT<MT, NT>& acc, StoreFn&& store32) {
   const int tid = threadIdx.x;

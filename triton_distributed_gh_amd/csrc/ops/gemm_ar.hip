@@ -1,28 +1,41 @@
 // GEMM + AllReduce in one persistent kernel:  out[M, N] = sum over ranks of A_r[M, K_local] * B_r[N, K_local]^T.
 //
 // Two-shot over 256x256 output tiles: tile t is OWNED by rank t % w.
-//   GEMM(t)   : every rank computes its partial tile and stores it as one contiguous 128 KiB block
-//               into the owner's slot [src_rank][t / w] (remote store over xGMI, or local), then
-//               raises flag1[t / w][src_rank] = epoch on the owner.
-//   REDUCE(t) : the owner waits for the w partial blocks, sums them in fp32 (rank order, so the
-//               result is bitwise identical everywhere), writes the tile into EVERY rank's
-//               symmetric output [M, N] and raises flag2[t] = epoch on every rank.
-//   DRAIN     : before leaving, each workgroup waits until every tile's flag2 has arrived, so
-//               kernel completion means the full output is present locally.
-// Work order: all GEMM tiles (owners visited round-robin, so each step loads all links evenly),
-// then this rank's REDUCE items.  Epoch flags + call-parity double buffering: no reset, no barrier.
+//   GEMM(t)      : every rank computes its partial tile and stores it as one contiguous 128 KiB block into the
+//                  owner's slot [src_rank][t / w] (remote store over xGMI, or local), then raises
+//                  flag1[t / w][src_rank] = epoch on the owner.
+//   REDUCE(t, s) : the owner waits for the w partial blocks, sums 32-row slab s of them in fp32 (rank order, so
+//                  the result is bitwise identical everywhere), writes the slab into EVERY rank's symmetric
+//                  output [M, N] and raises flag2[t][s] = epoch on every rank.  Eight slabs per tile: a round of
+//                  reductions is as many short items as the grid has workgroups, not w-times fewer long ones.
+//   DRAIN        : before leaving, each workgroup waits until every flag2 has arrived, so kernel completion means
+//                  the full output is present locally - and that every owner has finished reading its slots and
+//                  writing this call's output everywhere.  The output buffer therefore needs no parity: a peer's
+//                  NEXT call can only write into it after that peer has received this rank's next partials, which
+//                  this rank's stream issues behind its consumers of the current output.  The result's address is
+//                  the same every call (what a captured graph's consumers need); a private copy is optional.
+// Tile: 256 x 256, or 256 x 128 when the 256 x 256 tiles would leave half of the workgroups without a GEMM item.
+// Work order (the GEMM + RS order): tiles are cut into groups of about one grid round; every one of the eight
+// per-XCD queues (tdist/work_queue.hpp) runs  GEMM(g0) GEMM(g1) REDUCE(g0) GEMM(g2) REDUCE(g1) ... REDUCE(last),
+// so the reduction and broadcast of a group ride behind the GEMM of the next one instead of all reductions
+// waiting at the end, and a queue owns a contiguous run of a group's tiles (shared A row blocks in that XCD's L2).
+// Every rank runs the same order, and an item waits only for items earlier in it: no deadlock at any grid size
+// that is resident at once.
+// Calls are numbered on the device (tdist/call_state.hpp): slots / outputs / flags alternate by call parity, flags
+// carry the call's epoch, the last workgroup out re-arms the queue tickets - the launch is ONE kernel node, the
+// same every time, and can be captured into a HIP graph and replayed.
 //
 // Role in the reference: kernels/nvidia/gemm_allreduce.py - `kernel_fused_gemm_allreduce` :232-315
-// with NUM_COMM_SMS communication CTAs doing `multimem.ld_reduce` (:123-207) and the LL
-// double-buffered context (:73-91).  xGMI has no in-fabric reduction, hence owner-reduces-then-
-// broadcasts; the low-latency entry point is the same kernel because every context is already
-// double-buffered.
+// with NUM_COMM_SMS communication CTAs doing `multimem.ld_reduce` (:123-207) as tiles' flags flip, and the LL
+// double-buffered context (:73-91).  xGMI has no in-fabric reduction, hence owner-reduces-then-broadcasts, and
+// instead of dedicated communication CTAs every workgroup alternates between the two kinds of item.
 #include "tdist/cache_policy.hpp"
 #include "tdist/call_state.hpp"
 #include "tdist/common.hpp"
 #include "tdist/gemm_gfx950.hpp"
 #include "tdist/gemm_mid_gfx950.hpp"
 #include "tdist/primitives.hpp"
+#include "tdist/work_queue.hpp"
 
 using namespace tdist;
 using namespace tdist::gemm;
@@ -31,59 +44,82 @@ struct GemmArParams {
   SymmCtx ctx;
   const uint16_t* A;     // [M, K_local]
   const uint16_t* B;     // [N, K_local]
-  uint16_t* slots;       // symmetric, this parity: [w][tiles_per_owner][256*256]
-  uint16_t* out;         // symmetric, this parity: [M, N]
-  int* flags;            // symmetric (signal arena), this parity: flag1 [tiles_per_owner][w], then flag2 [tiles]
-  int* ticket;           // local, zeroed before launch
+  uint16_t *slots0, *slots1;   // symmetric, by call parity: [w][tiles_per_owner][256*256]
+  uint16_t* out;               // symmetric [M, N]: ONE buffer for both parities (see the DRAIN note above)
+  int *flags0, *flags1;        // symmetric (signal arena), by call parity: flag1 [tiles_per_owner][w], then flag2 [tiles][8]
+  int* counters;         // local: [0, 8) queue tickets, [8] finished-workgroup counter; zero at launch, left zero
   int* err;
+  int* state;            // [0] call number (tdist/call_state.hpp)
+  uint16_t* c_local;     // optional plain [M, N] copy of the result
   long long lda, ldb;
   int M, N, K;
+  int group_tiles;       // tiles per group (multiple of 8)
+};
+
+constexpr int AR_SLABS = 8;            // reduce items per tile
+constexpr int AR_SLAB_ROWS = BM / AR_SLABS;
+
+struct ArCall {
+  uint16_t *slots, *out;
+  int* flags;
   int epoch;
 };
 
-constexpr int AR_TICKET_SLOT = LDS_BYTES;
-constexpr int TILE_ELEMS = BM * BN;
-
-template <bool IS_BF16>
-__device__ __forceinline__ void reduce_tile(const GemmArParams& p, int t, int tiles_per_owner, int total_tiles) {
+// Slab `slab` of owned tile t: sum the w partials, broadcast, flag.  `acquired`: the tile whose partials this
+// workgroup has already waited for (they do not change within the call).
+template <bool IS_BF16, int NT>
+__device__ __forceinline__ void reduce_slab(const GemmArParams& p, const ArCall& cv, int t, int slab, int tiles_per_owner,
+                                            int& acquired) {
+  constexpr int BN = 64 * NT, TILE_ELEMS = BM * BN;
+  constexpr int TPR = BN / 8, RPP = THREADS / TPR;          // threads per row, rows per pass
   const int w = p.ctx.num_ranks, rank = p.ctx.rank;
   const int num_pid_n = (p.N + BN - 1) / BN;
   const int local = t / w;
-  {
+  if (acquired != t) {
     const bool dead = load_relaxed_agent(p.err) != 0;
     int failed = 0;
     if ((int)threadIdx.x < w) {
-      if (dead || !spin_until_eq(p.flags + local * w + threadIdx.x, p.epoch, SCOPE_SYS)) failed = 1;
+      if (dead || !spin_until_eq(cv.flags + local * w + threadIdx.x, cv.epoch, SCOPE_SYS)) failed = 1;
     }
     if (failed && !dead) atomicOr(p.err, 1);
     if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (__syncthreads_or(failed) == 0) acquired = t;
   }
   const int pid_m = t / num_pid_n, pid_n = t - pid_m * num_pid_n;
   const int rows = min(BM, p.M - pid_m * BM), cols = min(BN, p.N - pid_n * BN);
   const long long slot_stride = (long long)tiles_per_owner * TILE_ELEMS;
-  const uint16_t* base = p.slots + (long long)local * TILE_ELEMS;
-  // 32 threads per row (8 elements each), 16 rows per pass
-  const int r0 = threadIdx.x >> 5, c8 = (threadIdx.x & 31) * 8;
-  for (int r = r0; r < rows; r += 16) {
-    if (c8 >= cols) continue;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < w; ++s) {
-      const uint4 v = *(const uint4*)(base + s * slot_stride + r * BN + c8);
-      const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+  const uint16_t* base = cv.slots + (long long)local * TILE_ELEMS;
+  // BN / 8 threads per row (8 elements each)
+  const int c8 = (threadIdx.x % TPR) * 8;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (IS_BF16) {
-          acc[2 * e] += __builtin_bit_cast(float, x[e] << 16);
-          acc[2 * e + 1] += __builtin_bit_cast(float, x[e] & 0xffff0000u);
-        } else {
-          typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
-          const f16x2 h = __builtin_bit_cast(f16x2, x[e]);
-          acc[2 * e] += (float)h[0];
-          acc[2 * e + 1] += (float)h[1];
+  for (int pass = 0; pass < (AR_SLAB_ROWS + RPP - 1) / RPP; ++pass) {
+    const int r = slab * AR_SLAB_ROWS + pass * RPP + (threadIdx.x / TPR);
+    if (pass * RPP + (int)(threadIdx.x / TPR) >= AR_SLAB_ROWS) continue;
+    if (r >= rows || c8 >= cols) continue;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < w; s0 += 4) {
+      uint4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (s0 + u < w) v[u] = *(const uint4*)(base + (s0 + u) * slot_stride + r * BN + c8);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (s0 + u < w) {
+          const uint32_t x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (IS_BF16) {
+              acc[2 * e] += __builtin_bit_cast(float, x[e] << 16);
+              acc[2 * e + 1] += __builtin_bit_cast(float, x[e] & 0xffff0000u);
+            } else {
+              typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+              const f16x2 h = __builtin_bit_cast(f16x2, x[e]);
+              acc[2 * e] += (float)h[0];
+              acc[2 * e + 1] += (float)h[1];
+            }
+          }
         }
-      }
     }
     uint4 o;
     o.x = Frag<IS_BF16>::pack2(acc[0], acc[1]);
@@ -93,7 +129,7 @@ __device__ __forceinline__ void reduce_tile(const GemmArParams& p, int t, int ti
     const long long off = (long long)(pid_m * BM + r) * p.N + pid_n * BN + c8;
     for (int i = 0; i < w; ++i) {
       const int peer = (rank + i) % w;
-      uint16_t* dst = (i == 0) ? p.out : symm_at(p.ctx, p.out, peer);
+      uint16_t* dst = (i == 0) ? cv.out : symm_at(p.ctx, cv.out, peer);
       st_wt128_sys(dst + off, o);
     }
   }
@@ -101,31 +137,77 @@ __device__ __forceinline__ void reduce_tile(const GemmArParams& p, int t, int ti
   drain_stores();
   __syncthreads();
   if ((int)threadIdx.x < w) {
-    int* f2 = ((int)threadIdx.x == rank ? p.flags : symm_at(p.ctx, p.flags, (int)threadIdx.x)) + tiles_per_owner * w + t;
-    store_relaxed_system(f2, p.epoch);
+    int* f2 = ((int)threadIdx.x == rank ? cv.flags : symm_at(p.ctx, cv.flags, (int)threadIdx.x)) + tiles_per_owner * w +
+              t * AR_SLABS + slab;
+    store_relaxed_system(f2, cv.epoch);
   }
 }
 
-template <bool IS_BF16>
+template <bool IS_BF16, int NT>
 __global__ __launch_bounds__(THREADS, 2) void gemm_ar_kernel(GemmArParams p) {
+  using TS = TileShape<8, NT>;
+  constexpr int BN = TS::BN, TILE_ELEMS = BM * BN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  volatile int* s_ticket = (volatile int*)(smem + AR_TICKET_SLOT);
+  volatile int* s_ticket = (volatile int*)(smem + staged_lds_bytes<8, NT>());
   const int w = p.ctx.num_ranks, rank = p.ctx.rank;
   const int num_pid_m = (p.M + BM - 1) / BM, num_pid_n = (p.N + BN - 1) / BN;
   const int tiles = num_pid_m * num_pid_n;
   const int tiles_per_owner = (tiles + w - 1) / w;
-  const int owned = (tiles - rank + w - 1) / w;   // tiles t with t % w == rank
-  const int total = tiles + owned;
+  const int G = p.group_tiles, g8 = G / 8;
+  const int groups = (tiles + G - 1) / G;
+  // tiles t < x owned by this rank
+  auto owned_below = [=](int x) { return x > rank ? (x - rank + w - 1) / w : 0; };
+  auto group_end = [=](int c) { return min((c + 1) * G, tiles); };
+  // queue q of group c: GEMM items = tiles [c G + q g8, c G + (q + 1) g8) clipped to the group; REDUCE items =
+  // every eighth (owned tile, slab) pair of the group
+  auto gq = [=](int c, int q) { return min(max(group_end(c) - c * G - q * g8, 0), g8); };
+  auto rq = [=](int c, int q) {
+    const int n = (owned_below(group_end(c)) - owned_below(c * G)) * AR_SLABS;
+    return n > q ? (n - q + 7) >> 3 : 0;
+  };
+  auto queue_size = [=](int q) {
+    int n = 0;
+    for (int c = 0; c < groups; ++c) n += gq(c, q) + rq(c, q);
+    return n;
+  };
+  WorkQueues<decltype(queue_size)> wq(p.counters, s_ticket, 0, queue_size);
+  const int call = call_begin(p.state, s_ticket + 2);
+  ArCall cv;
+  cv.slots = call_parity(call) ? p.slots1 : p.slots0;
+  cv.out = p.out;
+  cv.flags = call_parity(call) ? p.flags1 : p.flags0;
+  cv.epoch = call_epoch(call);
 
-  while (true) {
-    const int item = fetch_ticket_block(p.ticket, s_ticket);
-    if (item >= total) break;
-    if (item >= tiles) {
-      reduce_tile<IS_BF16>(p, (item - tiles) * w + rank, tiles_per_owner, tiles);
+  int item = 0, acquired = -1;
+  bool have = wq.first(item);
+  if (!have) have = wq.next(item);
+  while (have) {
+    const int q = wq.q;
+    // decode: stage s runs GEMM(group s) then REDUCE(group s - 1)
+    int rem = item, grp = 0, idx = 0;
+    bool is_gemm = true;
+    for (int s = 0; s <= groups; ++s) {
+      if (s < groups) {
+        const int g = gq(s, q);
+        if (rem < g) { is_gemm = true; grp = s; idx = rem; break; }
+        rem -= g;
+      }
+      if (s >= 1) {
+        const int r = rq(s - 1, q);
+        if (rem < r) { is_gemm = false; grp = s - 1; idx = rem; break; }
+        rem -= r;
+      }
+    }
+    if (!is_gemm) {
+      wq.prefetch();
+      const int j = idx * 8 + q;                         // (owned tile, slab) pair of the group
+      const int t0 = grp * G;
+      const int first = t0 + ((rank - t0 % w) + w) % w;  // first tile of the group this rank owns
+      reduce_slab<IS_BF16, NT>(p, cv, first + (j / AR_SLABS) * w, j % AR_SLABS, tiles_per_owner, acquired);
+      have = wq.next(item);
       continue;
     }
-    // rotate so that at any moment different ranks are writing to different owners
-    const int t = (item + rank) % tiles;
+    const int t = grp * G + q * g8 + idx;
     const int owner = t % w, local = t / w;
     const int pid_m = t / num_pid_n, pid_n = t - pid_m * num_pid_n;
     const int rows = min(BM, p.M - pid_m * BM);
@@ -137,72 +219,123 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_ar_kernel(GemmArParams p) {
     ta.a_rows = rows;
     ta.b_rows = p.N - pid_n * BN;
     ta.K = p.K;
-    Acc<IS_BF16> acc;
-    mainloop_256_2ph<IS_BF16>(ta, smem, acc);
-    uint16_t* slot_base = (owner == rank) ? p.slots : symm_at(p.ctx, p.slots, owner);
+    AccT<8, NT> acc;
+    mainloop_2ph<IS_BF16 ? DT_BF16 : DT_F16, 8, NT>(ta, smem, acc);
+    // GEMM and reduce items differ 10x in length: the next item is drawn only now, under the epilogue
+    wq.prefetch();
+    uint16_t* slot_base = (owner == rank) ? cv.slots : symm_at(p.ctx, cv.slots, owner);
     uint16_t* dst = slot_base + ((long long)rank * tiles_per_owner + local) * TILE_ELEMS;
-    epilogue_256<IS_BF16>(acc, smem, [&](int r, int c, const uint4& v) {
+    epilogue_staged<IS_BF16 ? DT_BF16 : DT_F16, 8, NT>(acc, smem, [&](int r, int c, const uint4& v) {
       if (r < rows) st_wt128_sys(dst + r * BN + c, v);
     });
     drain_stores();
     __syncthreads();
     if (threadIdx.x == 0) {
-      int* f1 = ((owner == rank) ? p.flags : symm_at(p.ctx, p.flags, owner)) + local * w + rank;
-      store_relaxed_system(f1, p.epoch);
+      int* f1 = ((owner == rank) ? cv.flags : symm_at(p.ctx, cv.flags, owner)) + local * w + rank;
+      store_relaxed_system(f1, cv.epoch);
     }
+    have = wq.next(item);
   }
-  // DRAIN: all tiles' results must have landed locally before the kernel completes
+  // DRAIN: all slabs' results must have landed locally before the kernel completes
   {
-    const int* f2 = p.flags + tiles_per_owner * w;
+    const int* f2 = cv.flags + tiles_per_owner * w;
     const bool dead = load_relaxed_agent(p.err) != 0;
     int failed = 0;
-    for (int t = threadIdx.x; t < tiles; t += blockDim.x)
-      if (dead || !spin_until_eq(f2 + t, p.epoch, SCOPE_SYS)) failed = 1;
+    for (int i = threadIdx.x; i < tiles * AR_SLABS; i += blockDim.x) {
+      const int t = i / AR_SLABS, slab = i - t * AR_SLABS;
+      const int pm = t / num_pid_n;
+      if (slab * AR_SLAB_ROWS >= min(BM, p.M - pm * BM)) continue;       // (slab below the tile's last row: nothing to wait for)
+      if (dead || !spin_until_eq(f2 + i, cv.epoch, SCOPE_SYS)) failed = 1;
+    }
     if (failed && !dead) atomicOr(p.err, 1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   }
+  if (p.c_local) {
+    const long long n16 = (long long)p.M * p.N / 8;
+    const uint4* src = (const uint4*)cv.out;
+    uint4* dst = (uint4*)p.c_local;
+    for (long long i = (long long)blockIdx.x * THREADS + threadIdx.x; i < n16; i += (long long)gridDim.x * THREADS)
+      dst[i] = src[i];
+  }
+  call_end(p.state, call, p.counters + 8, p.counters, 8);
 }
 
-TDIST_API int tdist_gemm_ar(const tdist::SymmCtx* ctx, const void* A, const void* B, void* slots, void* out, int* flags,
-                            int* ticket, int* err, long long lda, long long ldb, int M, int N, int K, int epoch,
-                            int num_ctas, int dtype, void* stream) {
+// Flag words (per parity) and slot elements (per source rank) a context needs for problems up to [max_M, N]: the
+// 256 x 128 tiling has the most tiles, the paddings of both tilings are covered.
+TDIST_API int tdist_gemm_ar_sizes(int max_M, int N, int world, int* flag_ints, long long* slot_elems_per_rank) {
+  const int pm = (max_M + BM - 1) / BM;
+  const int t128 = pm * ((N + 127) / 128), t256 = pm * ((N + 255) / 256);
+  const int tpo128 = (t128 + world - 1) / world, tpo256 = (t256 + world - 1) / world;
+  *flag_ints = tpo128 * world + t128 * AR_SLABS;
+  const long long e128 = (long long)tpo128 * BM * 128, e256 = (long long)tpo256 * BM * 256;
+  *slot_elems_per_rank = e128 > e256 ? e128 : e256;
+  return 0;
+}
+
+// `counters`: 12 ints, zero at the first launch (the kernel leaves them zero).  `state`: call number word.  Both
+// parities of slots / out / flags are this rank's symmetric addresses.  `c_local`: optional plain [M, N] tensor that
+// receives a copy of the result.
+TDIST_API int tdist_gemm_ar(const tdist::SymmCtx* ctx, const void* A, const void* B, void* slots0, void* slots1, void* out,
+                            int* flags0, int* flags1, int* counters, int* err, int* state, void* c_local,
+                            long long lda, long long ldb, int M, int N, int K, int num_ctas, int bn, int dtype,
+                            void* stream) {
   TDIST_REQUIRE(K >= 128 && K % 64 == 0, "K must be a multiple of 64 and >= 128");
   TDIST_REQUIRE(N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "N/lda/ldb must be multiples of 8");
-  TDIST_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)out | (uintptr_t)slots) & 15) == 0,
-                "operands must be 16-byte aligned");
-  TDIST_REQUIRE(M > 0 && N > 0, "empty problem");
+  TDIST_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)out | (uintptr_t)slots0 | (uintptr_t)slots1 |
+                  (uintptr_t)c_local) & 15) == 0, "operands must be 16-byte aligned");
+  TDIST_REQUIRE(bn == 0 || bn == 128 || bn == 256, "bn must be 0 (auto), 128 or 256");
+  TDIST_REQUIRE(M > 0 && N > 0 && state && counters && err, "bad arguments");
   GemmArParams p;
   p.ctx = *ctx;
   p.A = (const uint16_t*)A;
   p.B = (const uint16_t*)B;
-  p.slots = (uint16_t*)slots;
+  p.slots0 = (uint16_t*)slots0;
+  p.slots1 = (uint16_t*)slots1;
   p.out = (uint16_t*)out;
-  p.flags = flags;
-  p.ticket = ticket;
+  p.flags0 = flags0;
+  p.flags1 = flags1;
+  p.counters = counters;
   p.err = err;
+  p.state = state;
+  p.c_local = (uint16_t*)c_local;
   p.lda = lda;
   p.ldb = ldb;
   p.M = M;
   p.N = N;
   p.K = K;
-  p.epoch = epoch;
+  typedef void (*ar_kern_t)(GemmArParams);
+  static const ar_kern_t kerns[2][2] = {{gemm_ar_kernel<true, 4>, gemm_ar_kernel<true, 2>},
+                                        {gemm_ar_kernel<false, 4>, gemm_ar_kernel<false, 2>}};
+  static const int lds_of[2] = {staged_lds_bytes<8, 4>() + 16, staged_lds_bytes<8, 2>() + 16};
   static bool attr_set = false;
   if (!attr_set) {
-    TDIST_HIP_TRY(hipFuncSetAttribute((const void*)gemm_ar_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      LDS_BYTES + 16));
-    TDIST_HIP_TRY(hipFuncSetAttribute((const void*)gemm_ar_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      LDS_BYTES + 16));
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 2; ++j)
+        TDIST_HIP_TRY(hipFuncSetAttribute((const void*)kerns[i][j], hipFuncAttributeMaxDynamicSharedMemorySize, lds_of[j]));
     attr_set = true;
   }
-  TDIST_HIP_TRY(hipMemsetAsync(ticket, 0, 16, (hipStream_t)stream));
-  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-  int grid = num_ctas > 0 ? num_ctas : 256;
-  const int work = tiles + (tiles + ctx->num_ranks - 1) / ctx->num_ranks;
+  static int num_cus = 0;
+  if (!num_cus) {
+    int dev = 0;
+    TDIST_HIP_TRY(hipGetDevice(&dev));
+    TDIST_HIP_TRY(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  // the whole grid must be resident (reduce items and the drain spin)
+  int grid = num_ctas > 0 ? num_ctas : num_cus;
+  if (grid > num_cus) grid = num_cus;
+  const int pm = (M + BM - 1) / BM;
+  const int t256 = pm * ((N + 255) / 256);
+  // at most half as many 256-wide tiles as workgroups: 128-wide tiles fill the idle half of the chip (measured,
+  // one rank of 8 alone on the GPU, N 5120, K 3200: 1024 rows 126 -> 110 us; from 2048 rows on the 256-wide tile wins)
+  const int shape = bn ? (bn == 128 ? 1 : 0) : (2 * t256 <= grid ? 1 : 0);
+  const int tiles = shape ? pm * ((N + 127) / 128) : t256;
+  const int work = tiles + ((tiles + ctx->num_ranks - 1) / ctx->num_ranks) * AR_SLABS;
   if (grid > work) grid = work;
-  if (dtype == 0)
-    hipLaunchKernelGGL(gemm_ar_kernel<true>, dim3(grid), dim3(THREADS), LDS_BYTES + 16, (hipStream_t)stream, p);
-  else
-    hipLaunchKernelGGL(gemm_ar_kernel<false>, dim3(grid), dim3(THREADS), LDS_BYTES + 16, (hipStream_t)stream, p);
+  // a group = one round of the grid (multiple of 8, at least 8 tiles)
+  p.group_tiles = grid >= 8 ? (grid & ~7) : 8;
+  hipLaunchKernelGGL(kerns[dtype == 0 ? 0 : 1][shape], dim3(grid), dim3(THREADS), lds_of[shape], (hipStream_t)stream, p);
   TDIST_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -5,14 +5,11 @@ Reference: python/triton_dist/models/engine.py:36-189.  Back-ends: ``torch`` (RC
 all-reduce kernels) and ``triton_dist_gemm_ar`` (GEMM fused with the all-reduce).
 
 Graph replay is used where the whole step is replay-safe: the torch back-end, any back-end at
-world size 1, and at any world size ``triton_dist_AR``, ``triton_dist`` (dense and MoE models, any decode
-batch) and - for decode batches up to 256 rows (``ops.gemm_ar.LL_MAX_M``) - ``triton_dist_gemm_ar``: the
-all-reduce kernels, AG + GEMM, GEMM + RS (both tile forms), the MoE pair (AG + grouped GEMM, grouped GEMM +
-top-k reduce + RS, with the low-latency all-gather of the routing data) and the low-latency GEMM + all-reduce
-keep their call number on the device, so a replayed launch picks a fresh epoch and buffer parity by itself
-(csrc/include/tdist/call_state.hpp).  Larger decode batches of ``triton_dist_gemm_ar`` run the decode loop
-eagerly at world size > 1 - that op refuses capture rather than race (utils/distributed.py:
-forbid_graph_capture).
+world size 1, and at any world size ``triton_dist_AR``, ``triton_dist`` (dense and MoE models) and
+``triton_dist_gemm_ar``, at any decode batch: the all-reduce kernels, AG + GEMM, GEMM + RS (both tile forms), the
+MoE pair (AG + grouped GEMM, grouped GEMM + top-k reduce + RS, with the low-latency all-gather of the routing data)
+and both forms of GEMM + all-reduce keep their call number on the device, so a replayed launch picks a fresh epoch
+and buffer parity by itself (csrc/include/tdist/call_state.hpp).
 """
 from __future__ import annotations
 
@@ -134,11 +131,8 @@ class Engine:
         self._switch_backend(bsz)
         if self.backend == "triton_dist":
             next_token = next_token.split(bsz // m.world_size, dim=0)[m.rank].contiguous()
-        from ..ops.gemm_ar import LL_MAX_M
         use_graph = not self.no_graph and m.device.type == "cuda" and (
-            self.backend in ("torch", "triton_dist_AR") or m.world_size == 1
-            or (self.backend == "triton_dist_gemm_ar" and bsz <= LL_MAX_M)
-            or self.backend == "triton_dist")
+            self.backend in ("torch", "triton_dist_AR", "triton_dist_gemm_ar", "triton_dist") or m.world_size == 1)
         if use_graph:
             self.model_launch = self._init_cuda_graph(bsz)
         else:
