@@ -22,7 +22,7 @@ for slices in (1, 2, 4, 8, 16):
     os.environ["TDIST_A2A_SLICES"] = str(slices)
     times = []
     for it in range(25):
-        ctx.signal_buf[0].fill_(ctx.call_count)      # every peer "has arrived" for this call
+        ctx.signal_buf[0].fill_(int(ctx.state[0]) % 4093 + 1)      # every peer "has arrived" for this call (device-numbered)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -19,7 +19,7 @@ def test_wait_and_notify_lowering():
 
 def test_write_through_tile_stores_carry_cache_policy_bits():
     # the GEMM+RS epilogue publishes tiles with system-scope write-through stores and no L2 write-back
-    body = isa.kernel_isa("gemm_rs.hip", "gemm_rs_kernelILb1")
+    body = isa.kernel_isa("gemm_rs.hip", "gemm_rs_kernelILi1")
     assert "global_store_dwordx4" in body and "sc0 sc1" in body
     stores = [ln for ln in body.splitlines() if ln.startswith("global_store_dwordx4")]
     assert any(ln.endswith("sc0 sc1") for ln in stores)
@@ -27,7 +27,7 @@ def test_write_through_tile_stores_carry_cache_policy_bits():
 
 
 def test_gemm_main_loop_uses_mfma_and_direct_to_lds_loads():
-    body = isa.kernel_isa("gemm.hip", "gemm_nt_256_kernelILb1ELi2")
+    body = isa.kernel_isa("gemm.hip", "gemm_nt_256_kernelILb1ELi2E")
     assert body.count("v_mfma_f32_16x16x32_bf16") >= 64           # 2 phases x 32 MFMAs per wave and K-step
     assert "global_load_lds_dwordx4" in body
     assert "ds_read_b128" in body or "ds_read2_b64" in body

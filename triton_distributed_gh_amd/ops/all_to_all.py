@@ -6,8 +6,12 @@ API of the reference (reference: python/triton_dist/kernels/nvidia/low_latency_a
 :260-279; fp8 helpers tutorials/04-deepseek-infer-all2all.py:334-427).  A few workgroups
 per destination rank move that rank's contiguous token rows (tokens are pre-sorted by expert), the
 per-expert splits and the optional fp32 scales straight from the caller's tensors into the peer's
-receive buffer over xGMI (no staging copy), then raise a 64-bit signal with the call count; receive buffers are double-buffered by call parity
+receive buffer over xGMI (no staging copy), then raise a 64-bit signal; receive buffers are double-buffered by call parity
 so the sender never waits for the receiver to have consumed the previous message.
+
+On the GPU backend the call number lives in device memory: the kernel picks the half and the signal value itself and
+copies what arrived into buffers whose address is the same every call, so ``fast_all_to_all`` (and
+``all_to_all_post_process``, one compaction kernel, no host round trip) can be captured into a HIP graph and replayed.
 """
 from __future__ import annotations
 
@@ -46,6 +50,11 @@ class AllToAllContext:
     env: Any = None
     call_count: int = 1
     MOD_VALUE: int = 1000000
+    # GPU backend: device call state and the parity-independent buffers fast_all_to_all returns views of
+    state: Optional[torch.Tensor] = None
+    out_rows: Optional[torch.Tensor] = None
+    out_scale: Optional[torch.Tensor] = None
+    out_splits: Optional[torch.Tensor] = None
 
     def check_error(self) -> None:
         code = int(self.err[0]) if self.err is not None else 0
@@ -71,30 +80,35 @@ def create_all_to_all_context(max_m, hidden, rank, num_tot_experts, WORLD_SIZE, 
     split_recv = heap.create_tensor_list([2, w * experts_per_rank], torch.int32)
     signal = heap.create_tensor_list([2 * w], torch.int64, arena="sig")
     err = torch.zeros(4 + 16, dtype=torch.int32, device=dev)   # error word + per-destination slice counters if env.backend == "hip" else None
+    state = out_rows = out_scale = out_splits = None
     if env.backend == "hip":
+        state = torch.zeros(4, dtype=torch.int32, device=dev)
+        out_rows = torch.empty((w, max_m, hidden), dtype=dtype, device=dev)
+        out_scale = torch.empty((w, max_m, scale_elems), dtype=scale_dtype, device=dev)
+        out_splits = torch.zeros((w, experts_per_rank), dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
     if env.cpu_group is not None:
         torch.distributed.barrier(group=env.cpu_group)
     return AllToAllContext(max_m, hidden, rank, num_tot_experts, w, experts_per_rank, dtype, scale_dtype, scale_elems,
-                           send_buf, recv, scale_send, scale_recv, split_send, split_recv, signal, err, env)
+                           send_buf, recv, scale_send, scale_recv, split_send, split_recv, signal, err, env,
+                           state=state, out_rows=out_rows, out_scale=out_scale, out_splits=out_splits)
 
 
 def fast_all_to_all(ctx: AllToAllContext, send_tensor: torch.Tensor, send_split_cumsum: torch.Tensor,
                     send_scale: Optional[torch.Tensor] = None):
     """send_tensor [num_tokens, hidden] sorted by destination expert; send_split_cumsum
     [num_tot_experts + 1] int32 exclusive cumsum.  Returns (recv_splits [w, EPR], recv [w, max_m,
-    hidden], recv_scale or None) - views into this call's half of the receive buffers."""
+    hidden], recv_scale or None): the context's result buffers on the GPU backend (same tensors every call, valid
+    until the next call), views into this call's half of the receive buffers on the host backend."""
     env = ctx.env
     w, rank = ctx.world_size, ctx.rank
     n = send_tensor.shape[0]
     assert n <= ctx.max_m and send_tensor.shape[1] == ctx.hidden
     assert send_split_cumsum.numel() == ctx.num_tot_experts + 1
-    # parity and flag value of a call are host state, and the returned views name this call's half of the
-    # receive buffers: a replayed graph would reuse one half and one flag value forever
-    forbid_graph_capture("fast_all_to_all", w)
     half = ctx.call_count & 1
     with_scale = send_scale is not None
     if env.backend == "host":
+        forbid_graph_capture("fast_all_to_all (host backend)", w)
         ctx.send_buf[:n].copy_(send_tensor)
         ctx.split_send_buf.copy_(send_split_cumsum.to(torch.int32))
         if with_scale:
@@ -123,7 +137,10 @@ def fast_all_to_all(ctx: AllToAllContext, send_tensor: torch.Tensor, send_split_
                                         _lib.ptr(ctx.split_recv_buf[rank]), _lib.ptr(ctx.signal_buf[rank]),
                                         _lib.ptr(ctx.err), ctypes.c_longlong(row_bytes), n, ctx.max_m,
                                         ctx.experts_per_rank, ctx.scale_elems, _a2a_slices(n * row_bytes, w, env.shared_gpu),
-                                        ctypes.c_ulonglong(ctx.call_count), _lib.stream_handle()), "tdist_all_to_all")
+                                        ctypes.c_ulonglong(0), _lib.stream_handle(), _lib.ptr(ctx.state),
+                                        _lib.ptr(ctx.out_rows), _lib.ptr(ctx.out_scale), _lib.ptr(ctx.out_splits)),
+            "tdist_all_to_all")
+        return ctx.out_splits, ctx.out_rows, (ctx.out_scale if with_scale else None)
     ctx.call_count = (ctx.call_count + 1) % ctx.MOD_VALUE or 1
     recv = ctx.recv_buf[rank][half].view(w, ctx.max_m, ctx.hidden)
     splits = ctx.split_recv_buf[rank][half].view(w, ctx.experts_per_rank)
@@ -163,11 +180,37 @@ def _a2a_host(ctx, n, half, with_scale):
         raise RuntimeError("fast_all_to_all(host) timed out")
 
 
-def all_to_all_post_process(ctx: AllToAllContext, splits: torch.Tensor, recv: torch.Tensor,
-                            scale: Optional[torch.Tensor] = None):
-    """Compact the per-source segments: returns (tokens [sum, hidden], scales or None,
-    tokens_per_local_expert [EPR])."""
+def _compact_device(ctx, splits, recv, scale):
     w = ctx.world_size
+    assert splits.dtype == torch.int32 and splits.is_contiguous() and recv.is_contiguous()
+    out = torch.empty((w * ctx.max_m, ctx.hidden), dtype=recv.dtype, device=recv.device)
+    out_scale = torch.empty((w * ctx.max_m, ctx.scale_elems), dtype=torch.float32, device=recv.device) if scale is not None else None
+    counts = torch.empty(ctx.experts_per_rank + 1, dtype=torch.int32, device=recv.device)
+    if scale is not None:
+        assert scale.dtype == torch.float32 and scale.is_contiguous()
+    _lib.check(
+        _lib.hip().tdist_a2a_compact(_lib.ptr(recv), _lib.ptr(scale), _lib.ptr(splits), _lib.ptr(out), _lib.ptr(out_scale),
+                                     _lib.ptr(counts), _lib.ptr(counts[ctx.experts_per_rank:]),
+                                     ctypes.c_longlong(ctx.hidden * recv.element_size()), w, ctx.max_m,
+                                     ctx.experts_per_rank, ctx.scale_elems, _lib.stream_handle()), "tdist_a2a_compact")
+    return out, out_scale, counts[: ctx.experts_per_rank], counts[ctx.experts_per_rank:]
+
+
+def all_to_all_post_process(ctx: AllToAllContext, splits: torch.Tensor, recv: torch.Tensor,
+                            scale: Optional[torch.Tensor] = None, padded: bool = False):
+    """Compact the per-source segments: returns (tokens [sum, hidden], scales or None,
+    tokens_per_local_expert [EPR]).  ``padded=True`` (implied while a HIP graph is being captured) keeps everything
+    on the device: tokens / scales come back with ``w * max_m`` rows, of which the first ``total`` are valid, and a
+    fourth value ``total`` (int32 [1]) is returned."""
+    w = ctx.world_size
+    capturing = recv.is_cuda and torch.cuda.is_current_stream_capturing()
+    if recv.is_cuda:
+        out, out_scale, per_expert, total = _compact_device(ctx, splits, recv, scale)
+        if padded or capturing:
+            return out, out_scale, per_expert, total
+        n = int(total)                      # the one host read an exactly sized result needs
+        return out[:n], (out_scale[:n] if out_scale is not None else None), per_expert
+    assert not padded, "padded compaction runs on the GPU backend"
     per_src = splits.sum(dim=1).tolist()
     rows = [recv[s, : per_src[s]] for s in range(w)]
     out = torch.cat(rows, dim=0)
