@@ -167,3 +167,60 @@ def test_ep_dispatch_combine_graph_replay(w, T, topk, hidden, epr, cap):
             check(f"replay {it}")
     finally:
         vc.close()
+
+
+def test_low_latency_dispatch_combine_round_trip_one_graph():
+    """DeepSeek decode shape, 8 ranks: dispatch (fp8 rows + scales) -> compaction -> the return all-to-all, all in ONE
+    graph per rank; the rows that come back are bit-identical to what was sent, in the original (expert-sorted)
+    order (the gather / scatter pair of tutorials/04-deepseek-infer-all2all.py)."""
+    w, epr, max_m, hidden = 8, 4, 1024, 7168
+    E = w * epr
+    vc = VirtualCluster(w, heap_bytes=1 << 29)
+    try:
+        mk = lambda r, env: create_all_to_all_context(max_m, hidden, r, E, w, epr, torch.float8_e4m3fn, env=env)  # noqa: E731
+        disp, comb = vc.collective(mk), vc.collective(mk)
+        send = [torch.zeros(max_m, hidden, device="cuda").to(torch.float8_e4m3fn) for _ in range(w)]
+        sscale = [torch.zeros(max_m, hidden // 128, device="cuda") for _ in range(w)]
+        cum = [torch.zeros(E + 1, dtype=torch.int32, device="cuda") for _ in range(w)]
+        back_cum = [torch.zeros(E + 1, dtype=torch.int32, device="cuda") for _ in range(w)]
+        back = [None] * w
+
+        def step(r, env):
+            splits, recv, rscale = fast_all_to_all(disp[r], send[r], cum[r], sscale[r])
+            toks, tscale, _, _ = all_to_all_post_process(disp[r], splits, recv, rscale, padded=True)
+            # the compacted rows are ordered by source rank = by destination of the way back; "expert" slot j of
+            # destination d carries what d sent for local expert j
+            back_cum[r][1:] = torch.cumsum(splits.reshape(-1), 0)
+            back[r] = fast_all_to_all(comb[r], toks[:max_m], back_cum[r], tscale[:max_m])
+
+        def fresh():
+            for r in range(w):
+                # every destination rank gets at most max_m / w rows from each source, so the way back fits max_m
+                counts = torch.randint(0, max_m // E + 1, (E,), device="cuda")
+                cum[r][1:] = torch.cumsum(counts, 0)
+                send[r].copy_((torch.randn(max_m, hidden, device="cuda") * 4).to(torch.float8_e4m3fn))
+                sscale[r].copy_(torch.rand(max_m, hidden // 128, device="cuda"))
+            torch.cuda.synchronize()
+
+        def check(what):
+            for r in range(w):
+                disp[r].check_error()
+                comb[r].check_error()
+                _, rows, scales = back[r]
+                for d in range(w):
+                    st, ed = int(cum[r][d * epr]), int(cum[r][(d + 1) * epr])
+                    assert torch.equal(rows[d, : ed - st].view(torch.uint8), send[r][st:ed].view(torch.uint8)), f"{what}: {r}<-{d}"
+                    assert torch.equal(scales[d, : ed - st], sscale[r][st:ed]), f"{what}: scales {r}<-{d}"
+
+        fresh()
+        vc.run(step)
+        torch.cuda.synchronize()
+        check("eager")
+        graphs = _capture(vc, step)
+        for it in range(3):
+            fresh()
+            vc.run(lambda r, env: graphs[r].replay())
+            torch.cuda.synchronize()
+            check(f"replay {it}")
+    finally:
+        vc.close()
