@@ -184,15 +184,19 @@ def create_virtual_node(world_size: int, heap_bytes: int = 1 << 28, sig_bytes: i
     Hardware queues: a rank that spins on a peer must not share a queue with it, so run with
     GPU_MAX_HW_QUEUES = min(32, 2 * world_size + 4), set before HIP initialises (at most 14 virtual
     ranks: utils/cli.py refuses more).  The variable is raised here when it is too low and torch has not touched
-    the GPU yet; a process that already initialised HIP with fewer queues is refused - its ranks would wait for
-    peers queued behind them until the spin budget runs out."""
+    the GPU yet; a process that already initialised HIP with fewer queues gets a warning - ranks that run TOGETHER
+    would wait for peers queued behind them until the spin budget runs out (a probe that runs one rank of the
+    cluster alone is fine)."""
     need = min(32, 2 * world_size + 4)
     have = int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0)
     if backend != "host" and world_size > 1 and have < need:
         if torch.cuda.is_initialized():
-            raise RuntimeError(f"{world_size} virtual ranks need GPU_MAX_HW_QUEUES >= {need} (it is {have or 'unset'}) "
-                               "and HIP is already initialised: export it before the first GPU call")
-        os.environ["GPU_MAX_HW_QUEUES"] = str(need)
+            import warnings
+
+            warnings.warn(f"{world_size} virtual ranks running together need GPU_MAX_HW_QUEUES >= {need} (it is "
+                          f"{have or 'unset'}) and HIP is already initialised: export it before the first GPU call")
+        else:
+            os.environ["GPU_MAX_HW_QUEUES"] = str(need)
     backend = backend or ("hip" if torch.cuda.is_available() else "host")
     device = torch.device("cuda", torch.cuda.current_device()) if backend == "hip" else torch.device("cpu")
     heaps = SymmetricHeap.create_virtual(world_size, backend, heap_bytes, sig_bytes)
