@@ -60,6 +60,27 @@ def test_heap_selftest_falls_back_to_the_next_memory_mode():
     assert out["checks_passed_before_timing"] == 2 and out["note"] == "", out
 
 
+def test_heap_selftest_ends_in_the_release_fence_library():
+    """Every memory mode fails with the default library (injected): all ranks switch to libtdist_hip_safe.so - a
+    system-scope release behind every payload publish - walk the modes again, and the run still yields a checked,
+    labelled number instead of none."""
+    res = _torchrun(2, ROOT / "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-baseline",
+                    "--check-iters", "2", port=29576, TDIST_SELFTEST_FAIL_MODES="0,1,2", TDIST_SELFTEST_ROUNDS="20")
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    out = _bench_line(res)
+    assert out["safe_publish"] is True and out["heap_mode"] == "coarse", out
+    assert len(out["heap_selftest"]) == 4 and out["heap_selftest"][3].startswith("coarse +release-fence: ok"), out
+    assert out["checks_passed_before_timing"] == 2 and out["value"] > 0, out
+
+
+def test_safe_publish_from_the_environment():
+    res = _torchrun(2, ROOT / "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-baseline",
+                    "--check-iters", "2", port=29577, TDIST_SAFE_PUBLISH="1")
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    out = _bench_line(res)
+    assert out["safe_publish"] is True and out["checks_passed_before_timing"] == 2 and out["value"] > 0, out
+
+
 def test_bench_exits_nonzero_when_the_fused_path_is_rejected():
     """No silent swap to torch + RCCL: without a symmetric heap there is no result and the exit status says so."""
     res = _torchrun(2, ROOT / "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-baseline",

@@ -5,6 +5,9 @@ next to this file:
 
 * ``libtdist_hip.so``  - gfx950 device code + host launchers + hipIpc runtime
   (built with ``hipcc --offload-arch=gfx950``; cross-compiles without a GPU).
+* ``libtdist_hip_safe.so`` - the same sources with ``-DTDIST_SAFE_PUBLISH=1``: every publish of a payload
+  is followed by a system-scope release fence (``TDIST_SAFE_PUBLISH=1``, or the end of the heap self-test's
+  fall-back chain, loads it instead).
 * ``libtdist_host.so`` - CPU-only runtime (POSIX-shm symmetric heap emulation,
   signal wait/notify with std::atomic, CPU oracle of the AG-MoE tile swizzle).
 
@@ -32,6 +35,7 @@ ARCH = os.environ.get("TDIST_OFFLOAD_ARCH", "gfx950")
 ROCM = Path(os.environ.get("ROCM_PATH", "/opt/rocm"))
 
 HIP_LIB = ROOT / "libtdist_hip.so"
+HIP_SAFE_LIB = ROOT / "libtdist_hip_safe.so"
 HOST_LIB = ROOT / "libtdist_host.so"
 
 HIPCC_FLAGS = [
@@ -66,12 +70,12 @@ def _digest(src: Path, flags: list[str]) -> str:
     return h.hexdigest()[:16]
 
 
-def _compile_one(cc: str, src: Path, flags: list[str], verbose: bool) -> Path:
+def _compile_one(cc: str, src: Path, flags: list[str], verbose: bool, prefix: str = "") -> Path:
     OBJ_DIR.mkdir(parents=True, exist_ok=True)
-    obj = OBJ_DIR / f"{src.stem}.{_digest(src, [cc] + flags)}.o"
+    obj = OBJ_DIR / f"{prefix}{src.stem}.{_digest(src, [cc] + flags)}.o"
     if obj.exists():
         return obj
-    for stale in OBJ_DIR.glob(f"{src.stem}.*.o"):
+    for stale in OBJ_DIR.glob(f"{prefix}{src.stem}.*.o"):
         stale.unlink()
     cmd = [cc, *flags, "-c", str(src), "-o", str(obj)]
     if verbose:
@@ -93,24 +97,33 @@ def host_sources() -> list[Path]:
     return sorted(p for p in (CSRC / "runtime").glob("*.cc") if not p.name.endswith("_hip.cc"))
 
 
-def build_hip(verbose: bool = True, jobs: int | None = None) -> Path:
+def build_hip(verbose: bool = True, jobs: int | None = None, safe: bool = False) -> Path:
+    """``safe``: the TDIST_SAFE_PUBLISH=1 flavour (own objects, own library)."""
     cc = _hipcc()
     srcs = hip_sources()
     jobs = jobs or min(8, max(1, (os.cpu_count() or 2)))
-    flags = list(HIPCC_FLAGS)
+    flags = list(HIPCC_FLAGS) + (["-DTDIST_SAFE_PUBLISH=1"] if safe else [])
+    lib = HIP_SAFE_LIB if safe else HIP_LIB
+    prefix = "safe-" if safe else ""
     with ThreadPoolExecutor(max_workers=jobs) as ex:
-        objs = list(ex.map(lambda s: _compile_one(cc, s, flags, verbose), srcs))
+        objs = list(ex.map(lambda s: _compile_one(cc, s, flags, verbose, prefix), srcs))
     newest = max(o.stat().st_mtime for o in objs)
-    if HIP_LIB.exists() and HIP_LIB.stat().st_mtime >= newest:
-        return HIP_LIB
-    cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fno-gpu-sanitize", *map(str, objs), "-o", str(HIP_LIB)]
+    if lib.exists() and lib.stat().st_mtime >= newest:
+        return lib
+    # -Bsymbolic: the library's own calls bind to itself, so both flavours can live in one process
+    cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fno-gpu-sanitize", "-Wl,-Bsymbolic", *map(str, objs), "-o",
+           str(lib)]
     if verbose:
-        print("[tdist build] link", HIP_LIB.name, flush=True)
+        print("[tdist build] link", lib.name, flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         sys.stderr.write(res.stdout + res.stderr)
-        raise RuntimeError("link failed: libtdist_hip.so")
-    return HIP_LIB
+        raise RuntimeError(f"link failed: {lib.name}")
+    return lib
+
+
+def build_hip_safe(verbose: bool = True, jobs: int | None = None) -> Path:
+    return build_hip(verbose, jobs, safe=True)
 
 
 def build_host(verbose: bool = True) -> Path:
@@ -133,8 +146,9 @@ def build_host(verbose: bool = True) -> Path:
 def build_all(verbose: bool = True) -> None:
     build_host(verbose)
     build_hip(verbose)
+    build_hip(verbose, safe=True)
 
 
 if __name__ == "__main__":
     build_all(verbose=True)
-    print("ok:", HIP_LIB, HOST_LIB)
+    print("ok:", HIP_LIB, HIP_SAFE_LIB, HOST_LIB)

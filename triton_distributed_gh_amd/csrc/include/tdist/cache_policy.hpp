@@ -45,6 +45,20 @@ __device__ __forceinline__ void st_wt64_sys(void* p, const uint2& v) {
 
 // Every storing wave calls this after its last write-through store and before the workgroup
 // barrier that precedes the flag / counter update.
-__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+//
+// TDIST_SAFE_PUBLISH (the second build of the library, libtdist_hip_safe.so): the zero-fence publish above rests on
+// the sc0 / sc1 policy bits pushing every line out of the L2 on this GPU, fabric and firmware.  The safe build pays
+// for not relying on it: the drain is followed by a system-scope release fence (write-back of the whole L2), so the
+// flag store that follows is ordered after the payload by the memory model alone.  Consumers already poll relaxed
+// and issue a system-scope acquire (L1 / L2 invalidate) before their first payload load.
+#ifndef TDIST_SAFE_PUBLISH
+#define TDIST_SAFE_PUBLISH 0
+#endif
+__device__ __forceinline__ void drain_stores() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if TDIST_SAFE_PUBLISH
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+#endif
+}
 
 }  // namespace tdist

@@ -737,3 +737,6 @@ TDIST_API int tdist_p2p_pull(const SymmCtx* ctx, void* local_dst, void* symm_src
   TDIST_HIP_TRY(hipGetLastError());
   return 0;
 }
+
+// 1 in the library built with -DTDIST_SAFE_PUBLISH=1 (release fence before every flag store), 0 in the default one.
+TDIST_API int tdist_build_safe_publish() { return TDIST_SAFE_PUBLISH; }

@@ -52,6 +52,14 @@ class DistEnv:
     def num_ranks(self) -> int:
         return self.world_size
 
+    @property
+    def safe_publish(self) -> bool:
+        """True when the release-fence flavour of the GPU library is in use (``TDIST_SAFE_PUBLISH=1`` or the
+        self-test's last resort): every number measured with it should say so."""
+        from .. import _lib
+
+        return self.backend == "hip" and _lib.safe_publish()
+
 
 _ENV: Optional[DistEnv] = None
 
@@ -147,11 +155,18 @@ def initialize_distributed(seed: Optional[int] = None, heap_bytes: Optional[int]
 def _create_checked_heap(rank: int, world_size: int, cpu_group, heap_bytes, sig_bytes):
     """Create the GPU symmetric heap and prove, before any op uses it, that payloads written by a peer are
     read correctly through this GPU's caches (utils/selftest.py).  Modes are tried in the order
-    coarse-grained -> fine-grained -> uncached; the first one that passes on EVERY rank is kept.
+    coarse-grained -> fine-grained -> uncached; the first one that passes on EVERY rank is kept.  When none does,
+    the process switches to the release-fence flavour of the GPU library (``_lib.use_safe_publish``: a system-scope
+    release behind every payload publish instead of relying on write-through stores) and walks the modes once
+    more, so a node on which the zero-fence publish does not hold still runs - slower, and labelled
+    (``DistEnv.safe_publish``).  The verdict of a probe is the same on every rank (it is all-reduced), so all ranks
+    switch together.
 
     Environment: ``TDIST_HEAP_ALLOC_MODE=m`` pins the mode (still probed; a failure raises),
-    ``TDIST_SELFTEST=0`` skips the probe, ``TDIST_SELFTEST_ROUNDS`` sets its length and
-    ``TDIST_SELFTEST_FAIL_MODES=0,1`` treats the listed modes as failed (exercises the fall-back)."""
+    ``TDIST_SELFTEST=0`` skips the probe, ``TDIST_SELFTEST_ROUNDS`` sets its length,
+    ``TDIST_SELFTEST_FAIL_MODES=0,1`` treats the listed modes as failed with the default library (exercises the
+    fall-back; ``0,1,2`` ends in the release-fence flavour) and ``TDIST_SAFE_PUBLISH=1`` starts with that flavour."""
+    from .. import _lib
     from .selftest import HEAP_MODE_NAMES, coherence_probe, probe_rounds
 
     pinned = os.environ.get("TDIST_HEAP_ALLOC_MODE")
@@ -159,21 +174,30 @@ def _create_checked_heap(rank: int, world_size: int, cpu_group, heap_bytes, sig_
     run_probe = world_size > 1 and os.environ.get("TDIST_SELFTEST", "1") != "0"
     forced_bad = {int(x) for x in os.environ.get("TDIST_SELFTEST_FAIL_MODES", "").split(",") if x.strip()}
     log = []
-    for mode in modes:
-        heap = SymmetricHeap(rank, world_size, cpu_group, "hip", heap_bytes, sig_bytes, data_mode=mode)
-        if not run_probe:
-            return heap, HEAP_MODE_NAMES[mode], None, ()
-        res = coherence_probe(heap, cpu_group, rounds=probe_rounds())
-        if mode in forced_bad:
-            res.ok = False
-        log.append((HEAP_MODE_NAMES[mode], ("ok " if res.ok else "FAILED ") + res.describe()))
-        if res.ok:
-            return heap, HEAP_MODE_NAMES[mode], res, tuple(log)
-        if rank == 0:
-            print(f"[tdist] symmetric heap self-test FAILED in mode {HEAP_MODE_NAMES[mode]}: {res.describe()}",
-                  flush=True)
-        heap.close(sync_group=cpu_group)
-    raise RuntimeError("symmetric heap self-test failed in every memory mode: " + "; ".join(f"{m}: {d}" for m, d in log))
+    for flavour in ("default", "safe"):
+        if flavour == "safe":
+            if _lib.safe_publish():
+                break                       # (already the flavour the first pass ran with)
+            if rank == 0:
+                print("[tdist] falling back to the release-fence publish (libtdist_hip_safe.so)", flush=True)
+            _lib.use_safe_publish()
+        tag = " +release-fence" if _lib.safe_publish() else ""
+        for mode in modes:
+            heap = SymmetricHeap(rank, world_size, cpu_group, "hip", heap_bytes, sig_bytes, data_mode=mode)
+            if not run_probe:
+                return heap, HEAP_MODE_NAMES[mode], None, ()
+            res = coherence_probe(heap, cpu_group, rounds=probe_rounds())
+            if mode in forced_bad and not _lib.safe_publish():
+                res.ok = False
+            log.append((HEAP_MODE_NAMES[mode] + tag, ("ok " if res.ok else "FAILED ") + res.describe()))
+            if res.ok:
+                return heap, HEAP_MODE_NAMES[mode], res, tuple(log)
+            if rank == 0:
+                print(f"[tdist] symmetric heap self-test FAILED in mode {HEAP_MODE_NAMES[mode]}{tag}: {res.describe()}",
+                      flush=True)
+            heap.close(sync_group=cpu_group)
+    raise RuntimeError("symmetric heap self-test failed in every memory mode, with and without release fences: " +
+                       "; ".join(f"{m}: {d}" for m, d in log))
 
 
 def create_virtual_node(world_size: int, heap_bytes: int = 1 << 28, sig_bytes: int = 1 << 22,
