@@ -78,17 +78,29 @@ def main():
         _, t_native = perf_func(g2.replay, args.iters, 5)
         res["native_layers_graph_ms"] = round(t_native, 4)
         model.set_fwd("torch")
-    mega = Qwen3Model(model, B, L, page_size=64, num_queues=args.queues, scheduler=args.scheduler, env=env)
-    mega.kv_cache.rand_fill_kv_cache(args.ctx)
+    # the mega API twice: its default back-end (the task graph lowered onto fused launches inside one HIP graph when
+    # the model lowers, mega/graph_backend.py) and the persistent interpreter kernel
+    t_mega = None
+    for backend in ("auto", "interpreter"):
+        mega = Qwen3Model(model, B, L, page_size=64, num_queues=args.queues, scheduler=args.scheduler, env=env,
+                          backend=backend)
+        mega.kv_cache.rand_fill_kv_cache(args.ctx)
 
-    def mega_step():
-        mega.set_kv_len(args.ctx)
-        return mega.mega_forward(tok)
+        def mega_step():
+            mega.set_kv_len(args.ctx)
+            return mega.mega_forward(tok)
 
-    _, t_mega = perf_func(mega_step, args.iters, 5)
-    mega.check_error()
-    res["mega_ms"] = round(t_mega, 4)
-    res["mega_tasks"] = mega.num_tasks
+        _, t = perf_func(mega_step, args.iters, 5)
+        mega.check_error()
+        key = "mega_ms" if backend == "auto" else "mega_interpreter_ms"
+        res[key] = round(t, 4)
+        if backend == "auto":
+            t_mega = t
+            res["mega_backend"] = mega.backend
+            res["mega_launches"] = mega.num_tasks
+        else:
+            res["mega_tasks"] = mega.num_tasks
+        del mega
     wbytes = sum(t.numel() * t.element_size() for layer in model.layers
                  for t in (layer.attn.wqkv, layer.attn.wo, layer.mlp.gate_up_proj, layer.mlp.down_proj)) \
         + model.lm_head.numel() * 2

@@ -185,12 +185,50 @@ def test_allreduce_and_barrier_tasks_on_virtual_ranks(w):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("w", [1, 2])
-def test_qwen3_mega_forward_matches_torch_decode(w):
+def test_graph_backend_matches_the_interpreter_on_a_small_graph():
+    """The same recorded ops through both back-ends: norm -> linear and norm(+residual) -> fc1 are fused launches in
+    the graph form, the rest lowers one to one; outputs land in the recorded tensors either way."""
+    M, H, N, I = 5, 1024, 768, 512
+    torch.manual_seed(3)
+    x, r = torch.randn(M, H, device="cuda").to(BF), torch.randn(M, H, device="cuda").to(BF)
+    nw = (1 + 0.1 * torch.randn(H, device="cuda")).to(BF)
+    w1 = (torch.randn(N, H, device="cuda") / 32).to(BF)
+    wgu = (torch.randn(2 * I, H, device="cuda") / 32).to(BF)
+    w2 = (torch.randn(H, I, device="cuda") / 32).to(BF)
+    results = {}
+    for backend in ("interpreter", "graph"):
+        new = lambda *s: torch.zeros(*s, device="cuda", dtype=BF)   # noqa: E731
+        xn, y1, hid, act, y2, s_ = new(M, H), new(M, N), new(M, H), new(M, I), new(M, H), new(M, H)
+        b = ModelBuilder(num_queues=32)
+        b.make_rms_norm(x, nw, xn, 1e-6)
+        b.make_linear(xn, w1, y1)
+        b.make_rms_norm(x, nw, xn, 1e-6, residual=r, residual_out=hid)
+        b.make_fc1(xn, wgu, act)
+        b.make_fc2(act, w2, y2, residual=hid)
+        b.make_add(y2, hid, s_)
+        c = b.compile(backend=backend)
+        assert c["backend"] == backend
+        for _ in range(3):                      # graph form: eager, capture + replay, replay
+            b.run()
+        torch.cuda.synchronize()
+        b.check_error()
+        results[backend] = (y1, hid, s_)
+        if backend == "graph":
+            assert len(c["program"].steps) == 4 and c["program"].graph is not None, c["program"].launch_names
+    for a, g_ in zip(results["interpreter"], results["graph"]):
+        assert _rel(g_, a.float()) < 2e-2
+    assert torch.equal(results["interpreter"][1], results["graph"][1])      # the residual stream is exact in both
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,name,backend", [(1, "tdist/tiny-dense", "interpreter"), (2, "tdist/tiny-dense", "interpreter"),
+                                            (1, "tdist/tiny-dense-d128", "graph"), (2, "tdist/tiny-dense-d128", "graph"),
+                                            (1, "tdist/tiny-dense", "auto")])
+def test_qwen3_mega_forward_matches_torch_decode(w, name, backend):
     from triton_distributed_gh_amd.models import AutoLLM, KV_Cache, ModelConfig
     from triton_distributed_gh_amd.utils.testing import VirtualCluster
 
-    name, B, prompt, L = "tdist/tiny-dense", 4, 24, 256
+    B, prompt, L = 4, 24, 256
     torch.manual_seed(7)
     g = AutoLLM.from_pretrained(ModelConfig(model_name=name, max_length=L, dtype=BF, rank=0, world_size=1))
     gkv = KV_Cache(g.num_layers, B, L, g.num_key_value_heads, g.head_dim, BF, 1)
@@ -202,7 +240,10 @@ def test_qwen3_mega_forward_matches_torch_decode(w):
     try:
         models = [AutoLLM.from_pretrained(ModelConfig(model_name=name, max_length=L, dtype=BF, rank=r, world_size=w),
                                           env=vc.envs[r]) for r in range(w)]
-        megas = vc.collective(lambda r, env: Qwen3Model(models[r], B, L, page_size=16, num_queues=64 // w, env=env))
+        megas = vc.collective(lambda r, env: Qwen3Model(models[r], B, L, page_size=16, num_queues=64 // w, env=env,
+                                                        backend=backend))
+        # head_dim 64 has no fused attention launch: "auto" falls back to the interpreter
+        assert megas[0].backend == ("graph" if backend == "graph" else "interpreter")
         hl = g.num_key_value_heads // w
         for r, m in enumerate(megas):       # copy the golden prefill cache into the paged caches
             for li in range(g.num_layers):
@@ -214,7 +255,7 @@ def test_qwen3_mega_forward_matches_torch_decode(w):
                     vcache[base:base + prompt] = gkv.v_cache[li, b_, :prompt, r * hl:(r + 1) * hl]
             m.set_kv_len(prompt)
         tok = logits[:, -1].argmax(-1, keepdim=True)
-        for step in range(3):
+        for step in range(4):
             ref = g.inference(tok, gkv.get_kv_len()[:, None].long(), gkv)
             gkv.inc_offset()
             torch.cuda.synchronize()

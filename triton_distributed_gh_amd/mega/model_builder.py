@@ -1,5 +1,7 @@
 """ModelBuilder: record ops (``make_*``), derive tile tasks + dependencies, schedule them onto work
-queues and run the whole graph as ONE persistent kernel launch.
+queues and run the whole graph as ONE persistent kernel launch (``compile(backend="interpreter")``), or lower the
+same op list onto the library's fused launches inside ONE HIP graph (``compile(backend="graph")``,
+mega/graph_backend.py - the faster of the two on MI355X).
 
 Reference: python/triton_dist/mega_triton_kernel/models/model_builder.py:85-404 (``make_fc1 / fc2 /
 qkv_proj / o_proj / linear`` :189-201, ``make_attn`` :211, ``make_silu_mul_up`` :251,
@@ -237,7 +239,27 @@ class ModelBuilder:
         return tasks
 
     # ---- compile / run -------------------------------------------------------------------------------
-    def compile(self, validate: bool = True):
+    def compile(self, validate: bool = True, backend: str = "interpreter", outputs=None):
+        """``backend``: "interpreter" (one persistent kernel walking the task queues), "graph" (fused native
+        launches captured in one HIP graph; raises ``LoweringError`` for a graph it cannot lower) or "auto" (graph
+        when the op list lowers, else the interpreter).  ``outputs`` (graph back-end): the recorded tensors the caller
+        reads after a step - only those are copied back from the fused launches' own buffers; default: every
+        tensor the graph writes."""
+        assert backend in ("interpreter", "graph", "auto")
+        if backend != "interpreter" and self.device.type == "cuda":
+            from .graph_backend import GraphProgram, LoweringError
+
+            try:
+                prog = GraphProgram(self, outputs)
+            except LoweringError:
+                if backend == "graph":
+                    raise
+                prog = None
+            if prog is not None:
+                self._compiled = dict(backend="graph", program=prog, num_tasks=len(prog.steps), err=None)
+                return self._compiled
+        elif backend == "graph":
+            raise RuntimeError("the graph back-end needs a GPU")
         tasks = self.build_tasks()
         queues = SCHEDULERS[self.scheduler](tasks, self.num_queues)
         if validate:
@@ -248,13 +270,16 @@ class ModelBuilder:
         max_tiles = max(op.num_tiles for op in self.ops)
         scoreboard = torch.zeros(len(self.ops) * max_tiles, dtype=torch.int32, device=self.device)
         err = torch.zeros(4, dtype=torch.int32, device=self.device)
-        self._compiled = dict(queues=qbuf, qlen=qlen, max_tasks=max_tasks, ops=raw, scoreboard=scoreboard, err=err,
-                              max_tiles=max_tiles, num_tasks=len(tasks))
+        self._compiled = dict(backend="interpreter", queues=qbuf, qlen=qlen, max_tasks=max_tasks, ops=raw,
+                              scoreboard=scoreboard, err=err, max_tiles=max_tiles, num_tasks=len(tasks))
         self._metrics["memory"] += qbuf.numel() * 4 + raw.numel() + scoreboard.numel() * 4
         return self._compiled
 
     def run(self, stream=None):
         c = self._compiled or self.compile()
+        if c["backend"] == "graph":
+            c["program"].run()
+            return
         self._epoch += 1
         cs = self.env.heap.ctx_struct() if self.env is not None else _null_ctx()
         _lib.check(
@@ -263,6 +288,11 @@ class ModelBuilder:
                                          c["max_tiles"], self._epoch, _lib.stream_handle(stream)), "tdist_mega_launch")
 
     def check_error(self):
+        if self._compiled is not None and self._compiled["backend"] == "graph":
+            ctx = self._compiled["program"]._ar_ctx
+            if ctx is not None:
+                ctx.check_error()
+            return
         if self._compiled is not None and int(self._compiled["err"][0]) != 0:
             raise RuntimeError(f"mega kernel reported error word {int(self._compiled['err'][0])} "
                                "(1 = dependency wait timed out, 2 = barrier timed out, 4 = unknown task type)")

@@ -1,4 +1,5 @@
-"""Qwen3-style dense decoder as ONE persistent-kernel launch per decode step.
+"""Qwen3-style dense decoder as ONE launch per decode step: a replayed HIP graph of fused kernels (``backend="auto"``
+/ ``"graph"``, the default and the faster form on MI355X) or the persistent interpreter kernel (``"interpreter"``).
 
 Reference: python/triton_dist/mega_triton_kernel/models/qwen3.py (``Qwen3Model`` :191-201
 ``mega_forwrad``), models/layers/tp_attn.py, tp_mlp.py and models/paged_kv_cache.py.  The graph is
@@ -61,7 +62,8 @@ class Qwen3LayerBuilder:
 class Qwen3Model:
 
     def __init__(self, model, batch_size: int, max_length: Optional[int] = None, page_size: int = 64,
-                 num_queues: int = 256, scheduler: str = "round_robin", env=None, prefetch_weights: bool = False):
+                 num_queues: int = 256, scheduler: str = "round_robin", env=None, prefetch_weights: bool = False,
+                 backend: str = "auto"):
         assert batch_size <= 16, "decode batch of at most 16 tokens per step"
         self.model, self.batch_size = model, batch_size
         self.env = env or model.env
@@ -113,7 +115,8 @@ class Qwen3Model:
         V = model.lm_head.shape[0]
         self.logits = new(B, V)
         b.make_linear(self.final, model.lm_head, self.logits, name="lm_head")
-        self.compiled = b.compile()
+        self.compiled = b.compile(backend=backend, outputs=[self.logits, self.hidden])
+        self.backend = self.compiled["backend"]
 
     @property
     def num_tasks(self) -> int:

@@ -69,6 +69,7 @@ KNOWN_ARCHS = {
                                                        max_position_embeddings=524288, qk_norm=False),
     # tiny architectures for tests and smoke runs (not in the reference's table)
     "tdist/tiny-dense": ArchConfig(512, 1024, 2, 8, 8, head_dim=64, vocab_size=1024, max_position_embeddings=2048),
+    "tdist/tiny-dense-d128": ArchConfig(1024, 2048, 2, 8, 4, head_dim=128, vocab_size=1024, max_position_embeddings=2048),
     "tdist/tiny-moe": ArchConfig(512, 1024, 2, 8, 8, head_dim=64, vocab_size=1024, max_position_embeddings=2048,
                                  num_experts=8, num_experts_per_tok=2, moe_intermediate_size=1024),
 }
