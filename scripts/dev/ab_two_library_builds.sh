@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of two builds of the native library on one box: libtdist_hip_old.so against libtdist_hip.so
 set -o pipefail
-O=gpurun_out/r2/ab
+O=gpurun_out/ab
 mkdir -p $O
 L=triton_distributed_gh_amd
 cp $L/libtdist_hip.so /tmp/new.so && cp $L/libtdist_hip_old.so /tmp/old.so

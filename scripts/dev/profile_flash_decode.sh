@@ -2,7 +2,7 @@
 # flash decode: throughput lines and two counter passes
 set -o pipefail
 R=$GRAFT_REPO_ROOT
-O=gpurun_out/r2/fdec
+O=gpurun_out/fdec
 mkdir -p $R/$O
 T=$R/triton_dist/test/nvidia/test_decode_attn.py
 timeout -k 10 200 python -u $T --batch 64 --kv-len 4096 --page-size 64 > $R/$O/b64.log 2>&1 || exit 1

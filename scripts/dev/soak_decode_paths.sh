@@ -1,7 +1,7 @@
 #!/bin/bash
 # soak of the decode paths: attention / layer / MoE tests three times over, then long generations on both model families
 set -o pipefail
-O=gpurun_out/r2/soak
+O=gpurun_out/soak
 mkdir -p $O
 for i in 1 2 3; do
   timeout -k 10 400 python -u -m pytest -x -q --timeout 120 --timeout-method thread -p no:randomly tests/test_attention_gpu.py tests/test_layers_gpu.py tests/test_moe_gpu.py tests/test_gemm_gpu.py > $O/t$i.log 2>&1 || { tail -30 $O/t$i.log; exit 1; }

@@ -2,7 +2,7 @@
 # long race hunt: fused TP ops under hostile timing at 2 / 4 / 8 virtual ranks, and the AG-GEMM stress script
 set -o pipefail
 R=$GRAFT_REPO_ROOT
-O=gpurun_out/r2/stress
+O=gpurun_out/stress
 mkdir -p $R/$O
 cd $R
 for W in 8; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # decode step of Qwen3-8B against batch size and context (HIP graph), current defaults
 set -o pipefail
-O=gpurun_out/r2/sweep
+O=gpurun_out/sweep
 mkdir -p $O
 for B in 1 2 4 8 16; do
   timeout -k 10 200 python -u benchmarks/bench_qwen3_mega.py --bsz $B > $O/bs$B.log 2>&1 || { tail -30 $O/bs$B.log; exit 1; }

@@ -1,8 +1,9 @@
 """GEMM + all-reduce layer wrapper (reference: layers/nvidia/gemm_allreduce_layer.py:33-116).
 
-The reference picks between a low-latency and a throughput kernel configuration; on MI355X both
-map to the same persistent 256x256 MFMA kernel whose reduction workgroups read peers over xGMI,
-so ``use_ll_kernel`` only changes how many workgroups are launched for small M."""
+The reference picks between a low-latency and a throughput kernel configuration; so does ``gemm_allreduce_op``:
+up to 256 rows the low-latency kernel (split-K partials pushed to every peer with the flag in the data, one
+launch), above that the persistent 256-row tile kernel whose 32-row reduce slabs are queued a tile group behind
+the GEMM tiles (csrc/ops/gemm_ar.hip).  The choice is made per call from the row count (``TDIST_GEMM_AR_LL_MAX_M``); ``use_ll_kernel`` is accepted for the reference's signature and recorded."""
 from __future__ import annotations
 
 import torch

@@ -79,7 +79,8 @@ def create_all_to_all_context(max_m, hidden, rank, num_tot_experts, WORLD_SIZE, 
     split_send = torch.zeros((num_tot_experts + 1,), dtype=torch.int32, device=dev)
     split_recv = heap.create_tensor_list([2, w * experts_per_rank], torch.int32)
     signal = heap.create_tensor_list([2 * w], torch.int64, arena="sig")
-    err = torch.zeros(4 + 16, dtype=torch.int32, device=dev)   # error word + per-destination slice counters if env.backend == "hip" else None
+    # [0] error word, [4 : 4 + w] per-destination slice counters (zero at rest: the kernel re-arms them)
+    err = torch.zeros(4 + 16, dtype=torch.int32, device=dev) if env.backend == "hip" else None
     state = out_rows = out_scale = out_splits = None
     if env.backend == "hip":
         state = torch.zeros(4, dtype=torch.int32, device=dev)
