@@ -258,6 +258,48 @@ def test_decode_step_from_qkv_matches_prep_then_attention(B, Hq, Hkv, max_len, n
         assert (out.float() - ref).abs().max().item() <= 2e-2
 
 
+@pytest.mark.parametrize("max_len", [64, 96, 100, 256])
+def test_decode_step_from_qkv_with_a_full_cache(max_len):
+    """kv_offset == max_len: the new token is attended from registers and NOT appended.  The cache tensors are the
+    last allocation of their sequence (B = 1 and the table of the LAST sequence): a look-up one page too far would
+    read beyond the table and the cache.  Result = attention over the max_len cached tokens plus the new one."""
+    from triton_distributed_gh_amd.ops import elementwise, flash_decode
+
+    torch.manual_seed(max_len)
+    dev, bf, D, Hq, Hkv, B = "cuda", torch.bfloat16, 128, 8, 2, 2
+    W = (Hq + 2 * Hkv) * D
+    cos, sin = elementwise.rope_cache(max_len + 8, D, device=dev)
+    qkv = (torch.rand(B, 1, W, device=dev) * 2 - 1).to(bf)
+    kc = (torch.randn(B, max_len, Hkv, D, device=dev) * 0.5).to(bf)
+    vc = torch.randn(B, max_len, Hkv, D, device=dev).to(bf)
+    kc0, vc0 = kc.clone(), vc.clone()
+    offs = torch.tensor([max_len, max_len - 1], dtype=torch.int32, device=dev)     # full, and one slot left
+    pos = offs.long()[:, None]
+    total = torch.zeros(B, dtype=torch.int32, device=dev)
+    for one_launch in (False, True):
+        kc.copy_(kc0), vc.copy_(vc0)
+        out = flash_decode.decode_step_from_qkv(qkv, None, None, 1e-6, 1e-6, pos, cos, sin, kc, vc, offs, total, Hq, Hkv,
+                                                one_launch=one_launch)
+        torch.cuda.synchronize()
+        assert total.tolist() == [max_len + 1, max_len]
+        assert torch.equal(kc[0], kc0[0]) and torch.equal(vc[0], vc0[0]), "a full cache is left as it is"
+        # reference: rotate q / k of the new token, attend over cached tokens + the new one
+        q = qkv[:, 0, : Hq * D].view(B, Hq, D).clone()
+        kn = qkv[:, 0, Hq * D:(Hq + Hkv) * D].view(B, Hkv, D).clone()
+        vn = qkv[:, 0, (Hq + Hkv) * D:].view(B, Hkv, D)
+        elementwise.apply_rope_(q, pos.view(-1), cos, sin)
+        elementwise.apply_rope_(kn, pos.view(-1), cos, sin)
+        for b in range(B):
+            n = int(offs[b])
+            keys = torch.cat([kc0[b, :n], kn[b:b + 1]]).float()        # [n + 1, Hkv, D]
+            vals = torch.cat([vc0[b, :n], vn[b:b + 1]]).float()
+            for h in range(Hq):
+                g = h // (Hq // Hkv)
+                p = torch.softmax(keys[:, g] @ q[b, h].float() * D ** -0.5, 0)
+                ref = p @ vals[:, g]
+                assert (out[b, h].float() - ref).abs().max().item() <= 2e-2, (max_len, b, h, one_launch)
+
+
 def test_attention_running_max_covers_every_lane_group():
     """One key far above the rest, placed at every position of a 32-token block in turn: the running maximum
     must be the maximum over ALL lane groups of the wave.  With a maximum taken from one group only, a

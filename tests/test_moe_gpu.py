@@ -166,3 +166,45 @@ def test_router_epilogue_matches_torch_topk(n, E, k, renorm):
         assert above <= got and got - above == set(ties[: k - len(above)]), f"row {t}: {sorted(got)}"
     if n > 1:
         assert ids[1].tolist() == list(range(k))
+
+
+def test_router_ids_stay_in_range_for_nan_and_inf_logits():
+    """A NaN or +inf logit (inf - inf) leaves no ordinary winner: the ids must still be valid, distinct experts -
+    they index the expert weights in the decode kernels - and rows without such values are untouched."""
+    from triton_distributed_gh_amd.ops.moe import moe_route
+
+    E, k = 128, 8
+    logits = (torch.randn(6, E, device="cuda") * 2).to(torch.bfloat16)
+    clean = logits.clone()
+    logits[1, 5] = float("nan")
+    logits[2, :] = float("nan")
+    logits[3, 7] = float("inf")
+    logits[4, 9] = float("-inf")
+    wts, ids = moe_route(logits, k, True)
+    assert int(ids.min()) >= 0 and int(ids.max()) < E
+    for t in range(6):
+        assert len(set(ids[t].tolist())) == k, f"row {t}: {ids[t].tolist()}"
+    w0, i0 = moe_route(clean, k, True)
+    for t in (0, 5):
+        assert torch.equal(ids[t], i0[t]) and torch.equal(wts[t], w0[t])
+    assert torch.isfinite(wts[4]).all() and 9 not in ids[4].tolist()
+
+
+def test_moe_decode_kernels_tolerate_an_expert_id_out_of_range():
+    """An id beyond the expert count is clamped by the kernels (no fault); the other tokens are exact."""
+    from triton_distributed_gh_amd.ops.moe import moe_decode_fwd
+
+    n, H, I, E, topk = 3, 512, 256, 8, 2
+    dev, bf = "cuda", torch.bfloat16
+    x = (torch.rand(n, H, device=dev) * 2 - 1).to(bf)
+    gate_up = ((torch.rand(E, 2 * I, H, device=dev) * 2 - 1) * 0.05).to(bf)
+    down = ((torch.rand(E, H, I, device=dev) * 2 - 1) * 0.05).to(bf)
+    ids = torch.tensor([[0, 1], [2, 3], [4, 5]], device=dev, dtype=torch.int32)
+    wts = torch.full((n, topk), 0.5, device=dev)
+    good = moe_decode_fwd(x, ids, wts, gate_up, down)
+    bad = ids.clone()
+    bad[1, 0] = 0x7fffffff
+    bad[1, 1] = -5
+    out = moe_decode_fwd(x, bad, wts, gate_up, down)
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], good[0]) and torch.equal(out[2], good[2]) and torch.isfinite(out.float()).all()

@@ -378,10 +378,16 @@ __device__ __forceinline__ int decode_split_body(const DecodeArgs& a, const int 
   // per-lane look-ups through the vector L1 in front of the sixteen K / V loads that depend on them.
   // The same holds for any page size that is a multiple of 32, and for a sequence that fits its first page
   // whatever the page size (a cache of one contiguous run of max_len slots per sequence: max_len is arbitrary).
-  const bool single = kv_len <= a.page_size;
+  // PREP with a full cache (kv_offset == max_slots: the new token is attended from registers and dropped): the
+  // attended range is one token longer than the cache, so everything that ADDRESSES the cache is clamped to its
+  // last slot / last 32-token block - the block that holds only the new token would otherwise look up a page
+  // beyond the sequence's table.
+  const int tok_cap = PREP ? min(kv_len, a.max_slots) - 1 : kv_len - 1;
+  const int n0_cap = PREP ? (tok_cap & ~31) : 0x7fffffff;
+  const bool single = tok_cap < a.page_size;
   const bool one_page = single || a.page_shift >= 5 || (a.page_shift < 0 && (a.page_size & 31) == 0);
   auto block_slot0 = [&](int n0) -> long long {     // slot of token n0 (wave-uniform)
-    const int n0u = __builtin_amdgcn_readfirstlane(n0);
+    const int n0u = __builtin_amdgcn_readfirstlane(min(n0, n0_cap));
     if (single) return (long long)table[0] * a.page_size + n0u;
     if (a.page_shift >= 0) {
       const int page = table[n0u >> a.page_shift];
@@ -396,19 +402,20 @@ __device__ __forceinline__ int decode_split_body(const DecodeArgs& a, const int 
     uint32_t v[8][VW];
   };
   auto load_block = [&](int n0, long long slot0, KVBlock& r) {
-    auto slot_in_block = [&](int tok) -> long long {      // tok in [n0, n0 + 32), already clamped to kv_len - 1
-      return one_page ? slot0 + (tok - n0) : slot_of(a, table, tok);
+    const int n0c = min(n0, n0_cap);
+    auto slot_in_block = [&](int tok) -> long long {      // tok in [n0c, n0c + 32), already clamped to tok_cap
+      return one_page ? slot0 + (tok - n0c) : slot_of(a, table, tok);
     };
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
-      const int tok = min(n0 + 16 * blk + li, kv_len - 1);
+      const int tok = min(n0 + 16 * blk + li, tok_cap);
       const uint16_t* kp = kbase + slot_in_block(tok) * a.k_stride_slot;
 #pragma unroll
       for (int s = 0; s < KS; ++s) r.k[blk][s] = ld_stream16(kp + 32 * s);
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      const int tok = min(n0 + 16 * (t >> 2) + 4 * lg + (t & 3), kv_len - 1);
+      const int tok = min(n0 + 16 * (t >> 2) + 4 * lg + (t & 3), tok_cap);
       const uint16_t* vp = vbase + slot_in_block(tok) * a.v_stride_slot;
       if constexpr (VW >= 4) {
 #pragma unroll

@@ -317,13 +317,13 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const uint16_t*
                                                              const uint16_t* __restrict__ G = nullptr,
                                                              uint16_t* __restrict__ Hout = nullptr, float eps = 0.f,
                                                              const int* __restrict__ gid = nullptr, int gdiv = 1,
-                                                             long long gstride = 0) {
+                                                             long long gstride = 0, int gcount = 1) {
   static_assert(!NORM || IS_BF16, "the fused norm is built for bf16");
   // Grouped form (MoE decode): blockIdx.y = (token, expert) pair p; the pair multiplies row p / gdiv of X with the
   // weights of expert gid[p] (gstride elements apart) into row p of C.
   if (gid) {
     const int p = blockIdx.y;
-    W += (long long)gid[p] * gstride;
+    W += (long long)min(max(gid[p], 0), gcount - 1) * gstride;      // (an id out of range must not become a fault)
     X += (long long)(p / gdiv) * ldx;
     C += (long long)p * ldc;
   }
@@ -588,7 +588,8 @@ __global__ __launch_bounds__(64 * NW) void moe_decode_down_kernel(const uint16_t
                                                                   const int* __restrict__ ids,
                                                                   const float* __restrict__ wts,
                                                                   const uint16_t* __restrict__ down,
-                                                                  uint16_t* __restrict__ out, int topk, int H, int Ip) {
+                                                                  uint16_t* __restrict__ out, int topk, int H, int Ip,
+                                                                  int E) {
   using F = Frag<true>;
   using VT = typename F::T;
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -600,7 +601,7 @@ __global__ __launch_bounds__(64 * NW) void moe_decode_down_kernel(const uint16_t
   float part = 0.f;
   for (int kk = wk; kk < topk; kk += NW) {
     const int p = t * topk + kk;
-    const int e = ids[p];
+    const int e = min(max(ids[p], 0), E - 1);
     const float wgt = wts[p];
     const uint16_t* wr = down + ((long long)e * H + min(n0 + li, H - 1)) * Ip + lg * 8;
     const uint16_t* xr = hbuf + (long long)p * Ip + lg * 8;
@@ -652,26 +653,26 @@ __global__ __launch_bounds__(64 * NW) void moe_decode_down_kernel(const uint16_t
 // e = ids[p]) pair p = t * topk + k.  gate_up [E, 2 Ip, H] (gate rows first), x [tokens, H], hbuf [pairs, Ip]; bf16.
 // The decode GEMM with its fused activation, one grid row per pair.
 TDIST_API int tdist_moe_decode_gate_up(const void* x, const int* ids, const void* gate_up, void* hbuf, int tokens,
-                                       int topk, int Ip, int H, void* stream) {
-  TDIST_REQUIRE(tokens > 0 && topk > 0 && (long long)tokens * topk <= 65535, "bad token / top-k count");
+                                       int topk, int Ip, int H, int E, void* stream) {
+  TDIST_REQUIRE(tokens > 0 && topk > 0 && (long long)tokens * topk <= 65535 && E > 0, "bad token / top-k / expert count");
   TDIST_REQUIRE(H >= 128 && H % 32 == 0 && Ip > 0 && Ip % 16 == 0, "H must be a multiple of 32 (>= 128), Ip of 16");
   TDIST_REQUIRE((((uintptr_t)x | (uintptr_t)gate_up) & 15) == 0 && (((uintptr_t)hbuf) & 3) == 0 && ids, "operands must be aligned");
   hipLaunchKernelGGL((gemm_nt_skinny_kernel<true, 2, 4, true>), dim3(Ip / 16, tokens * topk), dim3(256), 0,
                      (hipStream_t)stream, (const uint16_t*)x, (const uint16_t*)gate_up, (uint16_t*)hbuf, 1, Ip, H,
                      (long long)H, (long long)H, (long long)Ip, (const uint16_t*)nullptr, (const uint16_t*)nullptr,
-                     (uint16_t*)nullptr, 0.f, ids, topk, (long long)2 * Ip * H);
+                     (uint16_t*)nullptr, 0.f, ids, topk, (long long)2 * Ip * H, E);
   TDIST_HIP_TRY(hipGetLastError());
   return 0;
 }
 
 // out [tokens, H] = sum over the top-k experts of wts * down[e] @ hbuf[pair] (see moe_decode_down_kernel).
 TDIST_API int tdist_moe_decode_down(const void* hbuf, const int* ids, const float* wts, const void* down, void* out,
-                                    int tokens, int topk, int H, int Ip, void* stream) {
-  TDIST_REQUIRE(tokens > 0 && tokens <= 65535 && topk > 0, "bad token / top-k count");
+                                    int tokens, int topk, int H, int Ip, int E, void* stream) {
+  TDIST_REQUIRE(tokens > 0 && tokens <= 65535 && topk > 0 && E > 0, "bad token / top-k / expert count");
   TDIST_REQUIRE(Ip >= 32 && Ip % 32 == 0 && H > 0, "Ip must be a multiple of 32");
   TDIST_REQUIRE((((uintptr_t)hbuf | (uintptr_t)down) & 15) == 0 && ids && wts && out, "operands must be aligned");
   hipLaunchKernelGGL((moe_decode_down_kernel<8>), dim3((H + 15) / 16, tokens), dim3(512), 0, (hipStream_t)stream,
-                     (const uint16_t*)hbuf, ids, wts, (const uint16_t*)down, (uint16_t*)out, topk, H, Ip);
+                     (const uint16_t*)hbuf, ids, wts, (const uint16_t*)down, (uint16_t*)out, topk, H, Ip, E);
   TDIST_HIP_TRY(hipGetLastError());
   return 0;
 }

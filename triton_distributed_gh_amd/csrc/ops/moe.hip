@@ -672,7 +672,11 @@ __global__ __launch_bounds__(64) void moe_route_kernel(const uint16_t* __restric
   float den = 0.f;
 #pragma unroll
   for (int j = 0; j < VPT; ++j) {
-    v[j] = lane + 64 * j < E ? expf(v[j] - mx) : -1.f;      // probabilities are >= 0: -1 marks "not a candidate"
+    float pj = expf(v[j] - mx);
+    // a NaN logit (or +inf: inf - inf) must stay a candidate, or no lane would win a round and the sentinel index
+    // would be written as an expert id; tested on the bits because the file is built with finite-math assumptions
+    if ((__builtin_bit_cast(uint32_t, pj) & 0x7fffffffu) > 0x7f800000u) pj = 0.f;
+    v[j] = lane + 64 * j < E ? pj : -1.f;                    // probabilities are >= 0: -1 marks "not a candidate"
     den += fmaxf(v[j], 0.f);
   }
 #pragma unroll
@@ -699,7 +703,7 @@ __global__ __launch_bounds__(64) void moe_route_kernel(const uint16_t* __restric
     }
     const float p = best * inv;
     sum_w += p;
-    if (lane == i) my_id = bidx, my_w = p;
+    if (lane == i) my_id = min(bidx, E - 1), my_w = p;      // (in range whatever the inputs were)
   }
   if (lane < k) {
     ids[(long long)t * k + lane] = my_id;

@@ -495,9 +495,9 @@ def moe_decode_fwd(x: torch.Tensor, topk_ids: torch.Tensor, topk_weights: torch.
     out = torch.empty((n, H), dtype=x.dtype, device=x.device)
     lib = _lib.hip()
     _lib.check(lib.tdist_moe_decode_gate_up(_lib.ptr(x), _lib.ptr(ids), _lib.ptr(gate_up), _lib.ptr(hbuf), n, k, Ip, H,
-                                            _lib.stream_handle()), "tdist_moe_decode_gate_up")
+                                            gate_up.shape[0], _lib.stream_handle()), "tdist_moe_decode_gate_up")
     _lib.check(lib.tdist_moe_decode_down(_lib.ptr(hbuf), _lib.ptr(ids), _lib.ptr(wts), _lib.ptr(down), _lib.ptr(out),
-                                         n, k, H, Ip, _lib.stream_handle()), "tdist_moe_decode_down")
+                                         n, k, H, Ip, down.shape[0], _lib.stream_handle()), "tdist_moe_decode_down")
     return out
 
 
