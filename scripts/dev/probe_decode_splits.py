@@ -23,7 +23,10 @@ def bench(fn, n=20, reps=10):
     return s.elapsed_time(e) / (n * reps) * 1e3
 
 dev, bf, Hq, Hkv, D = "cuda", torch.bfloat16, 32, 8, 128
-for B, L in [(1, 512), (1, 2048), (1, 4096), (1, 8192), (1, 32768), (1, 131072), (2, 2048), (2, 32768), (4, 2048), (4, 8192), (4, 32768), (8, 8192), (16, 4096)]:
+ROWS = [(1, 512), (1, 2048), (1, 4096), (1, 8192), (1, 32768), (1, 131072), (2, 2048), (2, 32768), (4, 2048), (4, 8192), (4, 32768), (8, 8192), (16, 4096)]
+if os.environ.get("ROWS"):                 # e.g. ROWS=1x8192,1x32768
+    ROWS = [tuple(int(v) for v in r.split("x")) for r in os.environ["ROWS"].split(",")]
+for B, L in ROWS:
     per = 2 * B * L * Hkv * D * 2
     copies = max(2, min(160, int(600e6 / per) + 1))          # cold K / V on every call, like a layer of a model
     kcs = [torch.randn(B, L, Hkv, D, device=dev).to(bf) for _ in range(copies)]

@@ -103,6 +103,87 @@ __device__ __forceinline__ float from16(uint16_t v) {
   }
 }
 
+// Merge of fp32 partial rows of 128 values + LSE by ONE wave (the head-parallel merge launch).  Lane (cg = lane & 15,
+// rg = lane >> 4) owns columns 8 cg .. 8 cg + 7 of rows rg, rg + 4, ...: for a chunk of 32 rows every lane issues its
+// eight rows' loads - two 16-byte loads and the LSE each - before it uses any of them, so a merge of up to 32 splits
+// is ONE round trip to memory (the rows were written by the previous launch and sit in HBM or the memory-side
+// cache; the loop that kept eight rows in flight per lane took 11.7 us for 32 heads x 32 splits, most of it
+// waiting).  Lane groups keep running (max, sum, row) states and are merged by two butterfly steps at the end.
+// out_mode as for merge_rows.
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <bool IS_BF16>
+__device__ __forceinline__ void merge_rows_wave_d128(const float* part, long long stride, int n, const int* lens,
+                                                     int lens_stride, void* out, int out_mode, int lane) {
+  constexpr int D = 128;
+  // "no tokens" is a large negative FINITE number in here (an empty split stores -inf, clamped on load): the file is
+  // built with finite-math assumptions, under which a test against infinity may be folded away and inf - inf is a NaN
+  constexpr float NEG = -1.0e30f;
+  const int cg = lane & 15, rg = lane >> 4;
+  float m_run = NEG, l_run = 0.f;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  for (int s0 = 0; s0 < n; s0 += 32) {
+    f32x4_u v[8][2];
+    float l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int s = s0 + rg + 4 * j;
+      const bool valid = s < n && !(lens && lens[(long long)s * lens_stride] <= 0);
+      const float* row = part + (long long)min(s, n - 1) * stride;
+      v[j][0] = *(const f32x4_u*)(row + cg * 8);
+      v[j][1] = *(const f32x4_u*)(row + cg * 8 + 4);
+      l[j] = valid ? fmaxf(row[D], NEG) : NEG;
+    }
+    float m_new = m_run;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m_new = fmaxf(m_new, l[j]);
+    const float alpha = __expf(m_run - m_new);
+    l_run *= alpha;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] *= alpha;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float w = l[j] <= NEG ? 0.f : __expf(l[j] - m_new);
+      l_run += w;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += w != 0.f ? w * v[j][k >> 2][k & 3] : 0.f;   // (an unused row may hold anything)
+    }
+    m_run = m_new;
+  }
+#pragma unroll
+  for (int off = 16; off <= 32; off <<= 1) {
+    const float m_o = __shfl_xor(m_run, off), l_o = __shfl_xor(l_run, off);
+    const float m_new = fmaxf(m_run, m_o);
+    const float a = __expf(m_run - m_new), b = __expf(m_o - m_new);
+    l_run = l_run * a + l_o * b;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = acc[k] * a + __shfl_xor(acc[k], off) * b;
+    m_run = m_new;
+  }
+  const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+  if (rg == 0) {
+    if (out_mode == 2) {
+      float* o = (float*)out + cg * 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = acc[k] * inv;
+    } else {
+      uint16_t* o = (uint16_t*)out + cg * 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = to16<IS_BF16>(acc[k] * inv);
+    }
+  }
+  if (out_mode >= 2 && lane == 0) {
+    const float lse = l_run > 0.f ? m_run + __logf(l_run) : -INFINITY;
+    if (out_mode == 2) {
+      ((float*)out)[D] = lse;
+    } else {
+      ((uint16_t*)out)[D] = to16<IS_BF16>(lse);
+    }
+  }
+}
+
 // out_mode: 1 = 16-bit row, 2 = fp32 row + LSE at column D, 3 = 16-bit row + LSE at column D.
 // P16: the partial rows are in the 16-bit type instead of fp32.
 template <bool IS_BF16, bool P16 = false>
@@ -336,7 +417,7 @@ __device__ __forceinline__ int decode_split_body(const DecodeArgs& a, const int 
   }
   int nsplit = a.splits;
   if (a.adaptive) {
-    nsplit = min(nsplit, max(1, (int)(__builtin_sqrtf((float)kv_len * (a.fused ? 1.f / 32.f : 1.f / 16.f)) + 0.5f)));
+    nsplit = min(nsplit, max(1, (int)(__builtin_sqrtf((float)kv_len * (1.f / 16.f)) + 0.5f)));
     if (!a.fused) nsplit = min(nsplit, max(1, kv_len >> 7));
     if (a.fused && z >= nsplit) return nsplit;
   }
@@ -396,6 +477,22 @@ __device__ __forceinline__ int decode_split_body(const DecodeArgs& a, const int 
     const int pi = n0u / a.page_size;
     return (long long)table[pi] * a.page_size + (n0u - pi * a.page_size);
   };
+  // Pages shorter than a block: the lanes look their pages up one by one.  The split's share of the page table
+  // ((end - start) / page_size entries) is staged into LDS once - the accumulator area, unused until the final merge
+  // - so the look-up in front of every K / V load is an LDS read instead of a dependent trip through the vector L1.
+  int* s_pages = (int*)s_acc;
+  const int pi0 = a.page_shift >= 0 ? (start >> a.page_shift) : start / a.page_size;
+  const int pi1 = end > start ? (a.page_shift >= 0 ? ((end - 1) >> a.page_shift) : (end - 1) / a.page_size) : pi0 - 1;
+  const bool lds_pages = !one_page && pi1 >= pi0 && pi1 - pi0 + 1 <= 64 * D;
+  if (lds_pages) {
+    for (int i = threadIdx.x; i <= pi1 - pi0; i += blockDim.x) s_pages[i] = table[pi0 + i];
+    __syncthreads();
+  }
+  auto slot_lookup = [&](int tok) -> long long {
+    if (!lds_pages) return slot_of(a, table, tok);
+    const int pi = a.page_shift >= 0 ? (tok >> a.page_shift) : tok / a.page_size;
+    return (long long)s_pages[pi - pi0] * a.page_size + (tok - pi * a.page_size);
+  };
   // One 32-token block of K and V in registers (16 x 16 bytes per lane for D = 128).
   struct KVBlock {
     uint4 k[2][KS];
@@ -404,7 +501,7 @@ __device__ __forceinline__ int decode_split_body(const DecodeArgs& a, const int 
   auto load_block = [&](int n0, long long slot0, KVBlock& r) {
     const int n0c = min(n0, n0_cap);
     auto slot_in_block = [&](int tok) -> long long {      // tok in [n0c, n0c + 32), already clamped to tok_cap
-      return one_page ? slot0 + (tok - n0c) : slot_of(a, table, tok);
+      return one_page ? slot0 + (tok - n0c) : slot_lookup(tok);
     };
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
@@ -453,7 +550,7 @@ __device__ __forceinline__ int decode_split_body(const DecodeArgs& a, const int 
           }
         // append to the cache for the steps to come (one head block does it; a full cache drops the token)
         if (hblk == 0 && last < a.max_slots) {
-          const long long slot = one_page ? slot0 + rel : slot_of(a, table, last);
+          const long long slot = one_page ? slot0 + rel : slot_lookup(last);
           if (li == 0) {
             uint16_t* kd = const_cast<uint16_t*>(a.k_cache) + slot * a.k_stride_slot + (long long)kvh * a.k_stride_h + lg * 8;
 #pragma unroll
@@ -541,6 +638,7 @@ __device__ __forceinline__ int decode_split_body(const DecodeArgs& a, const int 
   }
 
   // ---- merge the four waves: lane (head li, group lg) holds dv = NDV * (4 lg + i) + j
+  if (lds_pages) __syncthreads();        // (the page list shares the accumulator area: every wave is done with it)
   l_run += __shfl_xor(l_run, 16);
   l_run += __shfl_xor(l_run, 32);
   if (lg == 0) {

@@ -20,6 +20,8 @@
 //     states are merged through LDS once at the end.
 //   * "fused" launches merge the splits in the last workgroup to finish a (batch, head block)
 //     (atomic ticket), which replaces the reference's grid barrier + second phase.
+#include <cstdlib>
+
 #include "tdist/common.hpp"
 #include "tdist/flash_decode_device.hpp"
 #include "tdist/gemm_gfx950.hpp"
@@ -28,8 +30,11 @@ namespace {
 
 using namespace tdist::fdec;
 
-template <bool IS_BF16, int D, bool PREP = false>
-__global__ __launch_bounds__(256) void decode_split_kernel(DecodeArgs a) {
+// LAT: the latency form for launches of at most two workgroups per CU (long-context decode of a few sequences cut
+// into many splits) - the single-register-set loop under a 256-register cap, so that two workgroups share a CU and
+// twice as many loads are in flight; the throughput form keeps the second register set and a CU to itself.
+template <bool IS_BF16, int D, bool PREP = false, bool LAT = false>
+__global__ __launch_bounds__(256, (LAT ? 2 : 1)) void decode_split_kernel(DecodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int s_last;
   const int b = blockIdx.x;
@@ -40,7 +45,7 @@ __global__ __launch_bounds__(256) void decode_split_kernel(DecodeArgs a) {
   const int hblk = blockIdx.y - kvh * hblocks;
   const int h0 = kvh * group + hblk * 16;
   const int valid_h = min(16, group - hblk * 16);
-  const int nsplit = decode_split_body<IS_BF16, D, true, PREP>(a, b, (int)blockIdx.y, (int)blockIdx.z, smem);
+  const int nsplit = decode_split_body<IS_BF16, D, !LAT, PREP>(a, b, (int)blockIdx.y, (int)blockIdx.z, smem);
 
   if (!a.fused || (a.fused == 1 && nsplit == 1) || (int)blockIdx.z >= nsplit) return;
   if (a.p16) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // 16-bit rows went out as plain stores
@@ -63,6 +68,18 @@ __global__ __launch_bounds__(256) void decode_split_kernel(DecodeArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
+  // head_dim 128, fp32 rows: one wave per head, every row of the head loaded in one round trip
+  if constexpr (D == 128) {
+    if (!a.p16) {
+      for (int h = wave; h < valid_h; h += 4) {
+        const long long poff = b * a.p_stride_b + (long long)(h0 + h) * a.p_stride_h;
+        char* o = (char*)a.out + (b * a.o_stride_b + (long long)(h0 + h) * a.o_stride_h) * (a.fused == 2 ? 4 : 2);
+        merge_rows_wave_d128<IS_BF16>((const float*)a.partial + poff, a.p_stride_s, nsplit, nullptr, 0, o, a.fused,
+                                      (int)(threadIdx.x & 63));
+      }
+      return;
+    }
+  }
   // 16 threads per head, all heads of the block at once
   {
     const int h = threadIdx.x >> 4, sub = threadIdx.x & 15;
@@ -88,6 +105,13 @@ __global__ __launch_bounds__(64) void decode_combine_kernel(const void* part, lo
   const int b = blockIdx.x, h = blockIdx.y;
   const char* p = (const char*)part + (b * p_stride_b + h * p_stride_h) * (P16 ? 2 : 4);
   char* o = (char*)out + (b * o_stride_b + h * o_stride_h) * (out_mode == 2 ? 4 : 2);
+  if constexpr (!P16) {
+    if (D == 128) {
+      merge_rows_wave_d128<IS_BF16>((const float*)p, p_stride_n, n, lens ? lens + b : nullptr, lens_stride, o, out_mode,
+                                    (int)threadIdx.x);
+      return;
+    }
+  }
   merge_rows<IS_BF16, P16>(p, p_stride_n, n, D, lens ? lens + b : nullptr, lens_stride, o, out_mode, threadIdx.x, 64);
 }
 
@@ -98,14 +122,36 @@ hipError_t launch_split(const DecodeArgs& a, int batch, hipStream_t st) {
   const size_t lds = (128 + 64 * D) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    const hipError_t e = hipFuncSetAttribute((const void*)decode_split_kernel<IS_BF16, D, PREP>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)decode_split_kernel<IS_BF16, D, PREP, false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    if constexpr (D <= 128) {
+      e = hipFuncSetAttribute((const void*)decode_split_kernel<IS_BF16, D, PREP, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
     attr_done = true;
   }
-  hipLaunchKernelGGL((decode_split_kernel<IS_BF16, D, PREP>), dim3(batch, a.kv_heads * hblocks, a.splits), dim3(256),
-                     lds, st, a);
+  const dim3 grid(batch, a.kv_heads * hblocks, a.splits);
+  static const int lat_knob = getenv("TDIST_DECODE_LAT") ? atoi(getenv("TDIST_DECODE_LAT")) : -1;    // tuning knob
+  bool lat = !a.deep;
+  if (lat_knob == 0 || lat_knob == 1) lat = lat_knob == 1 && !a.deep;
+  if constexpr (D <= 128) {
+    if (lat) {
+      hipLaunchKernelGGL((decode_split_kernel<IS_BF16, D, PREP, true>), grid, dim3(256), lds, st, a);
+      return hipGetLastError();
+    }
+  }
+  hipLaunchKernelGGL((decode_split_kernel<IS_BF16, D, PREP, false>), grid, dim3(256), lds, st, a);
   return hipGetLastError();
+}
+
+// Two register sets (the loads of block i + 1 issued before block i is multiplied) pay once a CU holds more than one
+// round of workgroups; TDIST_DECODE_DEEP = 0 / 1 forces the choice (tuning knob).
+int deep_choice(long long workgroups, int num_cus) {
+  static const int forced = getenv("TDIST_DECODE_DEEP") ? atoi(getenv("TDIST_DECODE_DEEP")) : -1;
+  if (forced == 0 || forced == 1) return forced;
+  return workgroups > 2ll * num_cus ? 1 : 0;
 }
 
 int num_cus_cached() {
@@ -160,7 +206,7 @@ TDIST_API int tdist_flash_decode_split(const void* q, const void* k_cache, const
   a.sm_scale = sm_scale, a.soft_cap = soft_cap;
   {
     const int hblocks = (q_heads / kv_heads + 15) / 16;
-    a.deep = (long long)batch * kv_heads * hblocks * splits > 2ll * num_cus_cached() ? 1 : 0;
+    a.deep = deep_choice((long long)batch * kv_heads * hblocks * splits, num_cus_cached());
   }
   hipStream_t st = (hipStream_t)stream;
   const bool bf = dtype == 0;
@@ -210,7 +256,7 @@ TDIST_API int tdist_flash_decode_prep(const void* qkv, long long qkv_stride, con
   a.page_shift = (max_len & (max_len - 1)) == 0 ? __builtin_ctzll(max_len) : -1;
   a.q_heads = q_heads, a.kv_heads = kv_heads, a.splits = splits, a.fused = fused, a.p16 = 0;
   a.sm_scale = sm_scale, a.soft_cap = 0.f;
-  a.deep = (long long)batch * kv_heads * ((q_heads / kv_heads + 15) / 16) * splits > 2ll * num_cus_cached() ? 1 : 0;
+  a.deep = deep_choice((long long)batch * kv_heads * ((q_heads / kv_heads + 15) / 16) * splits, num_cus_cached());
   a.qkv = (const uint16_t*)qkv, a.qkv_stride = qkv_stride;
   a.q_w = (const uint16_t*)q_w, a.k_w = (const uint16_t*)k_w, a.q_eps = q_eps, a.k_eps = k_eps;
   a.pos = pos, a.cos_t = cos_t, a.sin_t = sin_t, a.kv_offset = kv_offset, a.total_out = total_out, a.max_slots = max_len;

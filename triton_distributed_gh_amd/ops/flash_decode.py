@@ -36,7 +36,7 @@ def _tickets(device, n: int) -> torch.Tensor:
 
 
 def auto_kv_splits(batch: int, q_heads: int, kv_heads: int, max_kv_len: int, num_cus: int = 256,
-                   fused: bool = False) -> int:
+                   fused: bool = False, page_size: int = 0) -> int:
     """Number of KV splits of a decode launch (the grid; with an automatic count every sequence then uses as many
     of them as its own length calls for, see ``DecodeArgs::adaptive``).
 
@@ -46,19 +46,27 @@ def auto_kv_splits(batch: int, q_heads: int, kv_heads: int, max_kv_len: int, num
 
     * two launches (split kernel, then a merge kernel that is parallel over heads): s ~ sqrt(L / 16), at least 128
       tokens per split, at most 32 splits - batch 1: 15.2 us at 2048 tokens (16 splits; rule: 11), 18.1 at 4096
-      (16; 20.2 at 32), 23.3 at 8192 (16; 24.5 at 32; rule: 23), 43.6 at 32768 (32);
-    * ``fused`` (one launch; the last workgroup of a (sequence, head block) merges its splits): streaming costs
-      ~ L / s and the merge ~ s, optimum s ~ sqrt(L / 32) - batch 1: 17.0 us at 2048 (8 splits), 22.1 at 4096 (11),
-      54.1 at 32768 (32).  The two-launch form is ahead at every shape with fewer than ~64 (sequence, kv head) pairs
-      once the launches sit in a HIP graph."""
+      (16; 20.2 at 32), 23.3 at 8192 (16; 24.5 at 32; rule: 23), 43.6 at 32768 (32) - with the merge launch that
+      loads all rows of a head in one round trip these became 17.0 at 8192 and 36.5 at 32768;
+    * ``fused`` (one launch; the last workgroup of a (sequence, head block) merges its splits, one wave per head
+      with every row in flight at once): the same rule - batch 1: 11.7 us at 2048 (16 splits), 17.9 at 8192 (24),
+      36.6 at 32768 (32), 109.9 at 131072 (32); level with the two-launch form at every measured shape.
+
+    Up to two rounds of workgroups are allowed (batch 16 x 4096: 60.6 us with 4 splits = 512 workgroups against 68.5
+    with 2; batch 4 x 8192: 33.8 with 16 against 35.1 with 8).
+
+    Pages shorter than a 32-token block (``page_size`` 1 - 16) take the same counts: the kernel stages its split's
+    slice of the page table in LDS, which brought them within 3 % of whole-sequence pages (batch 1, 131072 tokens:
+    115 us at page 16, 119 at page 1, 112 with one page per sequence; 245 / 253 us before)."""
     group = q_heads // kv_heads
     base = batch * kv_heads * ((group + 15) // 16)
     one_round = max(1, num_cus // base)
-    if fused:
-        want = max(1, int(round(math.sqrt(max_kv_len / 32.0))))
-        return int(max(1, min(want, one_round, max(1, max_kv_len // 64), 64)))
+    # two rounds' worth of workgroups at most: the latency form of the kernel (150 registers) keeps two per CU resident
+    bound = 2 * one_round
     want = max(1, int(round(math.sqrt(max_kv_len / 16.0))))
-    return int(max(1, min(want, one_round, max(1, max_kv_len // 128), 32)))
+    if fused:
+        return int(max(1, min(want, bound, max(1, max_kv_len // 64), 32)))
+    return int(max(1, min(want, bound, max(1, max_kv_len // 128), 32)))
 
 
 def _dt(q: torch.Tensor) -> int:
@@ -133,7 +141,8 @@ def _splits(q, k_cache, block_table, kv_split, fused=False):
     if forced > 0:
         return forced
     batch, q_heads, _ = q.shape
-    return auto_kv_splits(batch, q_heads, k_cache.shape[2], block_table.shape[1] * k_cache.shape[1], fused=fused)
+    return auto_kv_splits(batch, q_heads, k_cache.shape[2], block_table.shape[1] * k_cache.shape[1], fused=fused,
+                          page_size=k_cache.shape[1])
 
 
 def _splits_forced(kv_split) -> bool:

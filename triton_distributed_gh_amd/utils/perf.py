@@ -34,6 +34,32 @@ def perf_func(func: Callable, iters: int, warmup_iters: int):
     return out, (time.perf_counter() - t0) * 1e3 / max(iters, 1)
 
 
+def graph_bench(fn: Callable, n: int = 20, reps: int = 10) -> float:
+    """Microseconds per call of ``fn`` with ``n`` calls captured in one HIP graph: kernel time without the host's
+    launch cost (``fn`` may rotate over input copies through a counter of its own to keep its operands cold)."""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        fn()
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(n):
+                fn()
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        g.replay()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / (n * reps) * 1e3
+
+
 def sleep_async(duration_ms: float) -> None:
     """Queue a busy kernel on the current stream so the host can run ahead of the device."""
     if torch.cuda.is_available():
