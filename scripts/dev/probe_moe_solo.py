@@ -33,6 +33,22 @@ def timed(fn, prep):
     return ts[len(ts) // 2], ts[0]
 
 
+def burst(fn, prep, n=10):
+    """n calls enqueued back to back (what a model's layer loop does): time per call without the host's share."""
+    for _ in range(2):
+        prep(); fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        prep(); fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / n
+
+
+ONLY = os.environ.get("ONLY", "")          # "ag" / "rs": one of the two ops (per-op counter runs)
+
 # ---- AG + grouped GEMM (w1: N = ffn, K = hidden) ----
 ctxs = vc.collective(lambda r, env: create_ag_group_gemm_context(M, ffn // w, hidden, E, topk, dt, r, w, env=env))
 c = ctxs[0]
@@ -43,10 +59,15 @@ def prep_ag():
     ag = c.ag
     ag.flags[ag.call_count & 1][0].fill_(ag.call_count % EPOCH_MOD + 1)
 
-med, mn = timed(lambda: ag_group_gemm(A, B, c, ids), prep_ag)
 fl = 2.0 * M * topk * (ffn // w) * hidden
-print(f"ag_group_gemm  solo rank: median {med:.1f} us  min {mn:.1f} us  ({fl / med / 1e6:.0f} TFLOP/s)", flush=True)
-c.check_error()
+if ONLY in ("", "ag"):
+    med, mn = timed(lambda: ag_group_gemm(A, B, c, ids), prep_ag)
+    print(f"ag_group_gemm  solo rank: median {med:.1f} us  min {mn:.1f} us  ({fl / med / 1e6:.0f} TFLOP/s); "
+          f"back to back {burst(lambda: ag_group_gemm(A, B, c, ids), prep_ag):.1f} us per call", flush=True)
+    c.check_error()
+if ONLY == "ag":
+    vc.close()
+    sys.exit(0)
 
 # ---- grouped GEMM + topk reduce + RS (w2: N = hidden, K = ffn / w) ----
 rs = vc.collective(lambda r, env: create_moe_rs_context(r, w, w, M, hidden, E, topk, dt, env=env))
@@ -67,7 +88,8 @@ for nck, rs_cus in sweep:
     if rs_cus:
         autotuner._ACTIVE["moe_rs.RS_CUS"] = rs_cus
     med, mn = timed(lambda: run_moe_reduce_rs(X, W2, ids, rw, c2, n_chunks=nck), prep_rs)
+    bb = burst(lambda: run_moe_reduce_rs(X, W2, ids, rw, c2, n_chunks=nck), prep_rs)
     print(f"moe_reduce_rs  solo rank, n_chunks {nck} (reduce keeps {rs_cus} CUs): median {med:.1f} us  min {mn:.1f} us  "
-          f"({fl / med / 1e6:.0f} TFLOP/s)", flush=True)
+          f"({fl / med / 1e6:.0f} TFLOP/s); back to back {bb:.1f} us per call", flush=True)
     c2.check_error()
 vc.close()

@@ -85,7 +85,10 @@ def test_swizzle_model_matches_native_align_order():
         # native block index b enumerates experts, then tiles: rebuild it from the model's (expert, tile)
         per_e = [(c + 255) // 256 for c in (sum(col) for col in zip(*counts))]
         base = [sum(per_e[:e]) for e in range(E)]
-        assert [base[t.expert_id] + t.tiled_m for t in tiles] == idx.order[:nb].tolist()
+        # the native order walks eight contiguous ranges of blocks (one per XCD), each in the model's arrival order
+        model = [base[t.expert_id] + t.tiled_m for t in tiles]
+        want = [b for q in range(8) for b in model if q * nb // 8 <= b < (q + 1) * nb // 8]
+        assert want == idx.order[:nb].tolist()
         for t in tiles:
             b = base[t.expert_id] + t.tiled_m
             assert [t.segment_start, t.segment_end] == idx.seg_range[b].tolist()

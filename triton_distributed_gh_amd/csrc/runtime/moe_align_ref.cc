@@ -63,9 +63,13 @@ TDH_API int tdh_moe_align_reference(const int32_t* topk_ids, int n, int num_expe
     for (int s = lo; s <= hi; ++s) st = std::max(st, (s - rank + world) % world);
     stage[b] = st;
   }
+  // eight contiguous ranges of blocks (one per XCD of the grouped GEMM), each in arrival order
   std::vector<int> ord(nblocks);
   std::iota(ord.begin(), ord.end(), 0);
-  std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return stage[a] < stage[b]; });
+  for (int q = 0; q < 8; ++q) {
+    const int64_t lo = (int64_t)q * nblocks / 8, hi = (int64_t)(q + 1) * nblocks / 8;
+    std::stable_sort(ord.begin() + lo, ord.begin() + hi, [&](int a, int b) { return stage[a] < stage[b]; });
+  }
   for (int b = 0; b < nblocks; ++b) order[b] = ord[b];
   meta[0] = nblocks;
   meta[1] = (int32_t)pad_off[num_experts];

@@ -60,9 +60,8 @@ def auto_kv_splits(batch: int, q_heads: int, kv_heads: int, max_kv_len: int, num
     115 us at page 16, 119 at page 1, 112 with one page per sequence; 245 / 253 us before)."""
     group = q_heads // kv_heads
     base = batch * kv_heads * ((group + 15) // 16)
-    one_round = max(1, num_cus // base)
     # two rounds' worth of workgroups at most: the latency form of the kernel (150 registers) keeps two per CU resident
-    bound = 2 * one_round
+    bound = max(1, (2 * num_cus) // base)
     want = max(1, int(round(math.sqrt(max_kv_len / 16.0))))
     if fused:
         return int(max(1, min(want, bound, max(1, max_kv_len // 64), 32)))

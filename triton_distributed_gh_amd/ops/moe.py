@@ -93,7 +93,12 @@ def _align_cpu(ids, E, w, rank, tpr, cap):
         seg[b, 0], seg[b, 1] = int(s.min()), int(s.max())
     stage = [max((s - rank + w) % w for s in range(int(seg[b, 0]), int(seg[b, 1]) + 1)) for b in range(nblocks)]
     ordv = torch.zeros(nb, dtype=torch.int32)
-    ordv[:nblocks] = torch.tensor(sorted(range(nblocks), key=lambda b: (stage[b], b)), dtype=torch.int32)
+    # eight contiguous ranges of blocks (one per XCD), each walked in arrival order
+    perm = []
+    for q in range(8):
+        lo, hi = q * nblocks // 8, (q + 1) * nblocks // 8
+        perm += sorted(range(lo, hi), key=lambda b: (stage[b], b))
+    ordv[:nblocks] = torch.tensor(perm, dtype=torch.int32)
     meta = torch.zeros(2 + E, dtype=torch.int32)
     meta[0], meta[1] = nblocks, int(padded.sum())
     meta[2:] = counts.int()
