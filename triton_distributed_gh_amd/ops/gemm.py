@@ -95,11 +95,10 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
         torch.matmul(a, b.t(), out=out)
         return out
     # More than MID_MAX_M rows but fewer 256x256 tiles than ~60 % of the CUs (prefill of a mid-sized prompt
-    # against a narrow projection: 2048 x 4096 = 128 tiles for 256 CUs): no kernel of this package fills the
-    # chip there - one item per tile leaves CUs idle, cutting K through parked fp32 tiles (gemm_nt_splitk)
-    # moves 64+ MB of partials, the mid-M kernel re-reads the activations - and the library's 128-wide tiles
-    # are 1.3 - 1.9 x ahead (profiles/gemm_few_tiles_r2.md), so this band of PLAIN GEMMs goes to the library.
-    # ``TDIST_FEW_TILES_GEMM`` = lib (default) | native (256x256 tiles) | mid | splitk.
+    # against a narrow projection: 2048 x 4096 = 128 tiles for 256 CUs): one 256x256 item per tile leaves CUs idle,
+    # cutting K through parked fp32 tiles (gemm_nt_splitk) moves 64+ MB of partials and the mid-M kernel re-reads the
+    # activations (profiles/gemm_few_tiles_r2.md), so this band runs on the tile family's smaller macro-tiles.
+    # ``TDIST_FEW_TILES_GEMM`` = tiles (default) | lib (hipBLASLt) | native (256x256 tiles) | mid | splitk.
     tiles = -(-M // 256) * -(-N // 256)
     if M > 16 and variant == GEMM_VARIANT and tiles < 160 and not force_native and FEW_TILES_GEMM != "native":
         if FEW_TILES_GEMM == "mid":
