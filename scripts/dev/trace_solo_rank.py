@@ -18,7 +18,7 @@ from triton_distributed_gh_amd.ops.gemm import gemm_nt  # noqa: E402
 from triton_distributed_gh_amd.ops.gemm_rs import create_gemm_rs_intra_node_context, gemm_rs_intra_node  # noqa: E402
 from triton_distributed_gh_amd.utils.testing import VirtualCluster  # noqa: E402
 
-M, N, K = 4096, 8192, 8192
+M, N, K = 4096, int(os.environ.get("TRACE_N", 8192)), 8192      # TRACE_N: another width (N // w per rank)
 EPOCH_MOD = 4093
 CAP = 160
 NAMES = {1: "start", 2: "ticket", 3: "wait", 4: "mainloop", 5: "epilogue", 6: "other item", 7: "loop exit"}
@@ -50,6 +50,14 @@ def analyse(buf, title):
     exits = sorted((end - e[-1][2]) / 100.0 for e in rows)
     print(f"   start skew: median {starts[len(starts) // 2]:.1f} us, max {starts[-1]:.1f} us; "
           f"idle before the end: median {exits[len(exits) // 2]:.1f} us, max {exits[-1]:.1f} us")
+    args = defaultdict(list)            # tags >= 8 carry a duration (100 MHz ticks) as their argument
+    for e in rows:
+        for tag, arg, _ in e:
+            if tag >= 8:
+                args[tag].append(arg / 100.0)
+    for tag in sorted(args):
+        v = sorted(args[tag])
+        print(f"   arg of tag {tag}: n={len(v)} mean {sum(v) / len(v):.2f} us  median {v[len(v) // 2]:.2f}  max {v[-1]:.2f}")
     for k, v in seg.items():
         v.sort()
         print(f"   -> {k:10s} n={len(v):5d} mean {sum(v) / len(v):8.2f} us  median {v[len(v) // 2]:8.2f}  "

@@ -117,14 +117,15 @@ __device__ __forceinline__ int wait(const T* barrier_ptrs, int num_barriers, int
   int failed = 0;
   for (int i = threadIdx.x; i < num_barriers; i += blockDim.x) {
     // the common case - the flag is already there - costs one load
-    const T v = (scope == SCOPE_SYS) ? load_relaxed_system(barrier_ptrs + i) : load_relaxed_agent(barrier_ptrs + i);
+    const T* fp = barrier_ptrs + i;
+    const T v = (scope == SCOPE_SYS) ? load_relaxed_system(fp) : load_relaxed_agent(fp);
     if (v == wait_value) continue;
     // Once any wait of this launch has timed out the error word is sticky and later waits give up
     // at once, so a lost peer costs one spin budget, not one per tile.
     const bool dead = err_word && load_relaxed_agent(err_word) != 0;
     if (dead) {
       failed = 1;
-    } else if (!spin_until_eq(barrier_ptrs + i, wait_value, scope)) {
+    } else if (!spin_until_eq(fp, wait_value, scope)) {
       failed = 1;
       if (err_word) atomicOr(err_word, 1);
     }

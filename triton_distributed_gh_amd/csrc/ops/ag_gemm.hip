@@ -74,6 +74,7 @@ struct AgGemmParams {
   int qn;                    // tile queues: qn column bands x (8 / qn) row-block residues
   int race_debug;            // tdist/race_debug.hpp
   int push_store;            // producer stores: 0 = write-through system scope, 1 = write-through agent scope, 2 = plain + release fence
+  int acquire_mode;          // consumer's fence behind a flag: 0 = system-scope acquire, 1 = agent scope, 2 = none (measurement knob)
   WgTrace trace;             // tdist/wg_trace.hpp (off unless the host armed a sink)
   // Device-side call numbering (tdist/call_state.hpp).  When `state` is set, ws / flags / epoch above
   // are ignored by the host and resolved on the device from the call number: the launch is then the
@@ -211,7 +212,39 @@ __global__ __launch_bounds__(THREADS, 2) void ag_gemm_consumer_kernel(AgGemmPara
       // Consecutive items of a queue mostly share their row block.  Rows this workgroup has waited for
       // before landed before that wait's acquire and do not change within the call: no second wait.
       if (f0 != seen_f0 || f1 != seen_f1) {
-        const int token = wait((const int*)cv.flags + f0, f1 - f0 + 1, SCOPE_SYS, SEM_ACQUIRE, cv.epoch, p.err);
+        int token;
+        if (tr.p) {
+          // traced launch: the three parts of the wait timed separately (flag load, acquire, barrier); the deltas
+          // travel as event arguments (tags 8, 9, 10) so that no trace store sits between the parts
+          const long long ta = (long long)wall_clock64();
+          int bad = 0;
+          if ((int)threadIdx.x < f1 - f0 + 1) {
+            const int* fp = (const int*)cv.flags + f0 + (int)threadIdx.x;
+            if (load_relaxed_system(fp) != cv.epoch && !spin_until_eq(fp, cv.epoch, SCOPE_SYS)) bad = 1;
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          const long long tb = (long long)wall_clock64();
+          if (threadIdx.x < 64) acquire_fence(SCOPE_SYS);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          const long long tc = (long long)wall_clock64();
+          __syncthreads();
+          const long long td = (long long)wall_clock64();
+          token = bad;
+          wg_trace(tr, 8, (int)(tb - ta));
+          wg_trace(tr, 9, (int)(tc - tb));
+          wg_trace(tr, 10, (int)(td - tc));
+        } else if (p.acquire_mode == 0) {
+          token = wait((const int*)cv.flags + f0, f1 - f0 + 1, SCOPE_SYS, SEM_ACQUIRE, cv.epoch, p.err);
+        } else {
+          token = wait((const int*)cv.flags + f0, f1 - f0 + 1, SCOPE_SYS, SEM_RELAXED, cv.epoch, p.err);
+          if (p.acquire_mode == 1) {
+            if (threadIdx.x < 64) {
+              acquire_fence(SCOPE_GPU);
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+          }
+        }
         a_ptr = consume_token(a_ptr, token);
         if (token == 0) {
           seen_f0 = f0;
@@ -393,7 +426,9 @@ static AgPlan plan_ag(int M_per_rank, int world, int N_local, int K16, int consu
       const long long items = tiles * s;
       const long long rounds = (items + consumers - 1) / consumers;
       const double tile_kb = tbm * tbn * 4 / 1024.0;
-      const double fix = s > 1 ? 2500.0 + 20.0 * tile_kb + (s - 1) * 30.0 * tile_kb : 0.0;
+      // (parking and re-reading fp32 tiles while every CU does the same: 19 - 25 us measured for 256 x 256 tiles cut in
+      // two, twice what the plain kernel's model charges)
+      const double fix = s > 1 ? 2500.0 + 40.0 * tile_kb + (s - 1) * 60.0 * tile_kb : 0.0;
       // a straddling walk costs the own rows a pass through the workspace; prefer aligned shapes on a near tie
       const double total = rounds * ((ksteps / s) * gemm::tile_step_ns(mt, nt, items > consumers / 2) + 7000.0) + fix +
                            (straddle ? 3000.0 : 0.0);
@@ -516,16 +551,22 @@ TDIST_API int tdist_ag_gemm_consumer(const tdist::SymmCtx* ctx, const void* a_lo
   p.push_wgs = world > 1 ? push_wgs : 0;
   p.split_k = split_k;
   {
-    // column bands first (B panels are the larger operand to share), row-block residues for the rest
+    // column bands first (B panels are the larger operand to share), row-block residues for the rest.  (Choosing the
+    // split that moves the fewest bytes per XCD - rows + columns - was measured at 4096 x 1024 x 8192: one band of
+    // four column tiles per XCD ran the main loops 10 % slower than four bands.)
     const int npn = (N_local + bn - 1) / bn;
     int qn = 1;
     while (qn < 8 && qn * 2 <= npn) qn *= 2;
+    static const int forced = getenv("TDIST_AG_QN") ? atoi(getenv("TDIST_AG_QN")) : 0;      // tuning knob
+    if ((forced == 1 || forced == 2 || forced == 4 || forced == 8) && forced <= (npn > 1 ? npn : 1)) qn = forced;
     p.qn = qn;
   }
   p.race_debug = race_debug_enabled();
   {
     static const int ps = getenv("TDIST_PUSH_STORE") ? atoi(getenv("TDIST_PUSH_STORE")) : 0;
     p.push_store = ps;
+    static const int am = getenv("TDIST_AG_ACQUIRE") ? atoi(getenv("TDIST_AG_ACQUIRE")) : 0;
+    p.acquire_mode = am;
   }
   p.trace = wg_trace_sink();
   p.scale_a = scale_a;
