@@ -125,7 +125,6 @@ def test_moe_decode_kernels_match_fp32_reference(n, H, I, E, topk):
     wts = torch.rand(n, topk, device=dev) + 0.1
     wts = wts / wts.sum(-1, keepdim=True)
     assert moe_decode_supported(x, gate_up, down, topk)
-    out = moe_decode_fwd(x, ids, wts, gate_up, down)
     ref = torch.zeros(n, H, device=dev)
     for t in range(n):
         for k in range(topk):
@@ -133,7 +132,9 @@ def test_moe_decode_kernels_match_fp32_reference(n, H, I, E, topk):
             gu = gate_up[e].float() @ x[t].float()
             h = (torch.nn.functional.silu(gu[:I].to(bf).float()) * gu[I:].to(bf).float()).to(bf).float()
             ref[t] += wts[t, k] * (down[e].float() @ h)
-    torch.testing.assert_close(out.float(), ref, atol=2e-2 * ref.abs().max().item(), rtol=2e-2)
+    for form in (1, 0):                    # both kernels: vector-ALU form, MFMA form
+        out = moe_decode_fwd(x, ids, wts, gate_up, down, down_form=form, gate_up_form=form)
+        torch.testing.assert_close(out.float(), ref, atol=2e-2 * ref.abs().max().item(), rtol=2e-2)
 
 
 @pytest.mark.parametrize("n,E,k,renorm", [(1, 128, 8, True), (7, 128, 8, False), (33, 8, 2, True), (4, 1000, 10, True),

@@ -393,7 +393,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const uint16_t*
     if constexpr (NORM) {
       return xvalid ? *(const u32x4*)(tbuf + li * trow + (ks * 32 + lg * 8) * 2) : u32x4{0, 0, 0, 0};
     } else {
-      return xvalid ? *(const u32x4*)(xr + ks * 32) : u32x4{0, 0, 0, 0};
+      // (unconditional: rows past M read row M - 1 again and are zeroed - a lane-dependent branch around the load
+      // would split every batch of weight loads)
+      const u32x4 v = *(const u32x4*)(xr + ks * 32);
+      return xvalid ? v : u32x4{0, 0, 0, 0};
     }
   };
   // (Walking K from a per-workgroup rotated start, against power-of-two row strides all starting on
@@ -509,12 +512,238 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const uint16_t*
   }
 }
 
+// Decode GEMM for ONE row on the vector ALUs (bf16): C[1, N] = X[1, K] W[N, K]^T, or with SILU
+// C[1, I] = silu(X Wgate^T) * (X Wup^T) for a gate_up weight [2 I, K].  At one row an MFMA tile is 15/16 padding and
+// its operand layout dictates 64-byte runs per weight row and load instruction; here a wave streams eight weight rows
+// with eight lanes per row, so every load instruction reads eight contiguous 128-byte runs, in batches of eight
+// pieces per lane with the next batch requested before the current one is multiplied (v_dot2_f32_bf16: two products
+// per instruction, no unpacking).  Wave k of NW owns the k-th slice of K of the workgroup's eight (SILU: four gate +
+// four up) rows; the slices are summed through LDS.  Without NORM the activations are read with the weights they
+// meet (L1 / L2 hits).  NORM: the RMSNorm in front of the projection rides along exactly as in
+// gemm_nt_skinny_kernel (h = bf16(X + R), workgroup 0 writes h to Hout, the products use bf16(h * G) staged in LDS and
+// the result is scaled by rsqrt(mean(h^2) + eps)).  Cold weights, one row, MFMA form -> this form: 50 MB 15.7 -> 10.6 us,
+// 101 MB 25.2 -> 18.0, 201 MB with SiLU 39.9 -> 34.0, 1245 MB 224.5 -> 182.0.  (MR = 2 exists for measurements: with
+// two rows the activation loads double and the MFMA form wins.)
+template <int NW, int MR, bool SILU, bool NORM = false>
+__global__ __launch_bounds__(64 * NW) void gemm_nt_dot_kernel(const uint16_t* __restrict__ X,
+                                                              const uint16_t* __restrict__ W,
+                                                              uint16_t* __restrict__ C, int M, int N, int K,
+                                                              long long ldx, long long ldw, long long ldc,
+                                                              const uint16_t* __restrict__ R = nullptr,
+                                                              const uint16_t* __restrict__ G = nullptr,
+                                                              uint16_t* __restrict__ Hout = nullptr, float eps = 0.f) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  using F = Frag<true>;
+  constexpr int U = 8;
+  __shared__ float red[NW * MR * 8];
+  __shared__ float s_ss[MR];
+  extern __shared__ __attribute__((aligned(16))) char tbuf[];     // NORM: [MR][K * 2 + 64] bytes
+  const long long trow = (long long)K * 2 + 64;
+  const int wk = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = lane >> 3, kl = lane & 7;
+  const int col = SILU ? (int)blockIdx.x * 4 + (r & 3) : (int)blockIdx.x * 8 + r;
+  const uint16_t* wr = W + ((SILU ? (long long)(r >> 2) * N : 0ll) + min(col, N - 1)) * ldw;
+  const uint16_t* xr[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) xr[m] = X + (long long)min(m, M - 1) * ldx;
+  const int steps = (K + 63) / 64;
+  const int per = (steps + NW - 1) / NW;
+  const int sb = min(wk * per, steps), se = min(sb + per, steps);
+  u32x4 wa[U], wb[U], xa[MR][U], xb[MR][U];
+  // K is a multiple of 32, so a 16-byte piece is in or out as a whole; a piece past the end of the slice reads the
+  // slice's last piece instead and meets zeros
+  auto ld = [&](u32x4(&w)[U], u32x4(&xv)[MR][U], int s0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = (s0 + u) * 64 + kl * 8;
+      const int kc = min(k, K - 8);
+      w[u] = __builtin_nontemporal_load((const u32x4*)(wr + kc));
+      if constexpr (!NORM) {
+        const bool in = s0 + u < se && k < K;
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+          const u32x4 v = *(const u32x4*)(xr[m] + kc);
+          xv[m][u] = in ? v : u32x4{0, 0, 0, 0};
+        }
+      }
+    }
+  };
+  auto ld_x_lds = [&](u32x4(&xv)[MR][U], int s0) {      // NORM: the activations of a batch, from LDS, at multiply time
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = (s0 + u) * 64 + kl * 8;
+      const bool in = s0 + u < se && k < K;
+      const int kc = min(k, K - 8);
+#pragma unroll
+      for (int m = 0; m < MR; ++m) {
+        const u32x4 v = *(const u32x4*)(tbuf + m * trow + kc * 2);
+        xv[m][u] = in ? v : u32x4{0, 0, 0, 0};
+      }
+    }
+  };
+  auto norm_prepass = [&]() {
+    if constexpr (NORM) {
+      if (threadIdx.x < MR) s_ss[threadIdx.x] = 0.f;
+      __syncthreads();
+      const int nvec = K / 8;
+      for (int row = 0; row < min(M, MR); ++row) {
+        float ss = 0.f;
+        for (int c = threadIdx.x; c < nvec; c += 64 * NW) {
+          const u32x4 xv = *(const u32x4*)(X + (long long)row * ldx + c * 8);
+          const u32x4 gv = *(const u32x4*)(G + c * 8);
+          u32x4 rv = {0, 0, 0, 0}, hb, t;
+          if (R) rv = *(const u32x4*)(R + (long long)row * K + c * 8);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float lo = __builtin_bit_cast(float, xv[i] << 16), hi = __builtin_bit_cast(float, xv[i] & 0xffff0000u);
+            hb[i] = xv[i];
+            if (R) {
+              lo += __builtin_bit_cast(float, rv[i] << 16);
+              hi += __builtin_bit_cast(float, rv[i] & 0xffff0000u);
+              hb[i] = F::pack2(lo, hi);      // the sum rounded to 16 bits is what the norm sees (as the separate kernel)
+              lo = __builtin_bit_cast(float, hb[i] << 16), hi = __builtin_bit_cast(float, hb[i] & 0xffff0000u);
+            }
+            ss += lo * lo + hi * hi;
+            t[i] = F::pack2(lo * __builtin_bit_cast(float, gv[i] << 16), hi * __builtin_bit_cast(float, gv[i] & 0xffff0000u));
+          }
+          *(u32x4*)(tbuf + row * trow + c * 16) = t;
+          if (R && blockIdx.x == 0) *(u32x4*)(Hout + (long long)row * K + c * 8) = hb;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        if (lane == 0) atomicAdd(&s_ss[row], ss);
+      }
+      __syncthreads();
+    }
+  };
+  float acc[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) acc[m] = 0.f;
+  auto mm = [&](const u32x4(&w)[U], const u32x4(&xv)[MR][U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // (through scalars: __builtin_bit_cast applied to a vector ELEMENT expression read element 0 every time)
+        const unsigned wi = w[u][i];
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+          const unsigned xi = xv[m][u][i];
+          acc[m] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, wi), __builtin_bit_cast(bf16x2, xi), acc[m], false);
+        }
+      }
+  };
+  // The norm pre-pass holds workgroup barriers: every wave runs it exactly once, behind its first batch of weight loads.
+  // (One batch ahead, not two: with both batches of a slice requested before the first multiply the kernel ran a
+  // third slower - 1245 MB in 272 instead of 182 us.)
+  if (sb < se) ld(wa, xa, sb);
+  norm_prepass();
+  for (int s0 = sb; s0 < se; s0 += 2 * U) {
+    if (s0 + U < se) ld(wb, xb, s0 + U);
+    if constexpr (NORM) ld_x_lds(xa, s0);
+    mm(wa, xa);
+    if (s0 + 2 * U < se) ld(wa, xa, s0 + 2 * U);
+    if (s0 + U < se) {
+      if constexpr (NORM) ld_x_lds(xb, s0 + U);
+      mm(wb, xb);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    acc[m] += __shfl_xor(acc[m], 1);
+    acc[m] += __shfl_xor(acc[m], 2);
+    acc[m] += __shfl_xor(acc[m], 4);
+    if (kl == 0) red[(wk * MR + m) * 8 + r] = acc[m];
+  }
+  __syncthreads();
+  // thread (m, r) of the first MR * 8 sums the K slices of row r for activation row m
+  if ((int)threadIdx.x < MR * 8) {
+    const int m = threadIdx.x >> 3, rr = threadIdx.x & 7;
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) sum += red[(q * MR + m) * 8 + rr];
+    if constexpr (NORM) sum *= rsqrtf(s_ss[m] / (float)K + eps);
+    if constexpr (SILU) {
+      // rows 0..3 are gate sums, rows 4..7 the up sums of the same columns (four lanes further on); both are
+      // rounded to bf16 first, as the separate kernels do
+      const float up = __shfl_down(sum, 4);
+      const int c = (int)blockIdx.x * 4 + rr;
+      if (rr < 4 && c < N && m < M) {
+        const float gr = (float)(__bf16)sum, ur = (float)(__bf16)up;
+        C[(long long)m * ldc + c] = __builtin_bit_cast(uint16_t, (__bf16)(gr / (1.f + __expf(-gr)) * ur));
+      }
+    } else {
+      const int c = (int)blockIdx.x * 8 + rr;
+      if (c < N && m < M) C[(long long)m * ldc + c] = __builtin_bit_cast(uint16_t, (__bf16)sum);
+    }
+  }
+}
+
+// TDIST_DECODE_DOT=0 keeps one-row decode GEMMs on the MFMA kernel (A/B measurements)
+static bool decode_dot_enabled() {
+  static const bool on = !(getenv("TDIST_DECODE_DOT") && atoi(getenv("TDIST_DECODE_DOT")) == 0);
+  return on;
+}
+
+// Launch of gemm_nt_dot_kernel (bf16).  nw: K slices per workgroup, 0 = four (the best of 1 / 2 / 4 / 8 on every
+// decode shape of a dense model; a wave wants at least one batch of loads, so short K uses fewer).
+template <int MR, bool SILU, bool NORM>
+static void launch_dot(const uint16_t* X, const uint16_t* W, uint16_t* C, int M, int N, int K, long long ldx,
+                       long long ldw, long long ldc, int nw, hipStream_t s, const uint16_t* R = nullptr,
+                       const uint16_t* G = nullptr, uint16_t* Hout = nullptr, float eps = 0.f) {
+  const int cb = SILU ? 4 : 8;
+  const dim3 grid((N + cb - 1) / cb);
+  if (nw <= 0) nw = 4;
+  while (nw > 1 && K < 64 * 8 * nw) nw >>= 1;
+  const size_t lds = NORM ? (size_t)MR * ((size_t)K * 2 + 64) : 0;
+  if (nw == 1)
+    hipLaunchKernelGGL((gemm_nt_dot_kernel<1, MR, SILU, NORM>), grid, dim3(64), lds, s, X, W, C, M, N, K, ldx, ldw, ldc, R, G, Hout, eps);
+  else if (nw == 2)
+    hipLaunchKernelGGL((gemm_nt_dot_kernel<2, MR, SILU, NORM>), grid, dim3(128), lds, s, X, W, C, M, N, K, ldx, ldw, ldc, R, G, Hout, eps);
+  else if (nw == 4)
+    hipLaunchKernelGGL((gemm_nt_dot_kernel<4, MR, SILU, NORM>), grid, dim3(256), lds, s, X, W, C, M, N, K, ldx, ldw, ldc, R, G, Hout, eps);
+  else
+    hipLaunchKernelGGL((gemm_nt_dot_kernel<8, MR, SILU, NORM>), grid, dim3(512), lds, s, X, W, C, M, N, K, ldx, ldw, ldc, R, G, Hout, eps);
+}
+
+// C[M, N] = X W^T (silu == 0) or C[M, N] = silu(X W[0:N]^T) * (X W[N:2N]^T) (silu != 0, W [2 N, K]) for M <= 2, bf16,
+// on the vector ALUs (gemm_nt_dot_kernel; the entry the probes time - the library's own decode entry points choose
+// this kernel at one row).  nw: K slices per workgroup (1 / 2 / 4 / 8; 0 = default).
+TDIST_API int tdist_gemm_nt_dot(const void* X, const void* W, void* C, int M, int N, int K, long long ldx, long long ldw,
+                                long long ldc, int silu, int nw, void* stream) {
+  TDIST_REQUIRE(M > 0 && M <= 2 && N > 0, "M must be 1 or 2");
+  TDIST_REQUIRE(K >= 128 && K % 32 == 0, "K must be a multiple of 32 and >= 128");
+  TDIST_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0, "row strides must keep the vector alignment");
+  TDIST_REQUIRE((((uintptr_t)X | (uintptr_t)W) & 15) == 0 && C, "operands must be aligned");
+  TDIST_REQUIRE(nw == 0 || nw == 1 || nw == 2 || nw == 4 || nw == 8, "nw must be 0, 1, 2, 4 or 8");
+  const uint16_t *x = (const uint16_t*)X, *w = (const uint16_t*)W;
+  uint16_t* c = (uint16_t*)C;
+  hipStream_t s = (hipStream_t)stream;
+  if (silu) {
+    if (M == 1) launch_dot<1, true, false>(x, w, c, M, N, K, ldx, ldw, ldc, nw, s);
+    else launch_dot<2, true, false>(x, w, c, M, N, K, ldx, ldw, ldc, nw, s);
+  } else {
+    if (M == 1) launch_dot<1, false, false>(x, w, c, M, N, K, ldx, ldw, ldc, nw, s);
+    else launch_dot<2, false, false>(x, w, c, M, N, K, ldx, ldw, ldc, nw, s);
+  }
+  TDIST_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 template <bool IS_BF16>
 static void launch_skinny(const void* A, const void* B, void* C, int M, int N, int K, long long lda, long long ldb,
                           long long ldc, hipStream_t s) {
   // Column-block size (measured on MI355X, K 2048..12288): with 1-4 tokens the activation loads
   // are negligible and small blocks (more workgroups) win; with more tokens sharing one activation
   // fragment between 2-4 column groups pays as soon as the grid still has a few hundred workgroups.
+  if constexpr (IS_BF16) {
+    // one row: the vector-ALU form (gemm_nt_dot_kernel) streams the weights 18 - 32 % faster
+    if (M == 1 && decode_dot_enabled() && ((uintptr_t)C & 1) == 0) {
+      launch_dot<1, false, false>((const uint16_t*)A, (const uint16_t*)B, (uint16_t*)C, M, N, K, lda, ldb, ldc, 0, s);
+      return;
+    }
+  }
   int bn;
   if (M <= 4)
     bn = N >= 16384 ? 32 : 16;
@@ -553,6 +782,14 @@ TDIST_API int tdist_gemm_nt_norm(const void* X, const void* R, const void* G, fl
   hipStream_t s = (hipStream_t)stream;
   const long long lds = (long long)M * ((long long)K * 2 + 64);       // normalised activations of the M rows
   TDIST_REQUIRE(lds <= 48 * 1024, "fused norm: M x K too large for the activation buffer in LDS");
+  if (M == 1 && decode_dot_enabled()) {
+    if (silu)
+      launch_dot<1, true, true>(x, w, c, M, N, K, ldx, ldw, ldc, 0, s, r, g, h, eps);
+    else
+      launch_dot<1, false, true>(x, w, c, M, N, K, ldx, ldw, ldc, 0, s, r, g, h, eps);
+    TDIST_HIP_TRY(hipGetLastError());
+    return 0;
+  }
   if (silu) {
     hipLaunchKernelGGL((gemm_nt_skinny_kernel<true, 2, 4, true, true>), dim3((N + 15) / 16), dim3(256), (size_t)lds, s, x, w,
                        c, M, N, K, ldx, ldw, ldc, r, g, h, eps);
@@ -649,30 +886,176 @@ __global__ __launch_bounds__(64 * NW) void moe_decode_down_kernel(const uint16_t
   }
 }
 
+// The same reduction with one workgroup per EIGHT output columns and token: twice as many workgroups pull the weights
+// (H / 16 per token are 128 for H = 2048, half the CUs at one token).  An MFMA tile is 16 columns wide, so this form
+// multiplies on the vector ALUs instead - the work is 2 flops per weight byte, nowhere near a limit.  Wave k streams the eight rows of expert ids[t, k]: eight lanes per row, each lane 16 bytes of
+// every 128-byte run of the row (a wave instruction reads eight contiguous 128-byte runs), all of a row's loads in
+// flight in batches of eight per lane with the next batch requested before the current one is multiplied.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void moe_decode_down_narrow_kernel(const uint16_t* __restrict__ hbuf,
+                                                                         const int* __restrict__ ids,
+                                                                         const float* __restrict__ wts,
+                                                                         const uint16_t* __restrict__ down,
+                                                                         uint16_t* __restrict__ out, int topk, int H,
+                                                                         int Ip, int E) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  constexpr int CB = 8, U = 6;
+  __shared__ float red[NW * CB];
+  const int t = blockIdx.y, n0 = blockIdx.x * CB;
+  const int wk = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = lane >> 3, kl = lane & 7;
+  const int steps = (Ip + 63) / 64;                  // 64 elements of a row per step (8 lanes x 8)
+  float part = 0.f;
+  for (int kk = wk; kk < topk; kk += NW) {
+    const int p = t * topk + kk;
+    const int e = min(max(ids[p], 0), E - 1);
+    const float wgt = wts[p];
+    const uint16_t* wr = down + ((long long)e * H + min(n0 + r, H - 1)) * Ip;
+    const uint16_t* xr = hbuf + (long long)p * Ip;
+    u32x4 wa[U], wb[U], xa[U], xb[U];
+    // Branch-free batches: Ip is a multiple of 32, so a 16-byte piece is in or out as a whole; a piece past the end
+    // of the row reads the row's last piece instead and meets zeros.
+    auto ld = [&](u32x4(&w)[U], u32x4(&x)[U], int s0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = (s0 + u) * 64 + kl * 8;
+        const int kc = min(k, Ip - 8);
+        w[u] = __builtin_nontemporal_load((const u32x4*)(wr + kc));
+        const u32x4 xv = *(const u32x4*)(xr + kc);
+        x[u] = k < Ip ? xv : u32x4{0, 0, 0, 0};
+      }
+    };
+    float acc = 0.f;
+    auto mm = [&](const u32x4(&w)[U], const u32x4(&x)[U]) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const unsigned wi = w[u][i], xi = x[u][i];      // (scalars first: see gemm_nt_dot_kernel)
+          acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, wi), __builtin_bit_cast(bf16x2, xi), acc, false);
+        }
+    };
+    ld(wa, xa, 0);
+    for (int s0 = 0; s0 < steps; s0 += 2 * U) {
+      if (s0 + U < steps) ld(wb, xb, s0 + U);
+      mm(wa, xa);
+      if (s0 + 2 * U < steps) ld(wa, xa, s0 + 2 * U);
+      if (s0 + U < steps) mm(wb, xb);
+    }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    acc += __shfl_xor(acc, 4);
+    part += wgt * acc;
+  }
+  if (kl == 0) red[wk * CB + r] = part;
+  __syncthreads();
+  if (threadIdx.x < CB && n0 + (int)threadIdx.x < H) {
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) sum += red[q * CB + threadIdx.x];
+    out[(long long)t * H + n0 + threadIdx.x] = __builtin_bit_cast(uint16_t, (__bf16)sum);
+  }
+}
+
+// MoE decode, first half on the vector ALUs (the counterpart of moe_decode_down_narrow_kernel): one workgroup per
+// (4 NW output columns, pair); a wave streams the four gate rows and the four up rows of four columns, eight lanes
+// per row, in batches of eight 16-byte pieces per lane with the next batch requested before the current one is
+// multiplied; the activation row x[t] is read with the weights it meets (L1 / L2 hits).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void moe_decode_gate_up_dot_kernel(const uint16_t* __restrict__ x,
+                                                                         const int* __restrict__ ids,
+                                                                         const uint16_t* __restrict__ gate_up,
+                                                                         uint16_t* __restrict__ hbuf, int topk, int Ip,
+                                                                         int H, int E) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  constexpr int U = 8;
+  const int p = blockIdx.y;
+  const int wk = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = lane >> 3, kl = lane & 7;
+  const int col = blockIdx.x * (4 * NW) + wk * 4 + (r & 3);          // output column of this lane's row
+  const int e = min(max(ids[p], 0), E - 1);
+  const uint16_t* wr = gate_up + ((long long)e * 2 * Ip + (r >> 2) * Ip + min(col, Ip - 1)) * H;
+  const uint16_t* xr = x + (long long)(p / topk) * H;
+  const int steps = (H + 63) / 64;
+  u32x4 wa[U], wb[U], xa[U], xb[U];
+  auto ld = [&](u32x4(&w)[U], u32x4(&xv)[U], int s0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = (s0 + u) * 64 + kl * 8;          // (H is a multiple of 32: a piece is in or out as a whole)
+      const int kc = min(k, H - 8);
+      w[u] = __builtin_nontemporal_load((const u32x4*)(wr + kc));
+      const u32x4 v = *(const u32x4*)(xr + kc);
+      xv[u] = k < H ? v : u32x4{0, 0, 0, 0};
+    }
+  };
+  float acc = 0.f;
+  auto mm = [&](const u32x4(&w)[U], const u32x4(&xv)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned wi = w[u][i], xi = xv[u][i];      // (scalars first: see gemm_nt_dot_kernel)
+        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, wi), __builtin_bit_cast(bf16x2, xi), acc, false);
+      }
+  };
+  ld(wa, xa, 0);
+  for (int s0 = 0; s0 < steps; s0 += 2 * U) {
+    if (s0 + U < steps) ld(wb, xb, s0 + U);
+    mm(wa, xa);
+    if (s0 + 2 * U < steps) ld(wa, xa, s0 + 2 * U);
+    if (s0 + U < steps) mm(wb, xb);
+  }
+  acc += __shfl_xor(acc, 1);
+  acc += __shfl_xor(acc, 2);
+  acc += __shfl_xor(acc, 4);
+  // rows 0..3 hold the gate sums, rows 4..7 the up sums of the same four columns (32 lanes further on)
+  const float up = __shfl_down(acc, 32);
+  if (kl == 0 && r < 4 && col < Ip) {
+    const float gr = (float)(__bf16)acc, ur = (float)(__bf16)up;      // both rounded to bf16 first, as the separate kernels do
+    hbuf[(long long)p * Ip + col] = __builtin_bit_cast(uint16_t, (__bf16)(gr / (1.f + __expf(-gr)) * ur));
+  }
+}
+
 // MoE decode, first half: hbuf[p, :] = silu(x[t] @ gate[e]^T) * (x[t] @ up[e]^T) for every (token t, expert
 // e = ids[p]) pair p = t * topk + k.  gate_up [E, 2 Ip, H] (gate rows first), x [tokens, H], hbuf [pairs, Ip]; bf16.
 // The decode GEMM with its fused activation, one grid row per pair.
 TDIST_API int tdist_moe_decode_gate_up(const void* x, const int* ids, const void* gate_up, void* hbuf, int tokens,
-                                       int topk, int Ip, int H, int E, void* stream) {
+                                       int topk, int Ip, int H, int E, int form, void* stream) {
   TDIST_REQUIRE(tokens > 0 && topk > 0 && (long long)tokens * topk <= 65535 && E > 0, "bad token / top-k / expert count");
   TDIST_REQUIRE(H >= 128 && H % 32 == 0 && Ip > 0 && Ip % 16 == 0, "H must be a multiple of 32 (>= 128), Ip of 16");
   TDIST_REQUIRE((((uintptr_t)x | (uintptr_t)gate_up) & 15) == 0 && (((uintptr_t)hbuf) & 3) == 0 && ids, "operands must be aligned");
-  hipLaunchKernelGGL((gemm_nt_skinny_kernel<true, 2, 4, true>), dim3(Ip / 16, tokens * topk), dim3(256), 0,
-                     (hipStream_t)stream, (const uint16_t*)x, (const uint16_t*)gate_up, (uint16_t*)hbuf, 1, Ip, H,
-                     (long long)H, (long long)H, (long long)Ip, (const uint16_t*)nullptr, (const uint16_t*)nullptr,
-                     (uint16_t*)nullptr, 0.f, ids, topk, (long long)2 * Ip * H, E);
+  // form: 0 = the decode GEMM (MFMA) with its fused activation, one grid row per pair; anything else = the vector-ALU
+  // kernel with two waves per workgroup (1 / 2 / 4 / 8 waves measured at 1 token: 12.1 / 11.7 / 13.6 / 16.3 us,
+  // MFMA form 14.6; at 16 tokens 116 / 118 / 124 / 172, MFMA 137)
+  if (form != 0)
+    hipLaunchKernelGGL((moe_decode_gate_up_dot_kernel<2>), dim3((Ip + 7) / 8, tokens * topk), dim3(128), 0,
+                       (hipStream_t)stream, (const uint16_t*)x, ids, (const uint16_t*)gate_up, (uint16_t*)hbuf, topk, Ip, H, E);
+  else
+    hipLaunchKernelGGL((gemm_nt_skinny_kernel<true, 2, 4, true>), dim3(Ip / 16, tokens * topk), dim3(256), 0,
+                       (hipStream_t)stream, (const uint16_t*)x, (const uint16_t*)gate_up, (uint16_t*)hbuf, 1, Ip, H,
+                       (long long)H, (long long)H, (long long)Ip, (const uint16_t*)nullptr, (const uint16_t*)nullptr,
+                       (uint16_t*)nullptr, 0.f, ids, topk, (long long)2 * Ip * H, E);
   TDIST_HIP_TRY(hipGetLastError());
   return 0;
 }
 
-// out [tokens, H] = sum over the top-k experts of wts * down[e] @ hbuf[pair] (see moe_decode_down_kernel).
+// out [tokens, H] = sum over the top-k experts of wts * down[e] @ hbuf[pair].  form: 1 = eight columns per workgroup on
+// the vector ALUs (moe_decode_down_narrow_kernel), 0 = sixteen columns on MFMAs (moe_decode_down_kernel), -1 = the
+// default.  Measured at 128 experts, top-8, H 2048, Ip 768 with cold weights, 1 / 2 / 4 / 8 / 16 tokens:
+// narrow 7.0 / 12.3 / 22.3 / 40.6 / 76.7 us, wide 12.2 / 14.4 / 25.1 / 46.4 / 90.2 us - the narrow form is the default.
 TDIST_API int tdist_moe_decode_down(const void* hbuf, const int* ids, const float* wts, const void* down, void* out,
-                                    int tokens, int topk, int H, int Ip, int E, void* stream) {
+                                    int tokens, int topk, int H, int Ip, int E, int form, void* stream) {
   TDIST_REQUIRE(tokens > 0 && tokens <= 65535 && topk > 0 && E > 0, "bad token / top-k / expert count");
   TDIST_REQUIRE(Ip >= 32 && Ip % 32 == 0 && H > 0, "Ip must be a multiple of 32");
   TDIST_REQUIRE((((uintptr_t)hbuf | (uintptr_t)down) & 15) == 0 && ids && wts && out, "operands must be aligned");
-  hipLaunchKernelGGL((moe_decode_down_kernel<8>), dim3((H + 15) / 16, tokens), dim3(512), 0, (hipStream_t)stream,
-                     (const uint16_t*)hbuf, ids, wts, (const uint16_t*)down, (uint16_t*)out, topk, H, Ip, E);
+  if (form != 0)
+    hipLaunchKernelGGL((moe_decode_down_narrow_kernel<8>), dim3((H + 7) / 8, tokens), dim3(512), 0, (hipStream_t)stream,
+                       (const uint16_t*)hbuf, ids, wts, (const uint16_t*)down, (uint16_t*)out, topk, H, Ip, E);
+  else
+    hipLaunchKernelGGL((moe_decode_down_kernel<8>), dim3((H + 15) / 16, tokens), dim3(512), 0, (hipStream_t)stream,
+                       (const uint16_t*)hbuf, ids, wts, (const uint16_t*)down, (uint16_t*)out, topk, H, Ip, E);
   TDIST_HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -684,6 +1067,11 @@ TDIST_API int tdist_gemm_nt_silu_mul(const void* X, const void* W, void* C, int 
   TDIST_REQUIRE(K >= 128 && K % 32 == 0, "K must be a multiple of 32 and >= 128");
   TDIST_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && ldc % 2 == 0, "row strides must keep the vector alignment");
   TDIST_REQUIRE((((uintptr_t)X | (uintptr_t)W) & 15) == 0 && (((uintptr_t)C) & 3) == 0, "operands must be aligned");
+  if (M == 1 && decode_dot_enabled()) {
+    launch_dot<1, true, false>((const uint16_t*)X, (const uint16_t*)W, (uint16_t*)C, M, I, K, ldx, ldw, ldc, 0, (hipStream_t)stream);
+    TDIST_HIP_TRY(hipGetLastError());
+    return 0;
+  }
   const dim3 grid((I + 15) / 16);
   hipLaunchKernelGGL((gemm_nt_skinny_kernel<true, 2, 4, true>), grid, dim3(256), 0, (hipStream_t)stream,
                      (const uint16_t*)X, (const uint16_t*)W, (uint16_t*)C, M, I, K, ldx, ldw, ldc);

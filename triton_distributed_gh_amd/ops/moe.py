@@ -481,13 +481,20 @@ def moe_decode_supported(x: torch.Tensor, gate_up: torch.Tensor, down: torch.Ten
             and n * topk <= 65535)
 
 
+# form of the down-projection kernel: -1 default (narrow), 0 = 16 columns per workgroup on MFMAs, 1 = 8 columns on the
+# vector ALUs (csrc/ops/gemm.hip: tdist_moe_decode_down)
+MOE_DOWN_FORM = int(os.environ.get("TDIST_MOE_DOWN_NARROW", "-1"))
+# form of the gate_up kernel: -1 default (vector ALUs), 0 = decode GEMM on MFMAs, 1 = vector ALUs (tdist_moe_decode_gate_up)
+MOE_GATE_UP_FORM = int(os.environ.get("TDIST_MOE_GATE_UP_DOT", "-1"))
+
+
 def moe_decode_fwd(x: torch.Tensor, topk_ids: torch.Tensor, topk_weights: torch.Tensor, gate_up: torch.Tensor,
-                   down: torch.Tensor) -> torch.Tensor:
+                   down: torch.Tensor, down_form: Optional[int] = None, gate_up_form: Optional[int] = None) -> torch.Tensor:
     """``out[t] = sum_k w[t, k] * down[e] @ (silu(gate[e] x[t]) * (up[e] x[t]))`` with ``e = topk_ids[t, k]``.
 
     The MoE block of a decode step as two weight-streaming launches (csrc/ops/gemm.hip): one decode GEMM with fused
     SiLU per (token, expert) pair, then one kernel whose eight waves stream the ``down`` rows of the token's experts
-    and fold the routing weights and the top-k sum into their reduction.  Nothing is sorted, padded to tiles or
+    and fold the routing weights and the top-k sum into their reduction (``down_form``: see ``MOE_DOWN_FORM``).  Nothing is sorted, padded to tiles or
     gathered: the grouped-GEMM path (``ag_group_gemm`` + ``run_moe_reduce_rs``) costs about 250 us per layer for
     one token of Qwen3-30B-A3B, these two launches stream the same 75 MB of expert weights.
     Reference role: layers/nvidia/tp_moe.py at decode sizes (it has no special case)."""
@@ -500,9 +507,11 @@ def moe_decode_fwd(x: torch.Tensor, topk_ids: torch.Tensor, topk_weights: torch.
     out = torch.empty((n, H), dtype=x.dtype, device=x.device)
     lib = _lib.hip()
     _lib.check(lib.tdist_moe_decode_gate_up(_lib.ptr(x), _lib.ptr(ids), _lib.ptr(gate_up), _lib.ptr(hbuf), n, k, Ip, H,
-                                            gate_up.shape[0], _lib.stream_handle()), "tdist_moe_decode_gate_up")
+                                            gate_up.shape[0], MOE_GATE_UP_FORM if gate_up_form is None else gate_up_form,
+                                            _lib.stream_handle()), "tdist_moe_decode_gate_up")
     _lib.check(lib.tdist_moe_decode_down(_lib.ptr(hbuf), _lib.ptr(ids), _lib.ptr(wts), _lib.ptr(down), _lib.ptr(out),
-                                         n, k, H, Ip, down.shape[0], _lib.stream_handle()), "tdist_moe_decode_down")
+                                         n, k, H, Ip, down.shape[0], MOE_DOWN_FORM if down_form is None else down_form,
+                                         _lib.stream_handle()), "tdist_moe_decode_down")
     return out
 
 
