@@ -1,5 +1,6 @@
-"""Decode GEMMs of a Qwen3-8B layer + LM head at 1 and 2 rows: vector-ALU form (tdist_gemm_nt_dot) against the MFMA
-decode kernel (gemm_nt / gemm_nt_silu_mul), inside a HIP graph over rotating weight copies (cold weights)."""
+"""Decode GEMMs of a Qwen3-8B layer + LM head at 1 and 2 rows: the vector-ALU form (tdist_gemm_nt_dot) against what
+gemm_nt / gemm_nt_silu_mul pick (TDIST_DECODE_DOT=0: the MFMA decode kernel), inside a HIP graph over rotating weight
+copies (cold weights)."""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from triton_distributed_gh_amd import _lib
@@ -35,8 +36,7 @@ for name, N, K, silu in shapes:
             else:
                 gemm_nt(x, ws[i % copies], out=out)
 
-        # correctness against fp32
-        dot(0)()
+        dot(0)()          # correctness against fp32
         w0 = ws[(it[0] - 1) % copies].float()
         ref = x.float() @ w0.t()
         if silu:
@@ -44,6 +44,6 @@ for name, N, K, silu in shapes:
         err = (out.float() - ref).abs().max().item() / ref.abs().max().item()
         t_m = graph_bench(mfma, n=copies)
         ts = {nw: graph_bench(dot(nw), n=copies) for nw in (0, 1, 2, 4, 8)}
-        line.append(f"M={M}: mfma {t_m:.1f} | dot auto {ts[0]:.1f} nw1 {ts[1]:.1f} nw2 {ts[2]:.1f} nw4 {ts[4]:.1f} nw8 {ts[8]:.1f} (err {err:.1e})")
+        line.append(f"M={M}: lib's choice {t_m:.1f} | dot auto {ts[0]:.1f} nw1 {ts[1]:.1f} nw2 {ts[2]:.1f} nw4 {ts[4]:.1f} nw8 {ts[8]:.1f} (err {err:.1e})")
     print(f"{name} {N}x{K} ({rows * K * 2 / 1e6:.0f} MB): " + "  ||  ".join(line), flush=True)
     del ws

@@ -118,6 +118,30 @@ def test_decode_gemm_matches_fp32_reference(M, N, K, dtype):
     assert (c2.float() - out[:, :N].float()).abs().max().item() <= 2e-2 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("silu", [0, 1])
+@pytest.mark.parametrize("nw", [0, 1, 2, 4, 8])
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (1, 1000, 2080), (1, 12, 160), (2, 520, 1056), (1, 6, 128)])
+def test_one_row_gemm_on_the_vector_alus(M, N, K, nw, silu):
+    """gemm_nt_dot_kernel (what gemm_nt / gemm_nt_norm / gemm_nt_silu_mul run at one row) with every K split, ragged
+    N and K that is not a multiple of the 64-element step, against fp32 PyTorch."""
+    import ctypes
+    from triton_distributed_gh_amd import _lib
+
+    torch.manual_seed(N + K + nw)
+    bf = torch.bfloat16
+    rows = 2 * N if silu else N
+    x = (torch.rand(M, K, device="cuda") * 2 - 1).to(bf)
+    w = ((torch.rand(rows, K, device="cuda") * 2 - 1) * 0.1).to(bf)
+    out = torch.zeros(M, N, device="cuda", dtype=bf)
+    _lib.check(_lib.hip().tdist_gemm_nt_dot(_lib.ptr(x), _lib.ptr(w), _lib.ptr(out), M, N, K, ctypes.c_longlong(K),
+                                            ctypes.c_longlong(K), ctypes.c_longlong(N), silu, nw, _lib.stream_handle()),
+               "tdist_gemm_nt_dot")
+    ref = x.float() @ w.float().t()
+    if silu:
+        ref = torch.nn.functional.silu(ref[:, :N].to(bf).float()) * ref[:, N:].to(bf).float()
+    torch.testing.assert_close(out.float(), ref, atol=2e-2 * max(ref.abs().max().item(), 1e-3), rtol=2e-2)
+
+
 @pytest.mark.parametrize("M", [1, 7, 16])
 @pytest.mark.parametrize("I,K", [(1024, 512), (12288, 4096), (1000, 192)])
 def test_decode_gemm_with_silu_mul_epilogue(M, I, K):

@@ -523,7 +523,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const uint16_t*
 // gemm_nt_skinny_kernel (h = bf16(X + R), workgroup 0 writes h to Hout, the products use bf16(h * G) staged in LDS and
 // the result is scaled by rsqrt(mean(h^2) + eps)).  Cold weights, one row, MFMA form -> this form: 50 MB 15.7 -> 10.6 us,
 // 101 MB 25.2 -> 18.0, 201 MB with SiLU 39.9 -> 34.0, 1245 MB 224.5 -> 182.0.  (MR = 2 exists for measurements: with
-// two rows the activation loads double and the MFMA form wins.)
+// two rows the activation loads double and the MFMA form wins on most shapes; a form that stages two to four rows in
+// LDS and reads them from there was built and measured too - 50 MB 15.1 vs 16.5 us and 101 MB 19.6 vs 23.1 at two
+// rows, but 201 MB with SiLU 45.1 vs 40.4, 1245 MB 237 vs 226, and slower everywhere at four rows - and dropped.)
 template <int NW, int MR, bool SILU, bool NORM = false>
 __global__ __launch_bounds__(64 * NW) void gemm_nt_dot_kernel(const uint16_t* __restrict__ X,
                                                               const uint16_t* __restrict__ W,

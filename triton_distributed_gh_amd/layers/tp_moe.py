@@ -19,6 +19,7 @@ import torch
 from ..ops import elementwise
 from ..ops.allgather import create_fast_allgather_context, fast_allgather
 from ..ops.allreduce import all_reduce, create_allreduce_ctx
+from ..ops.gemm import gemm_nt, gemm_supported
 from ..ops.moe import (ag_group_gemm, create_ag_group_gemm_context, create_moe_rs_context, MOE_DECODE_MAX_TOKENS, moe_decode_fwd,
                        moe_decode_supported, moe_route, moe_route_supported, run_moe_reduce_rs)
 from ..utils.distributed import get_env
@@ -115,7 +116,10 @@ class TP_MoE:
         self.ag_ctx = self.rs_ctx = None
 
     def _route(self, x2: torch.Tensor, fused: bool = False):
-        logits = torch.nn.functional.linear(x2, self.gate)
+        if fused and x2.shape[0] <= 16 and gemm_supported(x2, self.gate):
+            logits = gemm_nt(x2, self.gate)          # decode: the weight-streaming kernel (3 us at one row, library 8.5)
+        else:
+            logits = torch.nn.functional.linear(x2, self.gate)
         if fused and moe_route_supported(logits, self.top_k):
             return moe_route(logits, self.top_k, self.norm_topk_prob)      # one launch (ops/moe.py)
         probs = torch.nn.functional.softmax(logits, dim=1, dtype=torch.float)
