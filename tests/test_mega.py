@@ -54,6 +54,28 @@ def test_graph_dependencies_and_deadlock_check_cpu():
         check_schedule(bad)
 
 
+def test_reused_tensors_get_write_after_read_dependencies_cpu():
+    """One buffer written twice: the second writer waits for the reader of the first value unless a dependency it
+    already has orders it behind that reader."""
+    b = ModelBuilder(num_queues=8)
+    M, H, N = 4, 64, 96
+    x, r, g, xn = torch.zeros(M, H, dtype=BF), torch.zeros(M, H, dtype=BF), torch.ones(H, dtype=BF), torch.zeros(M, H, dtype=BF)
+    w1, y1, hid = torch.zeros(N, H, dtype=BF), torch.zeros(M, N, dtype=BF), torch.zeros(M, H, dtype=BF)
+    w2, y2 = torch.zeros(H, H, dtype=BF), torch.zeros(M, H, dtype=BF)
+    n1 = b.make_rms_norm(x, g, xn)
+    l1 = b.make_linear(xn, w1, y1)
+    n2 = b.make_rms_norm(x, g, xn, 1e-6, residual=r, residual_out=hid)       # overwrites xn while l1 may still read it
+    l2 = b.make_linear(xn, w2, y2)
+    n3 = b.make_rms_norm(y2, g, xn)          # reads l2's output: l2 (the reader of xn) is already in front of it
+    by_op = {}
+    for t in b.build_tasks():
+        by_op.setdefault(t.op, []).append(t)
+    assert all(t.deps == [TaskDependency(l1.op_id, 0, l1.num_tiles)] for t in by_op[n2.op_id])
+    assert all(t.deps == [TaskDependency(n2.op_id, 0, M)] for t in by_op[l2.op_id])
+    assert all(t.deps == [TaskDependency(l2.op_id, 0, l2.num_tiles)] for t in by_op[n3.op_id])
+    assert all(t.deps == [] for t in by_op[n1.op_id])
+
+
 def _rel(a, b):
     return (a.float() - b.float()).abs().max().item() / max(b.float().abs().max().item(), 1e-6)
 

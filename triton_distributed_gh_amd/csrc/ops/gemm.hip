@@ -682,6 +682,227 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_dot_kernel(const uint16_t* __
   }
 }
 
+// Decode GEMM for 2 .. 16 rows on MFMAs with 128-byte runs per weight row and load instruction.
+//
+// The B operand of a 16x16x32 MFMA wants lane (li, lg) to hold k = 8 lg .. 8 lg + 7 of weight row li: four lanes, 64
+// contiguous bytes per row and load instruction (gemm_nt_skinny_kernel).  The same one-row kernel on the vector ALUs
+// runs 13 - 20 % faster with eight lanes per row than with four (50 MB 11.1 vs 13.7 us, 1245 MB 183 vs 212 us; sixteen
+// lanes are slower again), so here a load instruction covers EIGHT rows x 128 bytes: lane (li, lg) loads k-group
+// 4 (li >> 3) + lg of row li & 7 of a 64-deep K step.  Lanes li < 8 then hold k-groups 0 .. 3 of the eight rows and
+// lanes li >= 8 k-groups 4 .. 7 of the SAME rows, and two MFMAs per step sort it out: the first multiplies with the
+// activations' k-groups 0 .. 3 (its columns 0 .. 7 are valid partial sums, 8 .. 15 meaningless), the second with
+// k-groups 4 .. 7 (columns 8 .. 15 valid); column j of the result is column j of the first accumulator plus column
+// j + 8 of the second.  Twice the MFMAs per weight byte - the matrix pipe idles either way at these row counts.
+// Everything else (K slices over the waves, WN column groups sharing the activation fragments, SILU, NORM, the
+// rolling window of loads) is gemm_nt_skinny_kernel's.
+template <bool IS_BF16, int WN, int NW, bool SILU = false, bool NORM = false>
+__global__ __launch_bounds__(64 * NW) void gemm_nt_skinny128_kernel(const uint16_t* __restrict__ X,
+                                                                const uint16_t* __restrict__ W,
+                                                                uint16_t* __restrict__ C, int M, int N, int K,
+                                                                long long ldx, long long ldw, long long ldc,
+                                                                const uint16_t* __restrict__ R,
+                                                                const uint16_t* __restrict__ G,
+                                                                uint16_t* __restrict__ Hout, float eps) {
+  static_assert(!NORM || IS_BF16, "the fused norm is built for bf16");
+  static_assert(!SILU || WN % 2 == 0, "the fused activation pairs gate group g with up group g + WN / 2");
+  static_assert(WN <= NW, "one wave per column group sums the K slices");
+  using F = Frag<IS_BF16>;
+  using VT = typename F::T;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  constexpr int GN = SILU ? WN / 2 : WN;                 // groups of eight OUTPUT columns per workgroup
+  constexpr int BN_ = 8 * GN;
+  constexpr int U = 16 / WN;                             // 64-deep K steps per batch (16 weight loads in flight per lane)
+  const int up_off = SILU ? N : 0;                       // (SILU: N is I, the number of OUTPUT columns)
+  __shared__ float red[NW * WN * 64 * 4];                // [K slice][column group][lane][4]
+  const int wk = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int li = lane & 15, lg = lane >> 4;
+  const int lrow = li & 7, kg = (li >> 3) * 4 + lg;      // weight row inside the group, k-group inside the step
+  const int n0 = blockIdx.x * BN_;
+  const int ksteps = (K + 63) / 64;
+  const int per = (ksteps + NW - 1) / NW;
+  const int ks0 = min(wk * per, ksteps), ks1 = min(ks0 + per, ksteps);
+  const uint16_t* xr = X + (long long)min(li, M - 1) * ldx + lg * 8;
+  const uint16_t* wr[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j)                            // clamped: out-of-range columns are not stored
+    wr[j] = W + (long long)((j / GN) * up_off + min(n0 + (j % GN) * 8 + lrow, N - 1)) * ldw;
+  const bool xvalid = li < M;
+  f32x4 acc1[WN], acc2[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) acc1[j] = acc2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  extern __shared__ __attribute__((aligned(16))) char tbuf[];     // NORM: [M][K * 2 + 64] bytes (rows padded: banks)
+  __shared__ float s_ss[16];
+  const long long trow = (long long)K * 2 + 64;
+  auto norm_prepass = [&]() {
+    if constexpr (NORM) {
+      if (threadIdx.x < 16) s_ss[threadIdx.x] = 0.f;
+      __syncthreads();
+      const int nvec = K / 8;
+      for (int row = 0; row < M; ++row) {
+        float ss = 0.f;
+        for (int c = threadIdx.x; c < nvec; c += 64 * NW) {
+          const u32x4 xv = *(const u32x4*)(X + (long long)row * ldx + c * 8);
+          const u32x4 gv = *(const u32x4*)(G + c * 8);
+          u32x4 rv = {0, 0, 0, 0}, hb, t;
+          if (R) rv = *(const u32x4*)(R + (long long)row * K + c * 8);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float lo = __builtin_bit_cast(float, xv[i] << 16), hi = __builtin_bit_cast(float, xv[i] & 0xffff0000u);
+            hb[i] = xv[i];
+            if (R) {
+              lo += __builtin_bit_cast(float, rv[i] << 16);
+              hi += __builtin_bit_cast(float, rv[i] & 0xffff0000u);
+              hb[i] = F::pack2(lo, hi);      // the sum rounded to 16 bits is what the norm sees (as the separate kernel)
+              lo = __builtin_bit_cast(float, hb[i] << 16), hi = __builtin_bit_cast(float, hb[i] & 0xffff0000u);
+            }
+            ss += lo * lo + hi * hi;
+            t[i] = F::pack2(lo * __builtin_bit_cast(float, gv[i] << 16), hi * __builtin_bit_cast(float, gv[i] & 0xffff0000u));
+          }
+          *(u32x4*)(tbuf + row * trow + c * 16) = t;
+          if (R && blockIdx.x == 0) *(u32x4*)(Hout + (long long)row * K + c * 8) = hb;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        if (lane == 0) atomicAdd(&s_ss[row], ss);
+      }
+      __syncthreads();
+    }
+  };
+  // activation fragment of K step ks, half h (k-groups 4 h .. 4 h + 3); zero past the end of K and for rows past M
+  auto load_x = [&](int ks, int h) -> u32x4 {
+    const int k = ks * 64 + h * 32 + lg * 8;
+    const bool ok = xvalid && k < K;
+    if constexpr (NORM) {
+      const u32x4 v = *(const u32x4*)(tbuf + min(li, M - 1) * trow + min(k, K - 8) * 2);
+      return ok ? v : u32x4{0, 0, 0, 0};
+    } else {
+      const u32x4 v = *(const u32x4*)(xr + min(k, K - 8) - lg * 8);
+      return ok ? v : u32x4{0, 0, 0, 0};
+    }
+  };
+  const int nfull = (ks1 - ks0) / U;
+  constexpr int H = U / 2;
+  u32x4 wv[U][WN], xv1[U], xv2[U];
+  auto issue = [&](int ks, auto u0c) {
+    constexpr int u0 = decltype(u0c)::value;
+#pragma unroll
+    for (int u = u0; u < u0 + H; ++u)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+        wv[u][j] = __builtin_nontemporal_load((const u32x4*)(wr[j] + min((ks + u) * 64 + kg * 8, K - 8)));
+    if constexpr (!NORM) {
+#pragma unroll
+      for (int u = u0; u < u0 + H; ++u) xv1[u] = load_x(ks + u, 0), xv2[u] = load_x(ks + u, 1);
+    }
+  };
+  auto consume = [&](int ks, auto u0c) {
+    constexpr int u0 = decltype(u0c)::value;
+    if constexpr (NORM) {
+#pragma unroll
+      for (int u = u0; u < u0 + H; ++u) xv1[u] = load_x(ks + u, 0), xv2[u] = load_x(ks + u, 1);
+    }
+#pragma unroll
+    for (int u = u0; u < u0 + H; ++u)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        acc1[j] = F::mfma(__builtin_bit_cast(VT, xv1[u]), __builtin_bit_cast(VT, wv[u][j]), acc1[j]);
+        acc2[j] = F::mfma(__builtin_bit_cast(VT, xv2[u]), __builtin_bit_cast(VT, wv[u][j]), acc2[j]);
+      }
+  };
+  using C0 = std::integral_constant<int, 0>;
+  using CH = std::integral_constant<int, H>;
+  if (nfull == 0) {
+    norm_prepass();
+  } else {
+    issue(ks0, C0{});
+    issue(ks0, CH{});
+    norm_prepass();
+    for (int bi = 0; bi < nfull; ++bi) {
+      const int ks = ks0 + bi * U;
+      const bool more = bi + 1 < nfull;
+      consume(ks, C0{});
+      if (more) issue(ks + U, C0{});
+      consume(ks, CH{});
+      if (more) issue(ks + U, CH{});
+    }
+  }
+  for (int ks = ks0 + nfull * U; ks < ks1; ++ks) {
+    const u32x4 x1 = load_x(ks, 0), x2 = load_x(ks, 1);
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const u32x4 w = __builtin_nontemporal_load((const u32x4*)(wr[j] + min(ks * 64 + kg * 8, K - 8)));
+      acc1[j] = F::mfma(__builtin_bit_cast(VT, x1), __builtin_bit_cast(VT, w), acc1[j]);
+      acc2[j] = F::mfma(__builtin_bit_cast(VT, x2), __builtin_bit_cast(VT, w), acc2[j]);
+    }
+  }
+  // accumulator: row (token) = 4*lg + r, column = li.  Column j < 8 of the result = acc1 column j + acc2 column j + 8
+  // (eight lanes further on); wave g then sums column group g over the K slices.
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    float* slot = red + ((wk * WN + j) * 64 + lane) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) slot[r] = acc1[j][r] + __shfl_down(acc2[j][r], 8);
+  }
+  __syncthreads();
+  float inv[4] = {1.f, 1.f, 1.f, 1.f};                  // per-row scale of the fused norm (rows 4 lg .. 4 lg + 3)
+  if constexpr (NORM) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) inv[r] = rsqrtf(s_ss[4 * lg + r] / (float)K + eps);
+  }
+  if constexpr (SILU) {
+    if (wk >= GN) return;                      // wave g: gate group g and up group g + GN
+    f32x4 g = {0.f, 0.f, 0.f, 0.f}, up = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      const float* og = red + ((q * WN + wk) * 64 + lane) * 4;
+      const float* ou = red + ((q * WN + wk + GN) * 64 + lane) * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) g[r] += og[r], up[r] += ou[r];
+    }
+    const int col = n0 + wk * 8 + li;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * lg + r;
+      // the separate kernels round gate and up to 16 bits first: do the same, then activate
+      const float gr = IS_BF16 ? (float)(__bf16)(g[r] * inv[r]) : (float)(_Float16)g[r];
+      const float ur = IS_BF16 ? (float)(__bf16)(up[r] * inv[r]) : (float)(_Float16)up[r];
+      const float mine = gr / (1.f + __expf(-gr)) * ur;
+      const float other = __shfl_xor(mine, 1);
+      if (row < M && li < 8 && col < N && (li & 1) == 0) *(uint32_t*)(C + (long long)row * ldc + col) = F::pack2(mine, other);
+    }
+    return;
+  }
+  if (wk >= WN) return;
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < NW; ++q) {
+    const float* o = red + ((q * WN + wk) * 64 + lane) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sum[r] += o[r];
+  }
+  // lanes li and li^1 hold neighbouring columns: the even lane stores both (N, ldc are even)
+  const int col = n0 + wk * 8 + li;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * lg + r;
+    const float mine = sum[r] * inv[r];
+    const float other = __shfl_xor(mine, 1);
+    if (row < M && li < 8 && col < N && (li & 1) == 0) *(uint32_t*)(C + (long long)row * ldc + col) = F::pack2(mine, other);
+  }
+}
+
+// Shape of gemm_nt_skinny128_kernel for a call: WN column groups of eight, NW waves (K slices).  Measured on cold
+// weights at 2 / 4 / 8 / 16 rows against gemm_nt_skinny_kernel (us): 6144 x 4096 12.6 / 14.4 / 15.2 / 16.4 with WN 4
+// (64-byte-run kernel 15.7 / 16.7 / 17.0 / 17.9), 4096 x 4096 9.0 / 9.1 / 9.4 / 10.2 with WN 2 (9.2 / 9.5 / 10.0 / 11.2),
+// 4096 x 12288 20.6 / 21.3 / 23.5 / 28.8 with WN 2 (25.7 / 27.1 / 29.2 / 32.8), 151936 x 4096 189 / 190 / 197 / 231 with
+// WN 4 (226 / 233 / 248 / 268); WN 1 and eight waves lose on every shape.
+// TDIST_SKINNY128: 0 = keep gemm_nt_skinny_kernel, "<WN><NW>" (e.g. 24) = force a shape.
+static int skinny128_choice(int N) {
+  static const int v = getenv("TDIST_SKINNY128") ? atoi(getenv("TDIST_SKINNY128")) : -1;
+  if (v >= 0) return v;
+  return N >= 6144 ? 44 : 24;
+}
+
 // TDIST_DECODE_DOT=0 keeps one-row decode GEMMs on the MFMA kernel (A/B measurements)
 static bool decode_dot_enabled() {
   static const bool on = !(getenv("TDIST_DECODE_DOT") && atoi(getenv("TDIST_DECODE_DOT")) == 0);
@@ -746,6 +967,20 @@ static void launch_skinny(const void* A, const void* B, void* C, int M, int N, i
       return;
     }
   }
+  if (const int ch = skinny128_choice(N); ch > 0 && M >= 2) {
+    const uint16_t *a = (const uint16_t*)A, *b = (const uint16_t*)B;
+    uint16_t* c = (uint16_t*)C;
+    const int wn = ch / 10, nw = ch % 10;
+#define TDIST_S128(WN_, NW_)                                                                                          \
+  if (wn == WN_ && nw == NW_) {                                                                                       \
+    hipLaunchKernelGGL((gemm_nt_skinny128_kernel<IS_BF16, WN_, NW_>), dim3((N + 8 * WN_ - 1) / (8 * WN_)), dim3(64 * NW_), \
+                       0, s, a, b, c, M, N, K, lda, ldb, ldc, (const uint16_t*)nullptr, (const uint16_t*)nullptr,     \
+                       (uint16_t*)nullptr, 0.f);                                                                      \
+    return;                                                                                                           \
+  }
+    TDIST_S128(1, 4) TDIST_S128(2, 4) TDIST_S128(4, 4) TDIST_S128(1, 8) TDIST_S128(2, 8) TDIST_S128(4, 8)
+#undef TDIST_S128
+  }
   int bn;
   if (M <= 4)
     bn = N >= 16384 ? 32 : 16;
@@ -789,6 +1024,22 @@ TDIST_API int tdist_gemm_nt_norm(const void* X, const void* R, const void* G, fl
       launch_dot<1, true, true>(x, w, c, M, N, K, ldx, ldw, ldc, 0, s, r, g, h, eps);
     else
       launch_dot<1, false, true>(x, w, c, M, N, K, ldx, ldw, ldc, 0, s, r, g, h, eps);
+    TDIST_HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  if (const int ch = skinny128_choice(N); ch > 0) {
+    if (silu && M >= 8)
+      hipLaunchKernelGGL((gemm_nt_skinny128_kernel<true, 4, 4, true, true>), dim3((N + 15) / 16), dim3(256), (size_t)lds, s, x, w,
+                         c, M, N, K, ldx, ldw, ldc, r, g, h, eps);
+    else if (silu)
+      hipLaunchKernelGGL((gemm_nt_skinny128_kernel<true, 2, 4, true, true>), dim3((N + 7) / 8), dim3(256), (size_t)lds, s, x, w,
+                         c, M, N, K, ldx, ldw, ldc, r, g, h, eps);
+    else if (ch / 10 >= 4)
+      hipLaunchKernelGGL((gemm_nt_skinny128_kernel<true, 4, 4, false, true>), dim3((N + 31) / 32), dim3(256), (size_t)lds, s, x,
+                         w, c, M, N, K, ldx, ldw, ldc, r, g, h, eps);
+    else
+      hipLaunchKernelGGL((gemm_nt_skinny128_kernel<true, 2, 4, false, true>), dim3((N + 15) / 16), dim3(256), (size_t)lds, s, x,
+                         w, c, M, N, K, ldx, ldw, ldc, r, g, h, eps);
     TDIST_HIP_TRY(hipGetLastError());
     return 0;
   }
@@ -1071,6 +1322,19 @@ TDIST_API int tdist_gemm_nt_silu_mul(const void* X, const void* W, void* C, int 
   TDIST_REQUIRE((((uintptr_t)X | (uintptr_t)W) & 15) == 0 && (((uintptr_t)C) & 3) == 0, "operands must be aligned");
   if (M == 1 && decode_dot_enabled()) {
     launch_dot<1, true, false>((const uint16_t*)X, (const uint16_t*)W, (uint16_t*)C, M, I, K, ldx, ldw, ldc, 0, (hipStream_t)stream);
+    TDIST_HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  if (skinny128_choice(I) > 0) {
+    // two gate + two up groups per workgroup from eight rows on: the activation fragments are shared by more weights
+    if (M >= 8)
+      hipLaunchKernelGGL((gemm_nt_skinny128_kernel<true, 4, 4, true, false>), dim3((I + 15) / 16), dim3(256), 0, (hipStream_t)stream,
+                         (const uint16_t*)X, (const uint16_t*)W, (uint16_t*)C, M, I, K, ldx, ldw, ldc, (const uint16_t*)nullptr,
+                         (const uint16_t*)nullptr, (uint16_t*)nullptr, 0.f);
+    else
+      hipLaunchKernelGGL((gemm_nt_skinny128_kernel<true, 2, 4, true, false>), dim3((I + 7) / 8), dim3(256), 0, (hipStream_t)stream,
+                         (const uint16_t*)X, (const uint16_t*)W, (uint16_t*)C, M, I, K, ldx, ldw, ldc, (const uint16_t*)nullptr,
+                         (const uint16_t*)nullptr, (uint16_t*)nullptr, 0.f);
     TDIST_HIP_TRY(hipGetLastError());
     return 0;
   }

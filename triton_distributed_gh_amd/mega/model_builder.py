@@ -212,30 +212,68 @@ class ModelBuilder:
         return None
 
     def build_tasks(self) -> List[Task]:
+        """Tile tasks with their dependencies.  An op waits for the last writer of everything it reads and - because
+        recorded tensors are reused (one normalised-activation buffer serves every norm of a model) - for the earlier
+        readers and the earlier writer of everything it WRITES, unless a dependency it already has orders it behind
+        them: ``settled[w]`` is the set of ops that are complete once every tile of ``w`` is, and a full-range
+        dependency on ``w`` puts all of them in front of every tile of the waiting op."""
         tasks: List[Task] = []
         row_tiled = (TaskType.RMS_NORM, TaskType.ADD, TaskType.SILU_MUL, TaskType.QK_NORM_ROPE_KV, TaskType.ALLREDUCE,
                      TaskType.ATTN_COMBINE)
+
+        def tile_dep(op, w, tile):
+            if op.type in row_tiled and w.type in row_tiled and w.num_tiles == op.num_tiles:
+                return TaskDependency(w.op_id, tile, tile + 1)          # same row / token
+            if op.type == TaskType.ATTN_SPLIT and w.type == TaskType.QK_NORM_ROPE_KV:
+                b = tile // (op.num_tiles // w.num_tiles)
+                return TaskDependency(w.op_id, b, b + 1)
+            if op.type == TaskType.ATTN_COMBINE and w.type == TaskType.ATTN_SPLIT:
+                per = w.num_tiles // op.num_tiles
+                return TaskDependency(w.op_id, tile * per, (tile + 1) * per)
+            return TaskDependency(w.op_id, 0, w.num_tiles)
+
+        def full_range(op, w):
+            d = tile_dep(op, w, 0)
+            return d.lo == 0 and d.hi == w.num_tiles
+
+        settled: List[set] = []                 # per op: ops complete once all of its tiles are
+        readers: Dict[int, List[int]] = {}      # tensor -> ops that read it since its last write
+        writer: Dict[int, int] = {}             # tensor -> last op that wrote it
         for op in self.ops:
             producers = []
             for ptr in dict.fromkeys(op.reads):
                 w = self._writer_of(ptr, op.op_id)
                 if w is not None and w.op_id not in [p.op_id for p in producers]:
                     producers.append(w)
-            assert len(producers) <= MAX_DEPS, f"{op.name}: more than {MAX_DEPS} producers"
+            # everything in front of EVERY tile of this op through the dependencies it has so far
+            ahead = set()
+            for w in producers:
+                if full_range(op, w):
+                    ahead |= {w.op_id} | settled[w.op_id]
+            hazards = []
+            for ptr in dict.fromkeys(op.writes):
+                hazards += readers.get(ptr, [])
+                if ptr in writer:
+                    hazards.append(writer[ptr])
+            for hz in sorted(set(hazards), reverse=True):          # latest first: it may settle the earlier ones
+                if hz == op.op_id or hz in ahead or hz in [p.op_id for p in producers]:
+                    continue
+                w = self.ops[hz]
+                producers.append(w)
+                if full_range(op, w):
+                    ahead |= {hz} | settled[hz]
+            assert len(producers) <= MAX_DEPS, f"{op.name}: more than {MAX_DEPS} dependencies"
+            done = set()
+            for w in producers:
+                done |= {w.op_id} | settled[w.op_id]
+            settled.append(done)
+            for ptr in dict.fromkeys(op.reads):
+                readers.setdefault(ptr, []).append(op.op_id)
+            for ptr in dict.fromkeys(op.writes):
+                readers[ptr] = []
+                writer[ptr] = op.op_id
             for tile in range(op.num_tiles):
-                deps = []
-                for w in producers:
-                    if op.type in row_tiled and w.type in row_tiled and w.num_tiles == op.num_tiles:
-                        deps.append(TaskDependency(w.op_id, tile, tile + 1))      # same row / token
-                    elif op.type == TaskType.ATTN_SPLIT and w.type == TaskType.QK_NORM_ROPE_KV:
-                        b = tile // (op.num_tiles // w.num_tiles)
-                        deps.append(TaskDependency(w.op_id, b, b + 1))
-                    elif op.type == TaskType.ATTN_COMBINE and w.type == TaskType.ATTN_SPLIT:
-                        per = w.num_tiles // op.num_tiles
-                        deps.append(TaskDependency(w.op_id, tile * per, (tile + 1) * per))
-                    else:
-                        deps.append(TaskDependency(w.op_id, 0, w.num_tiles))
-                tasks.append(Task(op.type, op.op_id, tile, deps))
+                tasks.append(Task(op.type, op.op_id, tile, [tile_dep(op, w, tile) for w in producers]))
         return tasks
 
     # ---- compile / run -------------------------------------------------------------------------------

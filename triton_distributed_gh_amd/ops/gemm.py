@@ -33,7 +33,7 @@ MID_GEMM = os.environ.get("TDIST_MID_GEMM", "native")
 MID_MAX_M = int(os.environ.get("TDIST_MID_MAX_M", "1024"))
 # decode shapes (M <= 16) with long K / mid-sized weights on the mid-M kernel's split-K: from this many rows on
 DECODE_SPLITK = os.environ.get("TDIST_DECODE_SPLITK", "0") != "0"
-DECODE_SPLITK_MIN_M = 1 if DECODE_SPLITK else int(os.environ.get("TDIST_DECODE_SPLITK_MIN_M", "2"))
+DECODE_SPLITK_MIN_M = 1 if DECODE_SPLITK else int(os.environ.get("TDIST_DECODE_SPLITK_MIN_M", "9"))
 
 
 def gemm_supported(a: torch.Tensor, b: torch.Tensor) -> bool:
@@ -76,14 +76,12 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
             return out
         if M <= MID_MAX_M:
             return gemm_nt_mid(a, b, out)
-    # Decode shapes (M <= 16): the weight-streaming kernel has no split of K across workgroups and every workgroup
-    # reads all M activation rows (at 16 rows as many bytes as its weight slice), so from two rows on the long-K /
-    # mid-sized layers go to the mid-M kernel (rows padded to 32, split-K).  Qwen3-8B decode step, HIP graph, `down`
-    # (4096 x 12288) moved: batch 4 4.77 -> 4.67 ms, batch 8 5.18 -> 4.86, batch 16 5.50 -> 5.04; at one row the
-    # step time is the same either way (4.399 vs 4.388 ms), so one row stays on the streaming kernel.
+    # Decode shapes (M <= 16): the weight-streaming kernels (csrc/ops/gemm.hip: one row on the vector ALUs, 2 .. 16 rows
+    # on MFMAs with 128-byte runs per weight row) take everything except long-K layers above eight rows, where the
+    # mid-M kernel (rows padded to 32, split-K) is ahead: 4096 x 12288 at 2 / 4 / 8 / 16 rows 20.6 / 21.3 / 23.5 / 28.8 us
+    # streaming against 23.9 / 23.9 / 24.1 / 24.3 us mid-M; 6144 x 4096 12.6 .. 16.4 against 16.3 .. 16.7.
     # TDIST_DECODE_SPLITK_MIN_M moves the first row count (17 = never); TDIST_DECODE_SPLITK=1 is 1.
-    if (DECODE_SPLITK_MIN_M <= M <= 16 and variant == GEMM_VARIANT and N <= 32768
-            and (K >= 8192 or N * K >= 20_000_000)):
+    if DECODE_SPLITK_MIN_M <= M <= 16 and variant == GEMM_VARIANT and N <= 32768 and K >= 8192:
         return gemm_nt_mid(a, b, out)
     # Otherwise decode shapes stay on the weight-streaming kernel.  Called back to back on ONE 100-270 MB layer the
     # library's 64x16x512 kernel looks faster (6.3-6.6 vs 4-5 TB/s), but there the weights partly sit in
