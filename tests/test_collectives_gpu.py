@@ -137,6 +137,41 @@ def test_fast_allgather(w, mode):
         vc.close()
 
 
+@pytest.mark.parametrize("w", [2, 4])
+@pytest.mark.parametrize("mode", ["pull", "push_2d", "push_2d_ll"])
+def test_fast_allgather_graph_replay(w, mode):
+    """Every form of the all-gather numbers its calls on the device: captured once per rank, replayed with fresh
+    shards, an eager call in between."""
+    vc = VirtualCluster(w, heap_bytes=1 << 26)
+    try:
+        shard = (300, 520)   # bf16 -> 312000 bytes per rank: two slices per peer in the bulk forms
+        ctxs = vc.collective(lambda r, env: create_fast_allgather_context(r, max_buffer_size=shard[0] * shard[1] * 2, env=env))
+        bufs = vc.collective(lambda r, env: env.heap.create_tensor([w, *shard], torch.bfloat16))
+        vc.run(lambda r, env: fast_allgather(bufs[r], ctxs[r], mode=mode))        # odd number of calls before capture
+        graphs = []
+        for r in range(w):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=vc.streams[r]):
+                fast_allgather(bufs[r], ctxs[r], mode=mode)
+            graphs.append(g)
+        for it in range(6):
+            vals = [torch.randn(shard, device="cuda").bfloat16() for _ in range(w)]
+            for r in range(w):
+                bufs[r].zero_()
+                bufs[r][r].copy_(vals[r])
+            torch.cuda.synchronize()
+            if it == 3:
+                vc.run(lambda r, env: fast_allgather(bufs[r], ctxs[r], mode=mode))
+            else:
+                vc.run(lambda r, env: graphs[r].replay())
+            for r in range(w):
+                ctxs[r].check_error()
+                for s_ in range(w):
+                    assert torch.equal(bufs[r][s_], vals[s_])
+    finally:
+        vc.close()
+
+
 @pytest.mark.parametrize("w,with_scale,max_m,hidden", [
     (2, False, 256, 1024), (4, True, 256, 1024), (8, True, 256, 1024),
     (4, True, 1024, 2048),       # ~1 MiB per destination: 8 workgroups per destination

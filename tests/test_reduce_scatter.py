@@ -44,6 +44,49 @@ def test_reduce_scatter_gpu(w, M, N, dtype):
     _run(w, M, N, dtype, "hip")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("w", [2, 4])
+def test_reduce_scatter_graph_replay(w):
+    """The call number lives on the device and the input copy is one buffer: the staging copy and the kernel are
+    captured once per rank and replayed with fresh partial sums, an eager call in between, one rank held back."""
+    M, N, dtype = 512, 1024, torch.bfloat16
+    vc = VirtualCluster(w, heap_bytes=1 << 26)
+    try:
+        ctxs = vc.collective(lambda r, env: create_reduce_scater_2d_ctx(M, N, r, w, w, dtype, env=env))
+        xs = [torch.zeros(M, N, device="cuda", dtype=dtype) for _ in range(w)]
+        outs = [torch.empty(M // w, N, device="cuda", dtype=dtype) for _ in range(w)]
+        vc.run(lambda r, env: reduce_scatter_2d_op(xs[r], ctxs[r], outs[r]))        # odd number of calls before capture
+        graphs = []
+        for r in range(w):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=vc.streams[r]):
+                reduce_scatter_2d_op(xs[r], ctxs[r], outs[r])
+            graphs.append(g)
+        Mr = M // w
+        for it in range(6):
+            for x in xs:
+                x.copy_((torch.rand(M, N, device="cuda") * 2 - 1).to(dtype))
+            for o in outs:
+                o.zero_()
+            torch.cuda.synchronize()
+
+            def step(r, env):
+                if it == 2 and r == 0:
+                    torch.cuda._sleep(10_000_000)
+                if it == 3:
+                    reduce_scatter_2d_op(xs[r], ctxs[r], outs[r])
+                else:
+                    graphs[r].replay()
+
+            vc.run(step)
+            ref = sum(x.float() for x in xs)
+            for r in range(w):
+                ctxs[r].check_error()
+                assert torch.allclose(outs[r].float(), ref[r * Mr:(r + 1) * Mr], atol=3e-2, rtol=2e-2), (r, it)
+    finally:
+        vc.close()
+
+
 def test_ring_reduce_helper():
     x = torch.randn(4 * 8, 16)
     out = torch.empty(8, 16)

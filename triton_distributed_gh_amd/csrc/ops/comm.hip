@@ -32,9 +32,25 @@ struct AgParams {
   long long bytes_per_rank;
   int slices;
   int epoch;
+  // Device-side call numbering (tdist/call_state.hpp): with `state` set, `flags` is the base of BOTH halves (half h
+  // at flags + h * half_stride), half and flag value come from the call number on the device and the last workgroup
+  // re-arms `local_cnt`, so the launch is one kernel node and the same every time.
+  int* state;
+  long long half_stride;
 };
 
+// the call's flag half and flag value (uniform; ends with a workgroup barrier when the numbering is on the device)
+__device__ __forceinline__ int ag_call_begin(AgParams& p, int* s_call) {
+  if (!p.state) return 0;
+  const int call = call_begin(p.state, s_call);
+  p.flags += call_parity(call) * p.half_stride;
+  p.epoch = call_epoch(call);
+  return call;
+}
+
 __global__ __launch_bounds__(512) void allgather_push_kernel(AgParams p) {
+  __shared__ int s_call;
+  const int call = ag_call_begin(p, &s_call);
   const int w = p.ctx.num_ranks, rank = p.ctx.rank;
   const int pi = blockIdx.x / p.slices, slice = blockIdx.x % p.slices;
   const int peer = (rank + 1 + pi) % w;
@@ -55,9 +71,12 @@ __global__ __launch_bounds__(512) void allgather_push_kernel(AgParams p) {
   __syncthreads();
   // every workgroup waits for the shard of "its" peer, so kernel completion = all shards present
   if (slice == 0) wait(p.flags + peer, 1, SCOPE_SYS, SEM_ACQUIRE, p.epoch, p.err);
+  if (p.state) call_end(p.state, call, p.state + 1, p.local_cnt, TDIST_MAX_RANKS);
 }
 
 __global__ __launch_bounds__(512) void allgather_pull_kernel(AgParams p) {
+  __shared__ int s_call;
+  const int call = ag_call_begin(p, &s_call);
   const int w = p.ctx.num_ranks, rank = p.ctx.rank;
   const int pi = blockIdx.x / p.slices, slice = blockIdx.x % p.slices;
   const int peer = (rank + 1 + pi) % w;
@@ -82,6 +101,7 @@ __global__ __launch_bounds__(512) void allgather_pull_kernel(AgParams p) {
   }
   __syncthreads();
   if (slice == 0) wait(p.flags + w + peer, 1, SCOPE_SYS, SEM_RELAXED, p.epoch, p.err);
+  if (p.state) call_end(p.state, call, p.state + 1, p.local_cnt, TDIST_MAX_RANKS);
 }
 
 // LL protocol: staging is symmetric uint64 [w][words_per_rank]; word = (flag << 32) | payload32.
@@ -543,8 +563,11 @@ __global__ __launch_bounds__(512) void p2p_pull_kernel(SymmCtx ctx, char* local_
 }
 
 // ------------------------------------------------------------------------------------------------
+// `state` != null: int32 [2] = {call number, finished workgroups}, zero when created, `local_cnt` zero at the first
+// launch; `flags` is then the base of both halves, `half_stride` their distance in ints, and `epoch` is ignored.
 TDIST_API int tdist_allgather(const SymmCtx* ctx, void* buf, int* flags, int* local_cnt, int* err,
-                              long long bytes_per_rank, int slices, int epoch, int mode, void* stream) {
+                              long long bytes_per_rank, int slices, int epoch, int mode, void* stream, int* state,
+                              long long half_stride) {
   const int w = ctx->num_ranks;
   if (w <= 1) return 0;
   AgParams p;
@@ -556,8 +579,10 @@ TDIST_API int tdist_allgather(const SymmCtx* ctx, void* buf, int* flags, int* lo
   p.bytes_per_rank = bytes_per_rank;
   p.slices = slices > 0 ? slices : 1;
   p.epoch = epoch;
+  p.state = state;
+  p.half_stride = half_stride;
   hipStream_t s = (hipStream_t)stream;
-  TDIST_HIP_TRY(hipMemsetAsync(local_cnt, 0, TDIST_MAX_RANKS * sizeof(int), s));
+  if (!state) TDIST_HIP_TRY(hipMemsetAsync(local_cnt, 0, TDIST_MAX_RANKS * sizeof(int), s));
   if (mode == 0) {
     hipLaunchKernelGGL(allgather_push_kernel, dim3((w - 1) * p.slices), dim3(512), 0, s, p);
   } else {

@@ -10,6 +10,7 @@
 // Buffers are double-buffered by call parity on the host side: a rank can run at most one call
 // ahead of its slowest peer, because finishing call n needs every peer's call-n flag.
 #include "tdist/common.hpp"
+#include "tdist/call_state.hpp"
 #include "tdist/primitives.hpp"
 #include "tdist/shmem_device.hpp"
 
@@ -24,6 +25,13 @@ struct RsParams {
   long long seg_elems;   // elements per rank segment (multiple of 8)
   int epoch;
   int out_fp32;
+  // Device-side call numbering (tdist/call_state.hpp).  With `state` set: `flags` is the base of both halves (half h
+  // at flags + h * 2 w: [0, w) "input published", [w, 2 w) "segment read"), half and flag value come from the call
+  // number on the device, and the input copy is ONE buffer for every call: the kernel does not end before every peer
+  // has read this rank's copy (the last workgroup to finish tells the peers and waits for theirs), so the copy that
+  // stages the next call's input - the next thing on the stream - cannot overtake a reader.  The launch is then one
+  // kernel node, the same every time.
+  int* state;            // {call number, finished workgroups, workgroups done reading}
 };
 
 template <bool IS_BF16>
@@ -45,7 +53,14 @@ __device__ __forceinline__ uint16_t from_f32(float f) {
 
 template <bool IS_BF16>
 __global__ __launch_bounds__(512) void reduce_scatter_kernel(RsParams p) {
+  __shared__ int s_call;
   const int w = p.ctx.num_ranks, rank = p.ctx.rank;
+  int call = 0;
+  if (p.state) {
+    call = call_begin(p.state, &s_call);
+    p.flags += call_parity(call) * 2 * w;
+    p.epoch = call_epoch(call);
+  }
   // Publish: the input copy was written by an earlier kernel of this stream, so it is complete;
   // one system-scope release makes it visible to the peers before the flag.
   if (blockIdx.x == 0 && threadIdx.x < w) {
@@ -86,12 +101,27 @@ __global__ __launch_bounds__(512) void reduce_scatter_kernel(RsParams p) {
       *(uint4*)((uint16_t*)p.out + v * 8) = r;
     }
   }
+  if (p.state) {
+    // loads of the peers' copies have returned (their values were consumed above); the last workgroup to get here
+    // reports "segment read" to every peer and waits until every peer has read this rank's copy
+    __syncthreads();
+    if (threadIdx.x == 0) s_call = atom_add_relaxed_agent(p.state + 2, 1);
+    __syncthreads();
+    if (s_call == (int)gridDim.x - 1) {
+      if ((int)threadIdx.x < w) store_relaxed_system(symm_at(p.ctx, p.flags, (int)threadIdx.x) + w + rank, p.epoch);
+      wait(p.flags + w, w, SCOPE_SYS, SEM_RELAXED, p.epoch, p.err);
+      if (threadIdx.x == 0) store_relaxed_agent(p.state + 2, 0);
+    }
+    call_end(p.state, call, p.state + 1, nullptr, 0);
+  }
 }
 
 // dtype: 0 = bf16, 1 = fp16.  `buf` must hold this rank's full input ([w * seg_elems]) before the
 // launch (written earlier on the same stream).
+// `state` != null: int32 [3], zero when created (see RsParams); `flags` is then int32 [4 w] and `epoch` is ignored.
 TDIST_API int tdist_reduce_scatter(const SymmCtx* ctx, const void* buf, int* flags, void* out, int* err,
-                                   long long seg_elems, int epoch, int out_fp32, int dtype, int num_ctas, void* stream) {
+                                   long long seg_elems, int epoch, int out_fp32, int dtype, int num_ctas, void* stream,
+                                   int* state) {
   TDIST_REQUIRE(seg_elems > 0 && seg_elems % 8 == 0, "segment must be a positive multiple of 8 elements");
   TDIST_REQUIRE(ctx->num_ranks >= 1 && ctx->num_ranks <= TDIST_MAX_RANKS, "bad world size");
   TDIST_REQUIRE((((uintptr_t)buf | (uintptr_t)out) & 15) == 0, "buffers must be 16-byte aligned");
@@ -104,6 +134,7 @@ TDIST_API int tdist_reduce_scatter(const SymmCtx* ctx, const void* buf, int* fla
   p.seg_elems = seg_elems;
   p.epoch = epoch;
   p.out_fp32 = out_fp32;
+  p.state = state;
   long long want = (seg_elems / 8 + 511) / 512;
   int grid = (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
   if (num_ctas > 0 && grid > num_ctas) grid = num_ctas;

@@ -56,6 +56,7 @@ class FastAllGatherContext:
     env: Any = None
     signal_target: int = 0
     ll_state: Optional[torch.Tensor] = None    # LL mode: {call number, finished workgroups} on the device
+    bulk_state: Optional[torch.Tensor] = None  # push / pull modes: the same pair
 
     def check_error(self) -> None:
         if self.scratch is not None and int(self.scratch[16]) != 0:
@@ -73,11 +74,12 @@ def create_fast_allgather_context(rank: int, node: int = 0, num_ranks: int = 1, 
     stage = heap.create_tensor_list([2 * w * words], torch.int64, zero=True)
     scratch = torch.zeros(32, dtype=torch.int32, device=env.device) if env.backend == "hip" else None
     ll_state = torch.zeros(4, dtype=torch.int32, device=env.device) if env.backend == "hip" else None
+    bulk_state = torch.zeros(4, dtype=torch.int32, device=env.device) if env.backend == "hip" else None
     if env.backend == "hip":
         torch.cuda.synchronize()
     if env.cpu_group is not None:
         torch.distributed.barrier(group=env.cpu_group)
-    return FastAllGatherContext(env.rank, w, max_buffer_size, flags, stage, scratch, env, 0, ll_state)
+    return FastAllGatherContext(env.rank, w, max_buffer_size, flags, stage, scratch, env, 0, ll_state, bulk_state)
 
 
 def fast_allgather(symm_buffer: torch.Tensor, ctx: FastAllGatherContext, rank: Optional[int] = None,
@@ -102,21 +104,20 @@ def fast_allgather(symm_buffer: torch.Tensor, ctx: FastAllGatherContext, rank: O
                                                  ctypes.c_uint(0), _lib.stream_handle(), _lib.ptr(ctx.ll_state),
                                                  ctypes.c_longlong(w * words)), "tdist_allgather_ll")
         return symm_buffer
-    forbid_graph_capture("fast_allgather", w)
-    ctx.signal_target += 1
-    epoch = ctx.signal_target
-    if env.backend == "host":
-        return _allgather_host(symm_buffer, ctx, epoch)
-    cs = env.heap.ctx_struct()
-    lib = _lib.hip()
-    kmode = 1 if mode == "pull" else 0
     if mode != "pull" and mode not in _PUSH:
         raise ValueError(f"unknown all-gather mode {mode}")
+    if env.backend == "host":
+        forbid_graph_capture("fast_allgather (host backend)", w)
+        ctx.signal_target += 1
+        return _allgather_host(symm_buffer, ctx, ctx.signal_target)
+    # The bulk forms number their calls on the device too (flag half and flag value from a counter the kernel advances,
+    # the slice counters re-armed by the last workgroup): one kernel node that records into a HIP graph.
+    cs = env.heap.ctx_struct()
     slices = max(1, min(8, bytes_per_rank // (128 * 1024)))
-    half = epoch & 1
-    _lib.check(lib.tdist_allgather(ctypes.byref(cs), _lib.ptr(symm_buffer), _lib.ptr(ctx.flags[ctx.rank][half * 2 * w:]),
-                                   _lib.ptr(ctx.scratch), _lib.ptr(ctx.scratch[16:]),
-                                   ctypes.c_longlong(bytes_per_rank), slices, epoch, kmode, _lib.stream_handle()),
+    _lib.check(_lib.hip().tdist_allgather(ctypes.byref(cs), _lib.ptr(symm_buffer), _lib.ptr(ctx.flags[ctx.rank]),
+                                          _lib.ptr(ctx.scratch), _lib.ptr(ctx.scratch[16:]),
+                                          ctypes.c_longlong(bytes_per_rank), slices, 0, 1 if mode == "pull" else 0,
+                                          _lib.stream_handle(), _lib.ptr(ctx.bulk_state), ctypes.c_longlong(2 * w)),
                "tdist_allgather")
     return symm_buffer
 

@@ -41,18 +41,26 @@ class ReduceScatter2DContext:
     num_sync_sms: int = 0
     num_p2p_sms: int = 0
     num_reduction_sms: int = 0
+    state: Optional[torch.Tensor] = None           # GPU: {call number, finished workgroups, workgroups done reading}
+    dev_flags: Optional[List[torch.Tensor]] = None  # GPU: [rank] -> int32 [4 world] (two halves of published / read flags)
 
     @property
     def nnodes(self) -> int:
         return self.world_size // self.local_world_size
 
     @property
+    def parity(self) -> int:
+        """Input copy of the next call: one buffer on the GPU (the kernel numbers its calls itself and does not end
+        before the copy has been read), alternating on the CPU backend."""
+        return 0 if self.state is not None else self.call_count & 1
+
+    @property
     def scatter_bufs(self):
-        return self.scatter[self.call_count & 1]
+        return self.scatter[self.parity]
 
     def get_scatter_bufs_and_signal_for_each_node(self, input: torch.Tensor, node_id: int = 0):
         M = input.shape[0]
-        return self.scatter_bufs[self.rank][:M], self.flags[self.call_count & 1][self.rank]
+        return self.scatter_bufs[self.rank][:M], self.flags[self.parity][self.rank]
 
     def check_error(self):
         if self.err is not None and int(self.err[0]) != 0:
@@ -71,12 +79,16 @@ def create_reduce_scater_2d_ctx(max_M, N, rank, world_size, local_world_size, dt
         scatter.append(heap.create_tensor_list([max_M, N], dtype, zero=False))
         flags.append(heap.create_tensor_list([world_size], torch.int32, arena="sig"))
     err = torch.zeros(4, dtype=torch.int32, device=env.device) if env.backend == "hip" else None
+    state = dev_flags = None
     if env.backend == "hip":
+        state = torch.zeros(4, dtype=torch.int32, device=env.device)
+        dev_flags = heap.create_tensor_list([4 * world_size], torch.int32, arena="sig")     # see csrc/ops/reduce_scatter.hip
         torch.cuda.synchronize()
     if env.cpu_group is not None:
         torch.distributed.barrier(group=env.cpu_group)
     return ReduceScatter2DContext(max_M, N, rank, world_size, local_world_size, dtype, overlap_with_gemm, scatter, flags,
-                                  err, env, default_num_ctas(env, world_size, 0), num_reduction_sms=num_reduction_sms)
+                                  err, env, default_num_ctas(env, world_size, 0), num_reduction_sms=num_reduction_sms,
+                                  state=state, dev_flags=dev_flags)
 
 
 create_reduce_scatter_2d_ctx = create_reduce_scater_2d_ctx
@@ -94,22 +106,27 @@ def reduce_scatter_2d_op(input: torch.Tensor, ctx: ReduceScatter2DContext, outpu
     if w == 1:
         output.copy_(input)
         return output
-    forbid_graph_capture("reduce_scatter", w)
-    parity = ctx.call_count & 1
+    parity = ctx.parity
     epoch = ctx.call_count % EPOCH_MOD + 1
     ctx.call_count += 1
     mine = ctx.scatter[parity][rank]
     stage = mine.view(-1)[: M * N].view(M, N)
+    if env.backend == "host":
+        forbid_graph_capture("reduce_scatter (host backend)", w)
+        if input.data_ptr() != stage.data_ptr():
+            stage.copy_(input)
+        return _reduce_scatter_host(ctx, parity, epoch, M, N, output)
+    # GPU: the call number lives on the device (ctx.state) and the input copy is one buffer, so copy + kernel are the
+    # same two nodes every time and record into a HIP graph
     if input.data_ptr() != stage.data_ptr():
         stage.copy_(input)
-    if env.backend == "host":
-        return _reduce_scatter_host(ctx, parity, epoch, M, N, output)
     assert input.dtype in _DT and (Mr * N) % 8 == 0, "16-bit dtypes, segment a multiple of 8 elements"
     cs = env.heap.ctx_struct()
     _lib.check(
-        _lib.hip().tdist_reduce_scatter(ctypes.byref(cs), _lib.ptr(mine), _lib.ptr(ctx.flags[parity][rank]),
-                                        _lib.ptr(output), _lib.ptr(ctx.err), ctypes.c_longlong(Mr * N), epoch, 0,
-                                        _DT[input.dtype], ctx.num_ctas, _lib.stream_handle()), "tdist_reduce_scatter")
+        _lib.hip().tdist_reduce_scatter(ctypes.byref(cs), _lib.ptr(mine), _lib.ptr(ctx.dev_flags[rank]),
+                                        _lib.ptr(output), _lib.ptr(ctx.err), ctypes.c_longlong(Mr * N), 0, 0,
+                                        _DT[input.dtype], ctx.num_ctas, _lib.stream_handle(), _lib.ptr(ctx.state)),
+        "tdist_reduce_scatter")
     return output
 
 
