@@ -53,6 +53,9 @@ HIPCC_FLAGS = [
 if os.environ.get("TDIST_SPIN_TIMEOUT_MS"):
     # device-side spin budget in 100 MHz ticks (default in common.hpp: 15 s)
     HIPCC_FLAGS.append(f"-DTDIST_SPIN_TIMEOUT_TICKS={int(os.environ['TDIST_SPIN_TIMEOUT_MS']) * 100000}ull")
+if os.environ.get("TDIST_EXTRA_HIPCC_FLAGS"):
+    # e.g. -DTDIST_EXP_...=1 for an A/B build of one experiment (objects are keyed by their flags)
+    HIPCC_FLAGS += os.environ["TDIST_EXTRA_HIPCC_FLAGS"].split()
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-pthread", f"-I{CSRC / 'include'}"]
 
 
