@@ -66,5 +66,6 @@ run $G/ops/test_mlp_layer.py
 run $G/ops/test_page_attn.py
 run $G/ops/test_allreduce.py 4
 run $G/models/test_qwen3.py 1
+run $G/models/test_qwen3.py 2 graph
 grep -E "^== |^-- rc|✅" "$out" | paste - - - 2>/dev/null | grep -v "rc=0" | head -40
 echo "passed: $(grep -c '^-- rc=0' "$out") of $(grep -c '^== ' "$out")"

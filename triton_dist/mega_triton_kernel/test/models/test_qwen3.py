@@ -1,6 +1,6 @@
 """Whole-model check: one decode step of the mega kernel vs the layer-by-layer torch forward.
 
-    python triton_dist/mega_triton_kernel/test/models/test_qwen3.py [world_size]
+    python triton_dist/mega_triton_kernel/test/models/test_qwen3.py [world_size] [interpreter|graph|auto]
 
 (Scenario of reference python/triton_dist/mega_triton_kernel/test/models/test_qwen3.py.)"""
 import os
@@ -14,5 +14,8 @@ from tests.test_mega import test_qwen3_mega_forward_matches_torch_decode  # noqa
 
 if __name__ == "__main__":
     w = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-    test_qwen3_mega_forward_matches_torch_decode(w)
-    print(f"✅ Qwen3 mega forward matches the torch decode step (world size {w})")
+    backend = sys.argv[2] if len(sys.argv) > 2 else "interpreter"
+    # (the graph back-end's attention lowering wants head size 128)
+    name = "tdist/tiny-dense-d128" if backend == "graph" else "tdist/tiny-dense"
+    test_qwen3_mega_forward_matches_torch_decode(w, name, backend)
+    print(f"✅ Qwen3 mega forward ({backend} back-end) matches the torch decode step (world size {w})")
