@@ -16,6 +16,7 @@ class AutoLLM:
         "meta-llama/Meta-Llama-3-70B": DenseLLM,
         "ByteDance-Seed/Seed-OSS-36B-Instruct": DenseLLM,
         "tdist/tiny-dense": DenseLLM,
+        "tdist/tiny-dense-d128": DenseLLM,
         "tdist/tiny-moe": Qwen3MoE,
     }
 
