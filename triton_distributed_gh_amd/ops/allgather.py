@@ -104,9 +104,9 @@ def fast_allgather(symm_buffer: torch.Tensor, ctx: FastAllGatherContext, rank: O
                                                  ctypes.c_uint(0), _lib.stream_handle(), _lib.ptr(ctx.ll_state),
                                                  ctypes.c_longlong(w * words)), "tdist_allgather_ll")
         return symm_buffer
-    if mode != "pull" and mode not in _PUSH:
+    if mode != "pull" and mode not in _PUSH and mode not in _LL:
         raise ValueError(f"unknown all-gather mode {mode}")
-    if env.backend == "host":
+    if env.backend == "host":          # (one protocol for every mode on the CPU backend)
         forbid_graph_capture("fast_allgather (host backend)", w)
         ctx.signal_target += 1
         return _allgather_host(symm_buffer, ctx, ctx.signal_target)
