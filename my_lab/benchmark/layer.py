@@ -31,7 +31,6 @@ class NativeLinear(torch.nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         lead = x.shape[:-1]
-        y = gemm_nt(x.reshape(-1, x.shape[-1]).contiguous(), self.weight.data)
-        if self.bias is not None:
-            y = y + self.bias
+        y = gemm_nt(x.reshape(-1, x.shape[-1]).contiguous(), self.weight.data,
+                    bias=None if self.bias is None else self.bias.data)
         return y.view(*lead, -1)

@@ -142,6 +142,26 @@ def test_one_row_gemm_on_the_vector_alus(M, N, K, nw, silu):
     torch.testing.assert_close(out.float(), ref, atol=2e-2 * max(ref.abs().max().item(), 1e-3), rtol=2e-2)
 
 
+@pytest.mark.parametrize("M", [1, 2, 9, 16, 40])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (6144, 2048), (12800, 8192), (776, 192), (50251, 1024), (100104, 3072)])
+def test_linear_with_bias(M, N, K):
+    """``gemm_nt(..., bias=)``: the bias rides in the epilogue of the decode kernels (one row on the vector ALUs, 2 .. 16
+    rows on MFMAs, the eight-slice shape of long-K layers included), in the epilogue of the 128 x 256 tiles that take
+    17 .. 128 rows of an LM head with more than 100k columns, and is a separate add elsewhere (odd N: the library's own
+    epilogue); the same numbers as fp32 PyTorch either way."""
+    from triton_distributed_gh_amd.ops.gemm import gemm_nt
+
+    torch.manual_seed(M + N + K)
+    bf = torch.bfloat16
+    x = (torch.rand(M, K, device="cuda") * 2 - 1).to(bf)
+    w = ((torch.rand(N, K, device="cuda") * 2 - 1) * 0.1).to(bf)
+    bias = (torch.rand(N, device="cuda") * 4 - 2).to(bf)
+    out = gemm_nt(x, w, bias=bias)
+    ref = x.float() @ w.float().t() + bias.float()
+    torch.testing.assert_close(out.float(), ref, atol=2e-2 * max(ref.abs().max().item(), 1e-3), rtol=2e-2)
+    assert_close_elementwise(out, ref, what=f"linear + bias {M}x{N}x{K}")
+
+
 @pytest.mark.parametrize("M", [1, 7, 16])
 @pytest.mark.parametrize("I,K", [(1024, 512), (12288, 4096), (1000, 192)])
 def test_decode_gemm_with_silu_mul_epilogue(M, I, K):

@@ -1432,19 +1432,21 @@ __device__ __forceinline__ void mainloop_2ph(const TileArgs& t, char* smem, AccT
 // Register-direct stores of the tile family's accumulators.
 //   store16(row, col, uint4): eight 16-bit results of one row (columns col .. col + 7), scaled by
 //     sa[row] * sb[col ..] when the scale pointers are given (per-row scale of A, per-column scale of B: the
-//     de-quantisation of 8-bit operands), after Frag::val (int32 -> float for int8);
+//     de-quantisation of 8-bit operands), after Frag::val (int32 -> float for int8), plus bias[col ..] (16-bit, the
+//     output type) when that pointer is given;
 //   store32(row, col, uint4 lo, uint4 hi): the same eight results as raw 32-bit accumulator words (int32 output
 //     of an int8 GEMM).
 template <int DT, int MT, int NT, class StoreFn>
 __device__ __forceinline__ void epilogue_direct(const AccT<MT, NT>& acc, const float* sa, const float* sb, int row0,
-                                                int col0, int mrem, int nrem, StoreFn&& store16) {
+                                                int col0, int mrem, int nrem, StoreFn&& store16,
+                                                const uint16_t* bias = nullptr) {
   using F = Frag<DT>;
   const int tid = threadIdx.x;
   const int w = tid >> 6, l = tid & 63;
   const int row = (w >> 2) * (16 * MT) + (l & 15);
   const int col = (w & 3) * (16 * NT) + (l >> 4) * 8;
-  const bool scaled = sa != nullptr || sb != nullptr;
-  float cs[NT / 2][8];
+  const bool scaled = sa != nullptr || sb != nullptr || bias != nullptr;
+  float cs[NT / 2][8], cb[NT / 2][8];
   if (scaled) {
 #pragma unroll
     for (int p = 0; p < NT / 2; ++p)
@@ -1452,6 +1454,12 @@ __device__ __forceinline__ void epilogue_direct(const AccT<MT, NT>& acc, const f
       for (int e = 0; e < 8; ++e) {
         const int c = col + 32 * p + e;
         cs[p][e] = (sb && c < nrem) ? sb[col0 + c] : 1.f;
+        float bv = 0.f;
+        if (bias && c < nrem) {
+          const uint16_t raw = bias[col0 + c];
+          bv = DT == DT_F16 ? (float)__builtin_bit_cast(_Float16, raw) : __builtin_bit_cast(float, (uint32_t)raw << 16);
+        }
+        cb[p][e] = bv;
       }
   }
 #pragma unroll
@@ -1465,12 +1473,12 @@ __device__ __forceinline__ void epilogue_direct(const AccT<MT, NT>& acc, const f
       const f32x4& x1 = NT == 4 ? acc.v[m][2 * p + 1] : acc.v[m][NT - 1];
       uint4 v;
       if (scaled) {
-        const float* c8 = cs[p];
+        const float *c8 = cs[p], *b8 = cb[p];
         using FO = Frag<DT == DT_F16 ? DT_F16 : DT_BF16>;     // output type: f16 for f16 operands, bf16 otherwise
-        v.x = FO::pack2(F::val(x0[0]) * rs * c8[0], F::val(x0[1]) * rs * c8[1]);
-        v.y = FO::pack2(F::val(x0[2]) * rs * c8[2], F::val(x0[3]) * rs * c8[3]);
-        v.z = FO::pack2(F::val(x1[0]) * rs * c8[4], F::val(x1[1]) * rs * c8[5]);
-        v.w = FO::pack2(F::val(x1[2]) * rs * c8[6], F::val(x1[3]) * rs * c8[7]);
+        v.x = FO::pack2(F::val(x0[0]) * rs * c8[0] + b8[0], F::val(x0[1]) * rs * c8[1] + b8[1]);
+        v.y = FO::pack2(F::val(x0[2]) * rs * c8[2] + b8[2], F::val(x0[3]) * rs * c8[3] + b8[3]);
+        v.z = FO::pack2(F::val(x1[0]) * rs * c8[4] + b8[4], F::val(x1[1]) * rs * c8[5] + b8[5]);
+        v.w = FO::pack2(F::val(x1[2]) * rs * c8[6] + b8[6], F::val(x1[3]) * rs * c8[7] + b8[7]);
       } else {
         v.x = F::pack2(x0[0], x0[1]);
         v.y = F::pack2(x0[2], x0[3]);

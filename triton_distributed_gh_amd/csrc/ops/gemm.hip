@@ -189,7 +189,8 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_nt_256_4w32_kernel(const uint
 
 // The tile family (gemm_gfx950.hpp: mainloop_2ph<DT, MT, NT>) as a persistent plain GEMM: BM = 32 MT, BN = 64 NT,
 // 16-bit or 8-bit operands.  OUT32: the raw int32 accumulators of an int8 GEMM are stored instead of 16-bit
-// results.  sa / sb: optional per-row (A) / per-column (B) fp32 scales applied to the 16-bit output.
+// results.  sa / sb: optional per-row (A) / per-column (B) fp32 scales applied to the 16-bit output, bias: optional
+// per-column addend of the output type (SCALED instances only).
 // A, B, lda, ldb, K are in 16-bit units (8-bit operands: two elements per unit).
 //
 // split_k > 1: K is cut into split_k ranges and the work items are (K range, tile) pairs, K range slowest, so the
@@ -201,7 +202,8 @@ template <int DT, int MT, int NT, bool OUT32, bool SCALED = false>
 __global__ __launch_bounds__(THREADS, (2 * TileShape<MT, NT>::WGS_PER_CU)) void gemm_nt_tile_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv, int M, int N, int K,
     long long lda, long long ldb, long long ldc, int group_m, const float* __restrict__ sa,
-    const float* __restrict__ sb, int split_k, float* __restrict__ partial, int* __restrict__ counters, int n_full) {
+    const float* __restrict__ sb, int split_k, float* __restrict__ partial, int* __restrict__ counters, int n_full,
+    const uint16_t* __restrict__ bias) {
   using S = TileShape<MT, NT>;
   using F = Frag<DT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(THREADS, (2 * TileShape<MT, NT>::WGS_PER_CU)) void 
       uint16_t* cbase = (uint16_t*)Cv + (long long)row0 * ldc + col0;
       epilogue_direct<DT, MT, NT>(acc, SCALED ? sa : nullptr, SCALED ? sb : nullptr, row0, col0, mrem, nrem, [&](int r, int c, const uint4& v) {
         if (r < mrem && c < nrem) *(uint4*)(cbase + (long long)r * ldc + c) = v;
-      });
+      }, SCALED ? bias : nullptr);
     }
   }
 }
@@ -521,7 +523,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny_kernel(const uint16_t*
 // four up) rows; the slices are summed through LDS.  Without NORM the activations are read with the weights they
 // meet (L1 / L2 hits).  NORM: the RMSNorm in front of the projection rides along exactly as in
 // gemm_nt_skinny_kernel (h = bf16(X + R), workgroup 0 writes h to Hout, the products use bf16(h * G) staged in LDS and
-// the result is scaled by rsqrt(mean(h^2) + eps)).  Cold weights, one row, MFMA form -> this form: 50 MB 15.7 -> 10.6 us,
+// the result is scaled by rsqrt(mean(h^2) + eps)).  Without NORM and SILU, G may point to a bias [N] that the
+// epilogue adds.  Cold weights, one row, MFMA form -> this form: 50 MB 15.7 -> 10.6 us,
 // 101 MB 25.2 -> 18.0, 201 MB with SiLU 39.9 -> 34.0, 1245 MB 224.5 -> 182.0.  (MR = 2 exists for measurements: with
 // two rows the activation loads double and the MFMA form wins on most shapes; a form that stages two to four rows in
 // LDS and reads them from there was built and measured too - 50 MB 15.1 vs 16.5 us and 101 MB 19.6 vs 23.1 at two
@@ -677,6 +680,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_dot_kernel(const uint16_t* __
       }
     } else {
       const int c = (int)blockIdx.x * 8 + rr;
+      if constexpr (!NORM) {                  // (without the fused norm G is an optional bias [N])
+        if (G && c < N) sum += __builtin_bit_cast(float, (uint32_t)G[c] << 16);
+      }
       if (c < N && m < M) C[(long long)m * ldc + c] = __builtin_bit_cast(uint16_t, (__bf16)sum);
     }
   }
@@ -882,10 +888,14 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny128_kernel(const uint16
   }
   // lanes li and li^1 hold neighbouring columns: the even lane stores both (N, ldc are even)
   const int col = n0 + wk * 8 + li;
+  float bias = 0.f;                            // (without the fused norm G is an optional bias [N])
+  if constexpr (!NORM) {
+    if (G && li < 8 && col < N) bias = IS_BF16 ? __builtin_bit_cast(float, (uint32_t)G[col] << 16) : (float)__builtin_bit_cast(_Float16, G[col]);
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = 4 * lg + r;
-    const float mine = sum[r] * inv[r];
+    const float mine = sum[r] * inv[r] + bias;
     const float other = __shfl_xor(mine, 1);
     if (row < M && li < 8 && col < N && (li & 1) == 0) *(uint32_t*)(C + (long long)row * ldc + col) = F::pack2(mine, other);
   }
@@ -897,9 +907,13 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny128_kernel(const uint16
 // 4096 x 12288 20.6 / 21.3 / 23.5 / 28.8 with WN 2 (25.7 / 27.1 / 29.2 / 32.8), 151936 x 4096 189 / 190 / 197 / 231 with
 // WN 4 (226 / 233 / 248 / 268); WN 1 and eight waves lose on every shape.
 // TDIST_SKINNY128: 0 = keep gemm_nt_skinny_kernel, "<WN><NW>" (e.g. 24) = force a shape.
-static int skinny128_choice(int N) {
+// Long K with a few hundred 64-column blocks (12800 x 8192: 200 workgroups of eight waves, one per compute unit, all
+// done at the same time) runs 36 - 42 us at 2 .. 16 rows with WN 8 / NW 8 against 44 - 52 us with WN 4 / NW 4, whose 400
+// workgroups sit one or two to a compute unit.
+static int skinny128_choice(int N, int K = 0) {
   static const int v = getenv("TDIST_SKINNY128") ? atoi(getenv("TDIST_SKINNY128")) : -1;
   if (v >= 0) return v;
+  if (K >= 8192 && N >= 12288) return 88;
   return N >= 6144 ? 44 : 24;
 }
 
@@ -910,7 +924,10 @@ static bool decode_dot_enabled() {
 }
 
 // Launch of gemm_nt_dot_kernel (bf16).  nw: K slices per workgroup, 0 = four (the best of 1 / 2 / 4 / 8 on every
-// decode shape of a dense model; a wave wants at least one batch of loads, so short K uses fewer).
+// decode shape of a dense model with K >= 4096).  A wave wants at least TWO batches of eight 64-deep steps - the second
+// is requested while the first is multiplied - so shorter K uses fewer slices: LM heads of 151936 x 2048 and
+// 256000 x 3072 run 87.5 and 226 us with two slices against 114 and 290 us with four (one and one and a half batches
+// per wave; scripts/dev/sweep_linear_kernels.py).
 template <int MR, bool SILU, bool NORM>
 static void launch_dot(const uint16_t* X, const uint16_t* W, uint16_t* C, int M, int N, int K, long long ldx,
                        long long ldw, long long ldc, int nw, hipStream_t s, const uint16_t* R = nullptr,
@@ -918,7 +935,7 @@ static void launch_dot(const uint16_t* X, const uint16_t* W, uint16_t* C, int M,
   const int cb = SILU ? 4 : 8;
   const dim3 grid((N + cb - 1) / cb);
   if (nw <= 0) nw = 4;
-  while (nw > 1 && K < 64 * 8 * nw) nw >>= 1;
+  while (nw > 1 && K < 64 * 8 * 2 * nw) nw >>= 1;
   const size_t lds = NORM ? (size_t)MR * ((size_t)K * 2 + 64) : 0;
   if (nw == 1)
     hipLaunchKernelGGL((gemm_nt_dot_kernel<1, MR, SILU, NORM>), grid, dim3(64), lds, s, X, W, C, M, N, K, ldx, ldw, ldc, R, G, Hout, eps);
@@ -956,29 +973,29 @@ TDIST_API int tdist_gemm_nt_dot(const void* X, const void* W, void* C, int M, in
 
 template <bool IS_BF16>
 static void launch_skinny(const void* A, const void* B, void* C, int M, int N, int K, long long lda, long long ldb,
-                          long long ldc, hipStream_t s) {
+                          long long ldc, hipStream_t s, const uint16_t* bias = nullptr) {
   // Column-block size (measured on MI355X, K 2048..12288): with 1-4 tokens the activation loads
   // are negligible and small blocks (more workgroups) win; with more tokens sharing one activation
   // fragment between 2-4 column groups pays as soon as the grid still has a few hundred workgroups.
   if constexpr (IS_BF16) {
     // one row: the vector-ALU form (gemm_nt_dot_kernel) streams the weights 18 - 32 % faster
     if (M == 1 && decode_dot_enabled() && ((uintptr_t)C & 1) == 0) {
-      launch_dot<1, false, false>((const uint16_t*)A, (const uint16_t*)B, (uint16_t*)C, M, N, K, lda, ldb, ldc, 0, s);
+      launch_dot<1, false, false>((const uint16_t*)A, (const uint16_t*)B, (uint16_t*)C, M, N, K, lda, ldb, ldc, 0, s, nullptr, bias);
       return;
     }
   }
-  if (const int ch = skinny128_choice(N); ch > 0 && M >= 2) {
+  if (const int ch = skinny128_choice(N, K); ch > 0 && M >= 2) {
     const uint16_t *a = (const uint16_t*)A, *b = (const uint16_t*)B;
     uint16_t* c = (uint16_t*)C;
     const int wn = ch / 10, nw = ch % 10;
 #define TDIST_S128(WN_, NW_)                                                                                          \
   if (wn == WN_ && nw == NW_) {                                                                                       \
     hipLaunchKernelGGL((gemm_nt_skinny128_kernel<IS_BF16, WN_, NW_>), dim3((N + 8 * WN_ - 1) / (8 * WN_)), dim3(64 * NW_), \
-                       0, s, a, b, c, M, N, K, lda, ldb, ldc, (const uint16_t*)nullptr, (const uint16_t*)nullptr,     \
+                       0, s, a, b, c, M, N, K, lda, ldb, ldc, (const uint16_t*)nullptr, bias,                         \
                        (uint16_t*)nullptr, 0.f);                                                                      \
     return;                                                                                                           \
   }
-    TDIST_S128(1, 4) TDIST_S128(2, 4) TDIST_S128(4, 4) TDIST_S128(1, 8) TDIST_S128(2, 8) TDIST_S128(4, 8)
+    TDIST_S128(1, 4) TDIST_S128(2, 4) TDIST_S128(4, 4) TDIST_S128(1, 8) TDIST_S128(2, 8) TDIST_S128(4, 8) TDIST_S128(8, 8)
 #undef TDIST_S128
   }
   int bn;
@@ -1000,6 +1017,31 @@ static void launch_skinny(const void* A, const void* B, void* C, int M, int N, i
     hipLaunchKernelGGL((gemm_nt_skinny_kernel<IS_BF16, 1, 8>), grid, dim3(512), 0, s, a, b, c, M, N, K, lda, ldb, ldc);
   else
     hipLaunchKernelGGL((gemm_nt_skinny_kernel<IS_BF16, 1, 4>), grid, dim3(256), 0, s, a, b, c, M, N, K, lda, ldb, ldc);
+}
+
+// gemm_nt_skinny128_kernel with a given shape (the entry the probes time; bf16, 2 .. 16 rows): wn column groups of
+// eight per workgroup (1 / 2 / 4 / 8), nw K slices (4 / 8; wn <= nw).
+TDIST_API int tdist_gemm_nt_skinny128(const void* A, const void* B, void* C, int M, int N, int K, long long lda,
+                                      long long ldb, long long ldc, int wn, int nw, void* stream) {
+  TDIST_REQUIRE(M > 0 && M <= 16 && N > 0 && N % 2 == 0, "M must be in [1, 16], N even");
+  TDIST_REQUIRE(K >= 128 && K % 32 == 0, "K must be a multiple of 32 and >= 128");
+  TDIST_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 2 == 0, "row strides must keep the vector alignment");
+  TDIST_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0 && (((uintptr_t)C) & 3) == 0, "operands must be aligned");
+  const uint16_t *a = (const uint16_t*)A, *b = (const uint16_t*)B;
+  uint16_t* c = (uint16_t*)C;
+  hipStream_t s = (hipStream_t)stream;
+#define TDIST_S128(WN_, NW_)                                                                                          \
+  if (wn == WN_ && nw == NW_) {                                                                                       \
+    hipLaunchKernelGGL((gemm_nt_skinny128_kernel<true, WN_, NW_>), dim3((N + 8 * WN_ - 1) / (8 * WN_)), dim3(64 * NW_), 0, \
+                       s, a, b, c, M, N, K, lda, ldb, ldc, (const uint16_t*)nullptr, (const uint16_t*)nullptr,        \
+                       (uint16_t*)nullptr, 0.f);                                                                      \
+    TDIST_HIP_TRY(hipGetLastError());                                                                                 \
+    return 0;                                                                                                         \
+  }
+  TDIST_S128(1, 4) TDIST_S128(2, 4) TDIST_S128(4, 4) TDIST_S128(1, 8) TDIST_S128(2, 8) TDIST_S128(4, 8) TDIST_S128(8, 8)
+#undef TDIST_S128
+  TDIST_REQUIRE(false, "no such shape of the kernel");
+  return 0;
 }
 
 // C[M, N] = rmsnorm(X [+ R]) * G @ W^T for M <= 16, bf16 (see the NORM comment on the kernel); `silu` != 0: W is a
@@ -1345,6 +1387,20 @@ TDIST_API int tdist_gemm_nt_silu_mul(const void* X, const void* W, void* C, int 
   return 0;
 }
 
+// C[M, N] = A W^T + bias for M <= 16, bf16: the weight-streaming decode kernels with the bias [N] added in their
+// epilogue (needs the 128-byte-run kernels: TDIST_SKINNY128=0 and TDIST_DECODE_DOT=0 are refused here).
+TDIST_API int tdist_gemm_nt_decode_bias(const void* A, const void* B, void* C, const void* bias, int M, int N, int K,
+                                        long long lda, long long ldb, long long ldc, void* stream) {
+  TDIST_REQUIRE(M > 0 && M <= 16 && N > 0 && bias, "M must be in [1, 16], bias given");
+  TDIST_REQUIRE(K >= 128 && K % 64 == 0, "K must be a multiple of 64 and >= 128");
+  TDIST_REQUIRE(N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0, "N/lda/ldb/ldc must be multiples of 8");
+  TDIST_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0 && (((uintptr_t)bias) & 1) == 0, "operands must be aligned");
+  TDIST_REQUIRE(skinny128_choice(N, K) > 0 && decode_dot_enabled(), "the kernels with a bias epilogue are switched off");
+  launch_skinny<true>(A, B, C, M, N, K, lda, ldb, ldc, (hipStream_t)stream, (const uint16_t*)bias);
+  TDIST_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // dtype: 0 = bf16, 1 = fp16.  Requires K % 64 == 0, K >= 128, N % 8 == 0, 16-byte aligned rows.
 TDIST_API int tdist_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, long long lda,
                             long long ldb, long long ldc, int dtype, int group_m, void* stream, int variant) {
@@ -1491,11 +1547,26 @@ TDIST_API int tdist_gemm_nt_ex_plan(int M, int N, int K, int dtype, int bm, int 
 // type; ldc in elements of the output type.  scale_a [M] / scale_b [N]: optional fp32 scales of the 16-bit output.
 // bm / bn: 128 or 256, split_k 1..4; 0 = chosen by the cost model (a split is only chosen when `partial` /
 // `counters` are large enough for it: see tdist_gemm_nt_ex_plan).
+// bias [N]: optional addend of the 16-bit output's type (out_kind 0).
+TDIST_API int tdist_gemm_nt_ex_bias(const void* A, const void* B, void* C, int M, int N, int K, long long lda, long long ldb,
+                                    long long ldc, int dtype, int out_kind, const float* scale_a, const float* scale_b,
+                                    const void* bias, int bm, int bn, int split_k, void* partial, long long partial_bytes,
+                                    int* counters, int n_counters, int group_m, void* stream);
+
 TDIST_API int tdist_gemm_nt_ex(const void* A, const void* B, void* C, int M, int N, int K, long long lda, long long ldb,
                                long long ldc, int dtype, int out_kind, const float* scale_a, const float* scale_b, int bm,
                                int bn, int split_k, void* partial, long long partial_bytes, int* counters,
                                int n_counters, int group_m, void* stream) {
+  return tdist_gemm_nt_ex_bias(A, B, C, M, N, K, lda, ldb, ldc, dtype, out_kind, scale_a, scale_b, nullptr, bm, bn, split_k,
+                               partial, partial_bytes, counters, n_counters, group_m, stream);
+}
+
+TDIST_API int tdist_gemm_nt_ex_bias(const void* A, const void* B, void* C, int M, int N, int K, long long lda, long long ldb,
+                                    long long ldc, int dtype, int out_kind, const float* scale_a, const float* scale_b,
+                                    const void* bias, int bm, int bn, int split_k, void* partial, long long partial_bytes,
+                                    int* counters, int n_counters, int group_m, void* stream) {
   TDIST_REQUIRE(M > 0 && N > 0, "empty GEMM");
+  TDIST_REQUIRE(!bias || (out_kind == 0 && ((uintptr_t)bias & 1) == 0), "a bias needs the 16-bit output");
   TDIST_REQUIRE(dtype >= 0 && dtype <= 4, "dtype must be 0..4");
   const int eb = dtype >= 2 ? 1 : 2;                       // bytes per input element
   const int per16 = 2 / eb;
@@ -1515,7 +1586,7 @@ TDIST_API int tdist_gemm_nt_ex(const void* A, const void* B, void* C, int M, int
   }
   if (group_m <= 0) group_m = 8;
   typedef void (*kern_t)(const uint16_t*, const uint16_t*, void*, int, int, int, long long, long long, long long, int,
-                         const float*, const float*, int, float*, int*, int);
+                         const float*, const float*, int, float*, int*, int, const uint16_t*);
   // [dtype][shape: 84, 82, 44, 42]
   static const kern_t table[5][4] = {
       {gemm_nt_tile_kernel<DT_BF16, 8, 4, false>, gemm_nt_tile_kernel<DT_BF16, 8, 2, false>,
@@ -1563,10 +1634,11 @@ TDIST_API int tdist_gemm_nt_ex(const void* A, const void* B, void* C, int M, int
   long long grid = (long long)(num_cus & ~7) * per_cu;
   if (grid < 8) grid = 8;
   if (items < grid) grid = items;
-  const kern_t k = out_kind == 1 ? table32[si] : ((scale_a || scale_b) ? table_sc[dtype][si] : table[dtype][si]);
+  const kern_t k = out_kind == 1 ? table32[si] : ((scale_a || scale_b || bias) ? table_sc[dtype][si] : table[dtype][si]);
   hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(THREADS), lds_of[si] + 16, (hipStream_t)stream, (const uint16_t*)A,
                      (const uint16_t*)B, C, M, N, K16, lda / per16, ldb / per16, ldc, group_m, scale_a, scale_b,
-                     pk.split_k, (float*)partial, counters, pk.split_k > 1 ? pk.n_full : (int)tiles_all);
+                     pk.split_k, (float*)partial, counters, pk.split_k > 1 ? pk.n_full : (int)tiles_all,
+                     (const uint16_t*)bias);
   TDIST_HIP_TRY(hipGetLastError());
   return 0;
 }

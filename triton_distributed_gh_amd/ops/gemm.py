@@ -47,9 +47,45 @@ def gemm_supported(a: torch.Tensor, b: torch.Tensor) -> bool:
             and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and M > 0 and N > 0)
 
 
+# the 128-byte-run decode kernels (the ones with a bias epilogue) are on unless switched off for A/B measurements
+_DECODE_BIAS_KERNELS = os.environ.get("TDIST_SKINNY128", "") != "0" and os.environ.get("TDIST_DECODE_DOT", "") != "0"
+
+
+def _big_head(M: int, N: int, K: int, variant, force_native: bool) -> bool:
+    """17 .. 128 rows against more than 100k columns with K >= 3072: the band ``gemm_nt`` gives to 128 x 256 tiles."""
+    return (16 < M <= 128 and (variant is None or variant == GEMM_VARIANT) and N >= 100_000 and K >= 3072
+            and not force_native)
+
+
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, group_m: Optional[int] = None,
-            force_native: bool = False, variant: Optional[int] = None) -> torch.Tensor:
+            force_native: bool = False, variant: Optional[int] = None, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``a [M, K] @ b [N, K]^T`` (+ ``bias [N]``) -> [M, N] on the gfx950 kernels; shapes they do not take run on
+    ``torch.matmul``.  The bias is added in the epilogue of the weight-streaming decode kernels (bf16, M <= 16) and as
+    a separate in-place add everywhere else."""
     assert a.shape[1] == b.shape[1], f"K mismatch: {tuple(a.shape)} vs {tuple(b.shape)}"
+    if bias is not None:
+        M, K = a.shape
+        N = b.shape[0]
+        assert bias.shape == (N,) and bias.dtype == a.dtype, "bias must be [N] of the operands' type"
+        if out is None:
+            out = torch.empty((M, N), dtype=a.dtype, device=a.device)
+        fused = (_DECODE_BIAS_KERNELS and M <= 16 and a.dtype == torch.bfloat16 and gemm_supported(a, b)
+                 and bias.is_contiguous() and out.stride(1) == 1 and out.stride(0) % 8 == 0 and out.data_ptr() % 16 == 0
+                 and not (DECODE_SPLITK_MIN_M <= M and N < 12288 and K >= 8192)
+                 and not (DECODE_LIB_BYTES > 0 and K >= 4096 and N * K * 2 >= DECODE_LIB_BYTES))
+        if fused:
+            _lib.check(
+                _lib.hip().tdist_gemm_nt_decode_bias(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), _lib.ptr(bias), M, N, K,
+                                                     ctypes.c_longlong(a.stride(0)), ctypes.c_longlong(b.stride(0)),
+                                                     ctypes.c_longlong(out.stride(0)), _lib.stream_handle()),
+                "tdist_gemm_nt_decode_bias")
+            return out
+        if not gemm_supported(a, b) and not force_native:
+            return torch.addmm(bias, a, b.t(), out=out)       # (the library adds it in its own epilogue)
+        if _big_head(M, N, K, variant, force_native) and gemm_tiles_supported(a, b) and bias.is_contiguous():
+            return gemm_nt_tiles(a, b, out, bm=128, bn=256, group_m=group_m, bias=bias)
+        out = gemm_nt(a, b, out, group_m, force_native, variant)
+        return out.add_(bias)
     if group_m is None:
         group_m = tuning.get("gemm.group_m", 8)
     if variant is None:
@@ -69,6 +105,12 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     # TDIST_MID_GEMM=lib hands the band to the library instead (A/B comparisons).
     # Up to 64 rows the mid-M kernel also beats the 256x256 tile at any width (LM heads: 42 vs 76 us at
     # 32768 x 4096, 144 vs 173 us at 151936 x 2048), up to 128 rows below ~100k columns.
+    # LM heads with more than 100k columns and K >= 3072 at 17 .. 128 rows: 128 x 256 tiles of the tile family stream the
+    # weights once with half the padding of a 256-row tile and none of the split-K traffic (128256 x 4096 at 32 / 64 /
+    # 128 rows: 183 / 188 / 200 us against 229 / 235 / 257 us mid-M and 201 / 213 / 237 us hipBLASLt; 256000 x 3072:
+    # 279 / 300 / 326 against 303 / 342 / 388 and 283 / 298 / 325; scripts/dev/sweep_linear_kernels.py).
+    if _big_head(M, N, K, variant, force_native) and gemm_tiles_supported(a, b):
+        return gemm_nt_tiles(a, b, out, bm=128, bn=256, group_m=group_m)
     if M > 16 and variant == GEMM_VARIANT and (-(-M // 256) * -(-N // 256) < 128 or M <= 64
                                                or (M <= 128 and N < 100_000)):
         if MID_GEMM == "lib" and not force_native:
@@ -80,8 +122,10 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     # on MFMAs with 128-byte runs per weight row) take everything except long-K layers above eight rows, where the
     # mid-M kernel (rows padded to 32, split-K) is ahead: 4096 x 12288 at 2 / 4 / 8 / 16 rows 20.6 / 21.3 / 23.5 / 28.8 us
     # streaming against 23.9 / 23.9 / 24.1 / 24.3 us mid-M; 6144 x 4096 12.6 .. 16.4 against 16.3 .. 16.7.
+    # From 12288 columns on the streaming kernel with 64-column blocks and eight K slices is ahead again (12800 x 8192 at
+    # 16 rows: 42 us against 48 us mid-M, cold weights).
     # TDIST_DECODE_SPLITK_MIN_M moves the first row count (17 = never); TDIST_DECODE_SPLITK=1 is 1.
-    if DECODE_SPLITK_MIN_M <= M <= 16 and variant == GEMM_VARIANT and N <= 32768 and K >= 8192:
+    if DECODE_SPLITK_MIN_M <= M <= 16 and variant == GEMM_VARIANT and N < 12288 and K >= 8192:
         return gemm_nt_mid(a, b, out)
     # Otherwise decode shapes stay on the weight-streaming kernel.  Called back to back on ONE 100-270 MB layer the
     # library's 64x16x512 kernel looks faster (6.3-6.6 vs 4-5 TB/s), but there the weights partly sit in
@@ -145,7 +189,7 @@ def gemm_tiles_supported(a: torch.Tensor, b: torch.Tensor) -> bool:
 def gemm_nt_tiles(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None,
                   scale_a: Optional[torch.Tensor] = None, scale_b: Optional[torch.Tensor] = None,
                   out_dtype: Optional[torch.dtype] = None, bm: int = 0, bn: int = 0, split_k: int = 0,
-                  group_m: Optional[int] = None) -> torch.Tensor:
+                  group_m: Optional[int] = None, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``a @ b^T`` on the tile family (csrc/ops/gemm.hip: gemm_nt_tile_kernel): 256x256, 256x128, 128x256 or 128x128
     macro-tiles (``bm`` / ``bn``; 0 = cost model), optionally with K cut into ``split_k`` ranges joined wait-free
     inside the launch (0 = cost model), bf16 / fp16 / fp8 (OCP e4m3, e5m2) / int8 operands.
@@ -154,6 +198,7 @@ def gemm_nt_tiles(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] 
     multiplied by ``scale_a`` [M] (per row of a) and ``scale_b`` [N] (per row of b) fp32 scales in the epilogue -
     the de-quantisation of per-token / per-channel quantised operands; ``out_dtype=torch.int32`` returns the exact
     int32 accumulators of an int8 GEMM.  fp8 runs on the 128-deep MFMA (twice the bf16 rate), int8 on the 64-deep one.
+    ``bias`` [N] of the output type is added to the 16-bit output in the same epilogue.
 
     Role in the reference: the dtype-generic consumer GEMM of kernels/amd/all_gather_gemm.py:127-245 (``--dtype
     float8_e4m3fn | float8_e5m2 | s8`` of test/amd/test_ag_gemm_intra_node.py:122-136) and its BM / BN autotune space."""
@@ -176,6 +221,7 @@ def gemm_nt_tiles(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] 
     assert out.stride(0) % (4 if want32 else 8) == 0 and out.data_ptr() % 16 == 0
     for sc, n in ((scale_a, M), (scale_b, N)):
         assert sc is None or (sc.dtype == torch.float32 and sc.is_contiguous() and sc.numel() == n and not want32)
+    assert bias is None or (bias.dtype == out_dtype and bias.is_contiguous() and bias.numel() == N and not want32)
     if group_m is None:
         group_m = tuning.get("gemm.group_m", 8)
     lib = _lib.hip()
@@ -186,13 +232,15 @@ def gemm_nt_tiles(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] 
                                          ctypes.byref(ncnt), ctypes.byref(nfull)), "tdist_gemm_nt_ex_plan")
     ws = _tile_workspace(a.device, pbytes.value, ncnt.value) if ps.value > 1 else None
     _lib.check(
-        lib.tdist_gemm_nt_ex(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), M, N, K, ctypes.c_longlong(a.stride(0)),
-                             ctypes.c_longlong(b.stride(0)), ctypes.c_longlong(out.stride(0)), _DT_EX[a.dtype],
-                             1 if want32 else 0, _lib.ptr(scale_a) if scale_a is not None else ctypes.c_void_p(0),
-                             _lib.ptr(scale_b) if scale_b is not None else ctypes.c_void_p(0), pbm.value, pbn.value,
-                             ps.value, _lib.ptr(ws[0]) if ws else ctypes.c_void_p(0),
-                             ctypes.c_longlong(ws[0].numel() if ws else 0), _lib.ptr(ws[1]) if ws else ctypes.c_void_p(0),
-                             ws[1].numel() if ws else 0, group_m, _lib.stream_handle()), "tdist_gemm_nt_ex")
+        lib.tdist_gemm_nt_ex_bias(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), M, N, K, ctypes.c_longlong(a.stride(0)),
+                                  ctypes.c_longlong(b.stride(0)), ctypes.c_longlong(out.stride(0)), _DT_EX[a.dtype],
+                                  1 if want32 else 0, _lib.ptr(scale_a) if scale_a is not None else ctypes.c_void_p(0),
+                                  _lib.ptr(scale_b) if scale_b is not None else ctypes.c_void_p(0),
+                                  _lib.ptr(bias) if bias is not None else ctypes.c_void_p(0), pbm.value, pbn.value,
+                                  ps.value, _lib.ptr(ws[0]) if ws else ctypes.c_void_p(0),
+                                  ctypes.c_longlong(ws[0].numel() if ws else 0),
+                                  _lib.ptr(ws[1]) if ws else ctypes.c_void_p(0), ws[1].numel() if ws else 0, group_m,
+                                  _lib.stream_handle()), "tdist_gemm_nt_ex_bias")
     return out
 
 

@@ -61,6 +61,12 @@ class VirtualCluster:
     def run(self, fn: Callable, sync: bool = True) -> List:
         outs = [None] * self.world_size
         if self.backend == "hip":
+            # The rank streams do not synchronise with the caller's stream (and must not wait for an event of it: see
+            # timed_run), so whatever the caller queued there - the fill of a fresh context's counters, the kernels
+            # that produce the inputs - has to be complete before a rank's kernel may read it.  Without this wait a
+            # fused kernel occasionally started while the bf16 conversion of its freshly drawn input was still
+            # running: one wrong result in several thousand test runs.
+            torch.cuda.current_stream().synchronize()
             for r, env in enumerate(self.envs):
                 with torch.cuda.stream(self.streams[r]), use_env(env):
                     outs[r] = fn(r, env)
@@ -101,6 +107,7 @@ class VirtualCluster:
         assert self.backend == "hip"
         import time
 
+        torch.cuda.current_stream().synchronize()        # (the inputs: see run())
         gate = _pool_streams("gate", 1)[0]
         ev_gate = torch.cuda.Event()
         with torch.cuda.stream(gate):
