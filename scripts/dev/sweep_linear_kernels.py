@@ -28,6 +28,9 @@ def candidates(M, N, K):
                 _lib.ptr(x), _lib.ptr(w), _lib.ptr(o), M, N, K, LL(K), LL(K), LL(N), wn, nw, _lib.stream_handle()), "s128"))(wn, nw)
     if M >= 2:
         c["mid"] = lambda x, w, o: gemm_nt_mid(x, w, o)
+    if M >= 17 and os.environ.get("MID_FORMS") == "1":
+        for wn, sp in ((1, 1), (1, 2), (2, 2), (2, 3), (2, 4), (1, 4)):
+            c[f"mid-w{wn}s{sp}"] = (lambda wn, sp: lambda x, w, o: gemm_nt_mid(x, w, o, wn=wn, splits=sp))(wn, sp)
     if M >= 32:
         for bm, bn in ((128, 128), (128, 256), (256, 256)):
             c[f"tile{bm}x{bn}"] = (lambda bm, bn: lambda x, w, o: gemm_nt_tiles(x, w, o, bm=bm, bn=bn))(bm, bn)

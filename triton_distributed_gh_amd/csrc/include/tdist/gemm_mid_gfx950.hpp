@@ -35,7 +35,17 @@ inline MidPlan mid_plan(int M, int N, int K, int num_cus, int force_wn, int forc
   // at 16*MT = 128 rows the ring (96 KiB) admits one workgroup per CU anyway, so a grid beyond the CU count
   // runs in two rounds.  Wide strips win once the narrow form no longer fits one round (N >= 16384:
   // 43.9 vs 54.7 us at 24576 x 4096, M = 128).
-  pl.wn = ((N + 63) / 64) * pl.passes > num_cus ? 2 : 1;
+  // Two refinements from cold-weight sweeps of LM-head sized layers (scripts/dev/sweep_linear_kernels.py, MID_FORMS=1):
+  //  * up to 64 rows two narrow workgroups share a CU (64 KiB of ring each), so a narrow grid of exactly two per CU
+  //    keeps twice the bytes in flight of one wide workgroup per CU: 32768 x 4096 at 32 / 64 rows 55 / 61 us narrow
+  //    against 66 / 66 us wide (a grid of one and a half per CU does not gain: 24576 x 4096 48 / 54 against 48 / 50);
+  //  * at 65 - 128 rows a narrow workgroup re-reads two bytes of activations per byte of weights, so when the narrow
+  //    grid would fill more than half of the CUs without any K split, the wide form with K cut in two (same number
+  //    of workgroups, half the activation traffic) is ahead: 12800 x 8192 at 128 rows 65 us against 72.
+  const int narrow = ((N + 63) / 64) * pl.passes;
+  pl.wn = narrow > num_cus ? 2 : 1;
+  if (pl.mt <= 4 && narrow == 2 * num_cus) pl.wn = 1;
+  if (pl.mt == 8 && narrow <= num_cus && 2 * narrow > num_cus && nst >= 8) pl.wn = 2;
   if (force_wn == 1 || force_wn == 2) pl.wn = force_wn;
   pl.ncb = (N + 64 * pl.wn - 1) / (64 * pl.wn);
   int splits = num_cus / (pl.ncb * pl.passes);
