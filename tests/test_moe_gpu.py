@@ -137,6 +137,45 @@ def test_moe_decode_kernels_match_fp32_reference(n, H, I, E, topk):
         torch.testing.assert_close(out.float(), ref, atol=2e-2 * ref.abs().max().item(), rtol=2e-2)
 
 
+@pytest.mark.parametrize("n,H,I,E,topk", [(12, 2048, 768, 128, 8), (17, 2048, 768, 128, 8), (40, 2048, 768, 128, 8), (256, 1024, 96, 64, 8),
+                                          (100, 512, 2304, 16, 4), (64, 512, 256, 8, 2), (33, 1056, 160, 12, 5)])
+def test_moe_block_grouped_by_expert_in_blocks_of_sixteen(n, H, I, E, topk):
+    """17 .. 256 tokens: pairs sorted by expert into sixteen-row blocks, gate_up + SiLU and down per block, top-k sum
+    (``moe_decode_fwd`` above ``MOE_DECODE_MAX_TOKENS`` tokens) against fp32 PyTorch; experts with no token, with a
+    partial block and with several blocks all occur.  An expert id out of range contributes nothing."""
+    from triton_distributed_gh_amd.ops import moe as moe_ops
+    from triton_distributed_gh_amd.ops.moe import moe_decode_fwd, moe_decode_supported
+
+    torch.manual_seed(n * 10 + topk)
+    dev, bf = "cuda", torch.bfloat16
+    x = (torch.rand(n, H, device=dev) * 2 - 1).to(bf)
+    gate_up = ((torch.rand(E, 2 * I, H, device=dev) * 2 - 1) * 0.05).to(bf)
+    down = ((torch.rand(E, H, I, device=dev) * 2 - 1) * 0.05).to(bf)
+    # skewed routing: low expert indices are chosen more often, the last expert never
+    pick = torch.rand(n, E - 1, device=dev) * torch.linspace(1.0, 0.2, E - 1, device=dev)
+    ids = torch.topk(pick, topk, dim=1).indices.int()
+    wts = torch.rand(n, topk, device=dev) + 0.1
+    wts = wts / wts.sum(-1, keepdim=True)
+    assert moe_decode_supported(x, gate_up, down, topk) and moe_ops._group16_takes(n, topk, E, I)
+    xf = x.float()
+    ref = torch.zeros(n, H, device=dev)
+    for e in range(E):
+        tok, k = torch.where(ids == e)
+        if tok.numel() == 0:
+            continue
+        gu = xf[tok] @ gate_up[e].float().t()
+        h = (torch.nn.functional.silu(gu[:, :I].to(bf).float()) * gu[:, I:].to(bf).float()).to(bf).float()
+        ref.index_add_(0, tok, (h @ down[e].float().t()) * wts[tok, k, None])
+    out = moe_decode_fwd(x, ids, wts, gate_up, down)
+    torch.testing.assert_close(out.float(), ref, atol=2e-2 * ref.abs().max().item(), rtol=2e-2)
+    bad = ids.clone()
+    bad[1, 0] = 0x7fffffff
+    bad[2, 1] = -3
+    out2 = moe_decode_fwd(x, bad, wts, gate_up, down)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out2.float()).all() and torch.equal(out2[0], out[0]) and torch.equal(out2[3:], out[3:])
+
+
 @pytest.mark.parametrize("n,E,k,renorm", [(1, 128, 8, True), (7, 128, 8, False), (33, 8, 2, True), (4, 1000, 10, True),
                                           (300, 64, 6, True), (2, 4, 4, True)])
 def test_router_epilogue_matches_torch_topk(n, E, k, renorm):

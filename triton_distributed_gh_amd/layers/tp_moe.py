@@ -20,7 +20,7 @@ from ..ops import elementwise
 from ..ops.allgather import create_fast_allgather_context, fast_allgather
 from ..ops.allreduce import all_reduce, create_allreduce_ctx
 from ..ops.gemm import gemm_nt, gemm_supported
-from ..ops.moe import (ag_group_gemm, create_ag_group_gemm_context, create_moe_rs_context, MOE_DECODE_MAX_TOKENS, moe_decode_fwd,
+from ..ops.moe import (ag_group_gemm, create_ag_group_gemm_context, create_moe_rs_context, MOE_DECODE_MAX_TOKENS, MOE_GROUP16_MAX_TOKENS, MOE_GROUP16_ROWS_PER_EXPERT, moe_decode_fwd,
                        moe_decode_supported, moe_route, moe_route_supported, run_moe_reduce_rs)
 from ..utils.distributed import get_env
 from .tp_mlp import shard_local
@@ -102,7 +102,7 @@ class TP_MoE:
         # decode path on several ranks (``_decode_fwd_tp``): the tokens' rows are all-gathered (low-latency form),
         # every rank runs ALL tokens against its slice of the experts' intermediate dimension, partial sums are
         # all-reduced
-        self.dec_per = max(1, MOE_DECODE_MAX_TOKENS // w)
+        self.dec_per = max(1, min(M, MOE_GROUP16_MAX_TOKENS) // w)
         self.dec_x_ctx = self.dec_x_buf = self.dec_ar_ctx = None
         if w > 1 and env.backend == "hip":
             xb = self.dec_per * self.hidden_size * self.dtype.itemsize
@@ -212,13 +212,23 @@ class TP_MoE:
         tot = all_reduce(part, ctx=self.dec_ar_ctx, output=torch.empty_like(part))
         return tot[self.rank * n_local:(self.rank + 1) * n_local]
 
+    def _decode_tp_ok(self, x2: torch.Tensor) -> bool:
+        """``moe_decode_supported`` for the gathered batch (``world_size`` times this rank's rows)."""
+        n_all = x2.shape[0] * self.world_size
+        E, two_ip, H = self.gate_up_proj.shape
+        if not moe_decode_supported(x2[:1], self.gate_up_proj, self.down_proj, self.top_k):
+            return False
+        return n_all <= MOE_DECODE_MAX_TOKENS or (n_all <= MOE_GROUP16_MAX_TOKENS and
+                                                  n_all * self.top_k <= MOE_GROUP16_ROWS_PER_EXPERT * E and E <= 1024
+                                                  and two_ip // 2 >= 64)
+
     @torch.inference_mode()
     def dist_triton_fwd(self, x: torch.Tensor):
         """x token-sharded [bsz / w, seq, H] (or [tokens / w, H]) -> same shape."""
         shape = x.shape
         x2 = x.reshape(-1, shape[-1]).contiguous()
         if (self.world_size > 1 and getattr(self, "dec_x_buf", None) is not None and x2.shape[0] <= self.dec_per
-                and x2.shape[1] % 2 == 0 and moe_decode_supported(x2, self.gate_up_proj, self.down_proj, self.top_k)):
+                and x2.shape[1] % 2 == 0 and self._decode_tp_ok(x2)):
             return self._decode_fwd_tp(x2).reshape(shape)
         wts, ids = self._route(x2, fused=True)
         if self.world_size == 1 and moe_decode_supported(x2, self.gate_up_proj, self.down_proj, self.top_k):

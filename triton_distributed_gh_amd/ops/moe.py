@@ -468,15 +468,46 @@ def run_moe_reduce_rs(x: torch.Tensor, weights: torch.Tensor, chosen_experts: to
 MOE_DECODE_MAX_TOKENS = int(os.environ.get("TDIST_MOE_DECODE_MAX_TOKENS", "16"))
 
 
-def moe_decode_supported(x: torch.Tensor, gate_up: torch.Tensor, down: torch.Tensor, topk: int) -> bool:
-    """Shapes the two decode kernels take: bf16 on the GPU, at most ``MOE_DECODE_MAX_TOKENS`` tokens, expert weights
-    ``gate_up [E, 2 Ip, H]`` / ``down [E, H, Ip]`` contiguous, H a multiple of 32, Ip of 32."""
+# Above MOE_DECODE_MAX_TOKENS tokens the (token, expert) pairs are grouped by expert into blocks of sixteen rows
+# (csrc/ops/gemm.hip: tdist_moe_group16_fwd) as long as an expert gets about two such blocks at most; from there on the
+# grouped GEMM on 256-row tiles (ag_group_gemm + run_moe_reduce_rs) takes over.
+MOE_GROUP16_MAX_TOKENS = int(os.environ.get("TDIST_MOE_GROUP16_MAX_TOKENS", "256"))
+MOE_GROUP16_ROWS_PER_EXPERT = int(os.environ.get("TDIST_MOE_GROUP16_ROWS_PER_EXPERT", "32"))
+# -1: the grouped form also takes MOE_DECODE_MAX_TOKENS tokens or fewer once the pairs outnumber half of the experts
+# (tokens then share experts often enough that streaming an expert once per block beats once per pair: Qwen3-30B-A3B,
+# 128 experts, top-8: 8 tokens 115 vs 116 us, 12 tokens 161 vs 143, 16 tokens 207 vs 163); 0: never below the limit;
+# 1: always
+MOE_GROUP16 = int(os.environ.get("TDIST_MOE_GROUP16", "-1"))
+
+
+def _group16_takes(n: int, topk: int, E: int, Ip: int) -> bool:
+    """Whether ``moe_decode_fwd`` runs ``n`` tokens on the expert-grouped kernels."""
+    able = (E <= 1024 and Ip >= 64 and n <= MOE_GROUP16_MAX_TOKENS and n * topk <= MOE_GROUP16_ROWS_PER_EXPERT * E)
+    if not able:
+        return False
+    if n > MOE_DECODE_MAX_TOKENS:
+        return True
+    return MOE_GROUP16 == 1 or (MOE_GROUP16 < 0 and n * topk > max(E // 2, topk))
+
+
+def moe_decode_supported(x: torch.Tensor, gate_up: torch.Tensor, down: torch.Tensor, topk: int,
+                         max_tokens: Optional[int] = None) -> bool:
+    """Shapes ``moe_decode_fwd`` takes: bf16 on the GPU, expert weights ``gate_up [E, 2 Ip, H]`` / ``down [E, H, Ip]``
+    contiguous, H a multiple of 32, Ip of 32, and at most ``MOE_DECODE_MAX_TOKENS`` tokens (one launch pair over the
+    (token, expert) pairs) or at most ``MOE_GROUP16_MAX_TOKENS`` tokens with on average no more than
+    ``MOE_GROUP16_ROWS_PER_EXPERT`` rows per expert (pairs grouped by expert in blocks of sixteen).  ``max_tokens``
+    lowers the token limit (callers whose buffers are sized for fewer rows)."""
     if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.bfloat16 == gate_up.dtype == down.dtype):
         return False
     n, H = x.shape
     E, two_ip, H2 = gate_up.shape
     Ip = two_ip // 2
-    return (0 < n <= MOE_DECODE_MAX_TOKENS and H2 == H and tuple(down.shape) == (E, H, Ip) and H % 32 == 0 and H >= 128
+    if max_tokens is not None and n > max_tokens:
+        return False
+    few = 0 < n <= MOE_DECODE_MAX_TOKENS
+    grouped = (MOE_DECODE_MAX_TOKENS < n <= MOE_GROUP16_MAX_TOKENS and n * topk <= MOE_GROUP16_ROWS_PER_EXPERT * E
+               and E <= 1024 and Ip >= 64 and H % 4 == 0)
+    return ((few or grouped) and H2 == H and tuple(down.shape) == (E, H, Ip) and H % 32 == 0 and H >= 128
             and Ip % 32 == 0 and gate_up.is_contiguous() and down.is_contiguous() and x.is_contiguous()
             and n * topk <= 65535)
 
@@ -503,9 +534,22 @@ def moe_decode_fwd(x: torch.Tensor, topk_ids: torch.Tensor, topk_weights: torch.
     Ip = gate_up.shape[1] // 2
     ids = topk_ids.to(torch.int32).contiguous()
     wts = topk_weights.to(torch.float32).contiguous()
-    hbuf = torch.empty((n * k, Ip), dtype=x.dtype, device=x.device)
     out = torch.empty((n, H), dtype=x.dtype, device=x.device)
     lib = _lib.hip()
+    if down_form is None and gate_up_form is None and _group16_takes(n, k, gate_up.shape[0], Ip):
+        # several tokens per expert: four launches over the pairs sorted by expert in blocks of sixteen rows, every
+        # expert's weights streamed once per block (Qwen3-30B-A3B layer, 32 / 128 tokens: see profiles/r3/moe_group16.md)
+        E = gate_up.shape[0]
+        nb_max = n * k // 16 + E
+        hbuf = torch.empty((nb_max * 16, Ip), dtype=x.dtype, device=x.device)
+        y = torch.empty((n * k, H), dtype=torch.float32, device=x.device)
+        idx = torch.empty(nb_max * 17 + 2, dtype=torch.int32, device=x.device)
+        _lib.check(lib.tdist_moe_group16_fwd(_lib.ptr(x), _lib.ptr(ids), _lib.ptr(wts), _lib.ptr(gate_up), _lib.ptr(down),
+                                             _lib.ptr(hbuf), _lib.ptr(y), _lib.ptr(out), _lib.ptr(idx),
+                                             _lib.ptr(idx[nb_max * 16:]), _lib.ptr(idx[nb_max * 17:]), n, k, H, Ip, E, nb_max,
+                                             _lib.stream_handle()), "tdist_moe_group16_fwd")
+        return out
+    hbuf = torch.empty((n * k, Ip), dtype=x.dtype, device=x.device)
     _lib.check(lib.tdist_moe_decode_gate_up(_lib.ptr(x), _lib.ptr(ids), _lib.ptr(gate_up), _lib.ptr(hbuf), n, k, Ip, H,
                                             gate_up.shape[0], MOE_GATE_UP_FORM if gate_up_form is None else gate_up_form,
                                             _lib.stream_handle()), "tdist_moe_decode_gate_up")
