@@ -192,10 +192,10 @@ def test_tp_moe_matches_expert_loop(w, T, H, I, E, topk):
 
 
 @pytest.mark.parametrize("w,T,H,I,E,topk", [(2, 8, 512, 512, 8, 2), (4, 16, 1024, 1024, 16, 4), (2, 2, 512, 512, 8, 8),
-                                            (2, 64, 512, 512, 8, 2), (4, 128, 1024, 1024, 16, 4)])
+                                            (2, 64, 512, 512, 8, 2), (4, 96, 1024, 1024, 16, 4)])
 def test_tp_moe_decode_path_on_several_ranks(w, T, H, I, E, topk):
     """A decode-sized batch on a tensor-parallel MoE layer: rows all-gathered, every rank runs all tokens against its
-    slice of the experts with the decode launches (per pair, or - the cases with 64 and 128 tokens - grouped by expert
+    slice of the experts with the decode launches (per pair, or - the cases with 64 and 96 tokens - grouped by expert
     in blocks of sixteen rows), partial sums all-reduced - eagerly and replayed from a graph, with a larger
     (grouped-GEMM) call in between."""
     from triton_distributed_gh_amd.ops import moe as moe_ops

@@ -137,7 +137,7 @@ def test_moe_decode_kernels_match_fp32_reference(n, H, I, E, topk):
         torch.testing.assert_close(out.float(), ref, atol=2e-2 * ref.abs().max().item(), rtol=2e-2)
 
 
-@pytest.mark.parametrize("n,H,I,E,topk", [(12, 2048, 768, 128, 8), (17, 2048, 768, 128, 8), (40, 2048, 768, 128, 8), (256, 1024, 96, 64, 8),
+@pytest.mark.parametrize("n,H,I,E,topk", [(12, 2048, 768, 128, 8), (17, 2048, 768, 128, 8), (40, 2048, 768, 128, 8), (200, 1024, 96, 64, 8),
                                           (100, 512, 2304, 16, 4), (64, 512, 256, 8, 2), (33, 1056, 160, 12, 5)])
 def test_moe_block_grouped_by_expert_in_blocks_of_sixteen(n, H, I, E, topk):
     """17 .. 256 tokens: pairs sorted by expert into sixteen-row blocks, gate_up + SiLU and down per block, top-k sum
@@ -156,7 +156,7 @@ def test_moe_block_grouped_by_expert_in_blocks_of_sixteen(n, H, I, E, topk):
     ids = torch.topk(pick, topk, dim=1).indices.int()
     wts = torch.rand(n, topk, device=dev) + 0.1
     wts = wts / wts.sum(-1, keepdim=True)
-    assert moe_decode_supported(x, gate_up, down, topk) and moe_ops._group16_takes(n, topk, E, I)
+    assert moe_decode_supported(x, gate_up, down, topk) and moe_ops._group16_takes(n, topk, E, I, H)
     xf = x.float()
     ref = torch.zeros(n, H, device=dev)
     for e in range(E):

@@ -20,7 +20,7 @@ from ..ops import elementwise
 from ..ops.allgather import create_fast_allgather_context, fast_allgather
 from ..ops.allreduce import all_reduce, create_allreduce_ctx
 from ..ops.gemm import gemm_nt, gemm_supported
-from ..ops.moe import (ag_group_gemm, create_ag_group_gemm_context, create_moe_rs_context, MOE_DECODE_MAX_TOKENS, MOE_GROUP16_MAX_TOKENS, MOE_GROUP16_ROWS_PER_EXPERT, moe_decode_fwd,
+from ..ops.moe import (ag_group_gemm, create_ag_group_gemm_context, create_moe_rs_context, MOE_DECODE_MAX_TOKENS, MOE_GROUP16_MAX_TOKENS, group16_row_limit, moe_decode_fwd,
                        moe_decode_supported, moe_route, moe_route_supported, run_moe_reduce_rs)
 from ..utils.distributed import get_env
 from .tp_mlp import shard_local
@@ -219,7 +219,7 @@ class TP_MoE:
         if not moe_decode_supported(x2[:1], self.gate_up_proj, self.down_proj, self.top_k):
             return False
         return n_all <= MOE_DECODE_MAX_TOKENS or (n_all <= MOE_GROUP16_MAX_TOKENS and
-                                                  n_all * self.top_k <= MOE_GROUP16_ROWS_PER_EXPERT * E and E <= 1024
+                                                  n_all * self.top_k <= group16_row_limit(E, H, two_ip // 2) and E <= 1024
                                                   and two_ip // 2 >= 64)
 
     @torch.inference_mode()

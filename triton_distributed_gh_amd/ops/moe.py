@@ -471,8 +471,20 @@ MOE_DECODE_MAX_TOKENS = int(os.environ.get("TDIST_MOE_DECODE_MAX_TOKENS", "16"))
 # Above MOE_DECODE_MAX_TOKENS tokens the (token, expert) pairs are grouped by expert into blocks of sixteen rows
 # (csrc/ops/gemm.hip: tdist_moe_group16_fwd) as long as an expert gets about two such blocks at most; from there on the
 # grouped GEMM on 256-row tiles (ag_group_gemm + run_moe_reduce_rs) takes over.
-MOE_GROUP16_MAX_TOKENS = int(os.environ.get("TDIST_MOE_GROUP16_MAX_TOKENS", "256"))
-MOE_GROUP16_ROWS_PER_EXPERT = int(os.environ.get("TDIST_MOE_GROUP16_ROWS_PER_EXPERT", "32"))
+# Measured on a Qwen3-30B-A3B layer (9.4 MB per expert: blocks of one expert run next to each other and share it in the
+# L2): 384 tokens = 24 rows per expert 467 us against 534 us for the grouped GEMM, 512 tokens = 32 rows 554 against 546.
+# An expert too large for the caches (Mixtral: 350 MB) is streamed from memory again for every block, so there the
+# limit is half a block per expert on average (not measured; TDIST_MOE_GROUP16_ROWS_PER_BIG_EXPERT).
+MOE_GROUP16_MAX_TOKENS = int(os.environ.get("TDIST_MOE_GROUP16_MAX_TOKENS", "448"))
+MOE_GROUP16_ROWS_PER_EXPERT = int(os.environ.get("TDIST_MOE_GROUP16_ROWS_PER_EXPERT", "28"))
+MOE_GROUP16_ROWS_PER_BIG_EXPERT = int(os.environ.get("TDIST_MOE_GROUP16_ROWS_PER_BIG_EXPERT", "8"))
+MOE_GROUP16_BIG_EXPERT_BYTES = 32 << 20
+
+
+def group16_row_limit(E: int, H: int, Ip: int) -> int:
+    """Most (token, expert) pairs the expert-grouped decode form takes for this expert shape."""
+    big = 3 * H * Ip * 2 > MOE_GROUP16_BIG_EXPERT_BYTES
+    return (MOE_GROUP16_ROWS_PER_BIG_EXPERT if big else MOE_GROUP16_ROWS_PER_EXPERT) * E
 # -1: the grouped form also takes MOE_DECODE_MAX_TOKENS tokens or fewer once the pairs outnumber half of the experts
 # (tokens then share experts often enough that streaming an expert once per block beats once per pair: Qwen3-30B-A3B,
 # 128 experts, top-8: 8 tokens 115 vs 116 us, 12 tokens 161 vs 143, 16 tokens 207 vs 163); 0: never below the limit;
@@ -480,9 +492,9 @@ MOE_GROUP16_ROWS_PER_EXPERT = int(os.environ.get("TDIST_MOE_GROUP16_ROWS_PER_EXP
 MOE_GROUP16 = int(os.environ.get("TDIST_MOE_GROUP16", "-1"))
 
 
-def _group16_takes(n: int, topk: int, E: int, Ip: int) -> bool:
+def _group16_takes(n: int, topk: int, E: int, Ip: int, H: int = 0) -> bool:
     """Whether ``moe_decode_fwd`` runs ``n`` tokens on the expert-grouped kernels."""
-    able = (E <= 1024 and Ip >= 64 and n <= MOE_GROUP16_MAX_TOKENS and n * topk <= MOE_GROUP16_ROWS_PER_EXPERT * E)
+    able = (E <= 1024 and Ip >= 64 and n <= MOE_GROUP16_MAX_TOKENS and n * topk <= group16_row_limit(E, H, Ip))
     if not able:
         return False
     if n > MOE_DECODE_MAX_TOKENS:
@@ -495,7 +507,7 @@ def moe_decode_supported(x: torch.Tensor, gate_up: torch.Tensor, down: torch.Ten
     """Shapes ``moe_decode_fwd`` takes: bf16 on the GPU, expert weights ``gate_up [E, 2 Ip, H]`` / ``down [E, H, Ip]``
     contiguous, H a multiple of 32, Ip of 32, and at most ``MOE_DECODE_MAX_TOKENS`` tokens (one launch pair over the
     (token, expert) pairs) or at most ``MOE_GROUP16_MAX_TOKENS`` tokens with on average no more than
-    ``MOE_GROUP16_ROWS_PER_EXPERT`` rows per expert (pairs grouped by expert in blocks of sixteen).  ``max_tokens``
+    ``MOE_GROUP16_ROWS_PER_EXPERT`` rows per expert (pairs grouped by expert in blocks of sixteen; ``group16_row_limit``).  ``max_tokens``
     lowers the token limit (callers whose buffers are sized for fewer rows)."""
     if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.bfloat16 == gate_up.dtype == down.dtype):
         return False
@@ -505,7 +517,7 @@ def moe_decode_supported(x: torch.Tensor, gate_up: torch.Tensor, down: torch.Ten
     if max_tokens is not None and n > max_tokens:
         return False
     few = 0 < n <= MOE_DECODE_MAX_TOKENS
-    grouped = (MOE_DECODE_MAX_TOKENS < n <= MOE_GROUP16_MAX_TOKENS and n * topk <= MOE_GROUP16_ROWS_PER_EXPERT * E
+    grouped = (MOE_DECODE_MAX_TOKENS < n <= MOE_GROUP16_MAX_TOKENS and n * topk <= group16_row_limit(E, H, Ip)
                and E <= 1024 and Ip >= 64 and H % 4 == 0)
     return ((few or grouped) and H2 == H and tuple(down.shape) == (E, H, Ip) and H % 32 == 0 and H >= 128
             and Ip % 32 == 0 and gate_up.is_contiguous() and down.is_contiguous() and x.is_contiguous()
@@ -536,7 +548,7 @@ def moe_decode_fwd(x: torch.Tensor, topk_ids: torch.Tensor, topk_weights: torch.
     wts = topk_weights.to(torch.float32).contiguous()
     out = torch.empty((n, H), dtype=x.dtype, device=x.device)
     lib = _lib.hip()
-    if down_form is None and gate_up_form is None and _group16_takes(n, k, gate_up.shape[0], Ip):
+    if down_form is None and gate_up_form is None and _group16_takes(n, k, gate_up.shape[0], Ip, H):
         # several tokens per expert: four launches over the pairs sorted by expert in blocks of sixteen rows, every
         # expert's weights streamed once per block (Qwen3-30B-A3B layer, 32 / 128 tokens: see profiles/r3/moe_group16.md)
         E = gate_up.shape[0]
