@@ -9,8 +9,8 @@ from triton_distributed_gh_amd.utils import initialize_distributed
 from triton_distributed_gh_amd.utils.perf import graph_bench
 
 BF = torch.bfloat16
-E, topk, H, I = 128, 8, 2048, 768
-env = initialize_distributed(seed=0, heap_bytes=1 << 30)
+E, topk, H, I = [int(v) for v in os.environ.get("SHAPE", "128,8,2048,768").split(",")]     # SHAPE=8,2,4096,14336: Mixtral-8x7B
+env = initialize_distributed(seed=0, heap_bytes=3 << 30)
 
 
 def lin(o, i, scale=0.05):
@@ -32,11 +32,14 @@ for T in [int(v) for v in os.environ.get("TOKENS", "1,4,16,17,32,64,128,256,512"
     def ref():
         i = it[0]; it[0] += 1
         return moe.torch_fwd_no_loop(xs[i % 8])
-    a, b = moe.dist_triton_fwd(xs[0]).float(), moe.torch_fwd_no_loop(xs[0]).float()
-    rel = (a - b).abs().max().item() / b.abs().max().item()
+    if os.environ.get("NO_TORCH") == "1":
+        rel = float("nan")
+    else:
+        a, b = moe.dist_triton_fwd(xs[0]).float(), moe.torch_fwd_no_loop(xs[0]).float()
+        rel = (a - b).abs().max().item() / b.abs().max().item()
     t_n = graph_bench(nat, n=8)
     try:
-        t_r = graph_bench(ref, n=8)
+        t_r = float("nan") if os.environ.get("NO_TORCH") == "1" else graph_bench(ref, n=8)
     except Exception as exc:  # noqa: BLE001
         t_r = float("nan")
     print(f"tokens {T}: native {t_n:.1f} us  torch (no loop) {t_r:.1f} us  rel diff {rel:.1e}", flush=True)

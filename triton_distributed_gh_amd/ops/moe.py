@@ -473,11 +473,13 @@ MOE_DECODE_MAX_TOKENS = int(os.environ.get("TDIST_MOE_DECODE_MAX_TOKENS", "16"))
 # grouped GEMM on 256-row tiles (ag_group_gemm + run_moe_reduce_rs) takes over.
 # Measured on a Qwen3-30B-A3B layer (9.4 MB per expert: blocks of one expert run next to each other and share it in the
 # L2): 384 tokens = 24 rows per expert 467 us against 534 us for the grouped GEMM, 512 tokens = 32 rows 554 against 546.
-# An expert too large for the caches (Mixtral: 350 MB) is streamed from memory again for every block, so there the
-# limit is half a block per expert on average (not measured; TDIST_MOE_GROUP16_ROWS_PER_BIG_EXPERT).
+# An expert too large for the caches (Mixtral-8x7B: 8 experts of 350 MB, top-2) is streamed from memory again for every
+# block, so there the limit is one block per expert on average: 64 tokens 741 us against 830 us for the grouped GEMM,
+# 128 tokens 1211 against 841.  For such experts the grouped form also beats the per-pair kernels from the first token
+# on (1 / 4 / 16 tokens: 142 / 352 / 480 us against 158 / 565 / 2178; profiles/r3/moe_group16.md).
 MOE_GROUP16_MAX_TOKENS = int(os.environ.get("TDIST_MOE_GROUP16_MAX_TOKENS", "448"))
 MOE_GROUP16_ROWS_PER_EXPERT = int(os.environ.get("TDIST_MOE_GROUP16_ROWS_PER_EXPERT", "28"))
-MOE_GROUP16_ROWS_PER_BIG_EXPERT = int(os.environ.get("TDIST_MOE_GROUP16_ROWS_PER_BIG_EXPERT", "8"))
+MOE_GROUP16_ROWS_PER_BIG_EXPERT = int(os.environ.get("TDIST_MOE_GROUP16_ROWS_PER_BIG_EXPERT", "16"))
 MOE_GROUP16_BIG_EXPERT_BYTES = 32 << 20
 
 
@@ -499,7 +501,8 @@ def _group16_takes(n: int, topk: int, E: int, Ip: int, H: int = 0) -> bool:
         return False
     if n > MOE_DECODE_MAX_TOKENS:
         return True
-    return MOE_GROUP16 == 1 or (MOE_GROUP16 < 0 and n * topk > max(E // 2, topk))
+    big = 3 * H * Ip * 2 > MOE_GROUP16_BIG_EXPERT_BYTES
+    return MOE_GROUP16 == 1 or (MOE_GROUP16 < 0 and (big or n * topk > max(E // 2, topk)))
 
 
 def moe_decode_supported(x: torch.Tensor, gate_up: torch.Tensor, down: torch.Tensor, topk: int,
