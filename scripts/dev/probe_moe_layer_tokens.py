@@ -22,7 +22,7 @@ tree = SimpleNamespace(num_experts=E, top_k=topk, norm_topk_prob=True, gate=lin(
                                                 act_fn=torch.nn.functional.silu) for _ in range(E)])
 moe = TP_MoE(rank=0, world_size=1, env=env)
 moe._init_parameters(tree)
-moe._init_ctx(512)
+moe._init_ctx(int(os.environ.get("CTX_M", "512")))
 for T in [int(v) for v in os.environ.get("TOKENS", "1,4,16,17,32,64,128,256,512").split(",")]:
     xs = [(torch.rand(T, H, device="cuda") * 2 - 1).to(BF) for _ in range(8)]
     it = [0]
