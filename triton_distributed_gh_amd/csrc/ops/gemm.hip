@@ -1563,6 +1563,38 @@ __global__ __launch_bounds__(256) void moe_topk_sum_kernel(const float* __restri
   }
 }
 
+// out[t, :] = sum over k of x[t * topk + k, :] for bf16 rows (fp32 accumulation): the top-k reduce of the grouped-GEMM
+// path on one rank (on several ranks it is part of the reduce-scatter kernel).  H a multiple of 8, 16-byte aligned rows.
+__global__ __launch_bounds__(256) void moe_topk_sum_bf16_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ out,
+                                                                int topk, int H) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  const int t = blockIdx.x;
+  for (int c = threadIdx.x * 8; c < H; c += 256 * 8) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < topk; ++k) {
+      const u32x4 v = __builtin_nontemporal_load((const u32x4*)(x + ((long long)t * topk + k) * H + c));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[2 * i] += __builtin_bit_cast(float, v[i] << 16);
+        acc[2 * i + 1] += __builtin_bit_cast(float, v[i] & 0xffff0000u);
+      }
+    }
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = Frag<true>::pack2(acc[2 * i], acc[2 * i + 1]);
+    *(u32x4*)(out + (long long)t * H + c) = o;
+  }
+}
+
+TDIST_API int tdist_moe_topk_sum_bf16(const void* x, void* out, int tokens, int topk, int H, void* stream) {
+  TDIST_REQUIRE(tokens > 0 && topk > 0 && H > 0 && H % 8 == 0, "H must be a multiple of 8");
+  TDIST_REQUIRE((((uintptr_t)x | (uintptr_t)out) & 15) == 0, "operands must be 16-byte aligned");
+  hipLaunchKernelGGL(moe_topk_sum_bf16_kernel, dim3(tokens), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
+                     (uint16_t*)out, topk, H);
+  TDIST_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // The MoE block for `tokens` rows in four launches: sort the pairs by expert into blocks of sixteen, gate_up + SiLU per
 // block, down per block (weighted, fp32, one row per pair), sum of every token's top-k rows.  x [tokens, H],
 // ids / wts [tokens * topk], gate_up [E, 2 Ip, H], down [E, H, Ip], out [tokens, H]; bf16.  Work buffers: hbuf bf16

@@ -237,7 +237,10 @@ class TP_MoE:
         full_w, full_ids = self._gather_meta(wts, ids)
         h = self.ag_group_gemm(x2, self.gate_up_proj, ctx=self.ag_ctx, full_topk_ids=full_ids.contiguous())
         h = self._act(h)
-        out = self.run_moe_reduce_rs(h, self.down_proj, full_ids.contiguous(), full_w.contiguous(), ctx=self.rs_ctx)
+        # one rank: the sort by expert that ag_group_gemm just made (world size 1, rank 0) is the one the second
+        # grouped GEMM needs
+        extra = {"idx": getattr(self.ag_ctx, "last_index", None)} if self.world_size == 1 else {}
+        out = self.run_moe_reduce_rs(h, self.down_proj, full_ids.contiguous(), full_w.contiguous(), ctx=self.rs_ctx, **extra)
         return out.view(shape)
 
     def fwd(self, x: torch.Tensor):

@@ -141,6 +141,12 @@ def histogram(x: torch.Tensor, bins: int) -> torch.Tensor:
 def reduce_topk(x: torch.Tensor, topk: int, weights: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[ntokens*topk, N] -> [ntokens, N] (optionally weighted), fp32 accumulation."""
     n = x.shape[0] // topk
+    if (weights is None and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.is_contiguous()
+            and x.shape[1] % 8 == 0 and x.data_ptr() % 16 == 0 and n > 0):
+        out = torch.empty((n, x.shape[1]), dtype=x.dtype, device=x.device)      # one launch instead of convert + sum + convert
+        _lib.check(_lib.hip().tdist_moe_topk_sum_bf16(_lib.ptr(x), _lib.ptr(out), n, topk, x.shape[1], _lib.stream_handle()),
+                   "tdist_moe_topk_sum_bf16")
+        return out
     xf = x.float().view(n, topk, -1)
     if weights is not None:
         xf = xf * weights.float().view(n, topk, 1)
@@ -174,6 +180,7 @@ class MoEAllGatherGroupGEMMTensorParallelContext:
     env: Any = None
     num_ctas: int = 0
     tickets: Optional[torch.Tensor] = None      # int32 [8]: per-XCD work queues of the grouped GEMM
+    last_index: Any = None                      # the AlignedIndex of the latest ag_group_gemm call
 
     def check_error(self):
         self.ag.check_error()
@@ -212,6 +219,7 @@ def ag_group_gemm(a: torch.Tensor, b: torch.Tensor, ctx: MoEAllGatherGroupGEMMTe
         return _ag_group_gemm_host(a, b, ctx, full_topk_ids)
     a = a.contiguous()
     idx = moe_align_block_size(full_topk_ids, ctx.num_experts, w, rank, M_per_rank)
+    ctx.last_index = idx        # (one rank: the same sort serves run_moe_reduce_rs, see its ``idx`` argument)
     out = torch.empty((ntokens * topk, N), dtype=a.dtype, device=a.device)
     # The call number lives on the device (ag.state, csrc/include/tdist/call_state.hpp): the kernel picks the
     # workspace / flag parity and the flag value itself, so the launch is the same every time and records into
@@ -362,7 +370,8 @@ def _column_chunks(N: int, n_chunks: int):
 
 
 def run_moe_reduce_rs(x: torch.Tensor, weights: torch.Tensor, chosen_experts: torch.Tensor,
-                      expert_weight: torch.Tensor, ctx: MoEReduceRSContext, n_chunks: Optional[int] = None, config=None):
+                      expert_weight: torch.Tensor, ctx: MoEReduceRSContext, n_chunks: Optional[int] = None, config=None,
+                      idx: Optional["AlignedIndex"] = None):
     """x [ntokens*topk, K/w] (row token*topk+k), weights = expert weights ([E, hidden, K/w] or
     [E, K/w, hidden]), chosen_experts [ntokens, topk], expert_weight [ntokens, topk] routing
     weights.  Returns [ntokens/w, hidden] = ReduceScatter_tokens(sum_k w_k * x_k @ W[e_k]).
@@ -382,7 +391,8 @@ def run_moe_reduce_rs(x: torch.Tensor, weights: torch.Tensor, chosen_experts: to
     if env.backend == "host" or not x.is_cuda:
         return _moe_reduce_rs_host(x, b, chosen_experts, expert_weight, ctx)
     x = x.contiguous()
-    idx = moe_align_block_size(chosen_experts, ctx.num_experts, 1, 0, ntokens)
+    if idx is None:       # (``idx``: the sort of the same ``chosen_experts`` by ``moe_align_block_size(ids, E, 1, 0, ntokens)``)
+        idx = moe_align_block_size(chosen_experts, ctx.num_experts, 1, 0, ntokens)
     gemm_out = torch.empty((ntokens * topk, N), dtype=x.dtype, device=x.device)
     scale = expert_weight.reshape(-1).to(torch.float32).contiguous()
     lib = _lib.hip()
