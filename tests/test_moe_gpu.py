@@ -139,7 +139,7 @@ def test_moe_decode_kernels_match_fp32_reference(n, H, I, E, topk):
 
 @pytest.mark.parametrize("n,H,I,E,topk", [(12, 2048, 768, 128, 8), (17, 2048, 768, 128, 8), (40, 2048, 768, 128, 8), (200, 1024, 96, 64, 8),
                                           (100, 512, 2304, 16, 4), (64, 512, 256, 8, 2), (33, 1056, 160, 12, 5)])
-def test_moe_block_grouped_by_expert_in_blocks_of_sixteen(n, H, I, E, topk):
+def test_moe_block_grouped_by_expert_in_blocks_of_sixteen(n, H, I, E, topk, monkeypatch):
     """17 .. 256 tokens: pairs sorted by expert into sixteen-row blocks, gate_up + SiLU and down per block, top-k sum
     (``moe_decode_fwd`` above ``MOE_DECODE_MAX_TOKENS`` tokens) against fp32 PyTorch; experts with no token, with a
     partial block and with several blocks all occur.  An expert id out of range contributes nothing."""
@@ -168,6 +168,11 @@ def test_moe_block_grouped_by_expert_in_blocks_of_sixteen(n, H, I, E, topk):
         ref.index_add_(0, tok, (h @ down[e].float().t()) * wts[tok, k, None])
     out = moe_decode_fwd(x, ids, wts, gate_up, down)
     torch.testing.assert_close(out.float(), ref, atol=2e-2 * ref.abs().max().item(), rtol=2e-2)
+    for rows in (16, 32):                  # both block heights, whatever the rule picked above
+        monkeypatch.setattr(moe_ops, "MOE_GROUP_BLOCK_ROWS", rows)
+        o2 = moe_decode_fwd(x, ids, wts, gate_up, down)
+        torch.testing.assert_close(o2.float(), ref, atol=2e-2 * ref.abs().max().item(), rtol=2e-2)
+    monkeypatch.setattr(moe_ops, "MOE_GROUP_BLOCK_ROWS", 0)
     bad = ids.clone()
     bad[1, 0] = 0x7fffffff
     bad[2, 1] = -3

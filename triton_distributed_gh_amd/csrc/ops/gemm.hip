@@ -1368,7 +1368,8 @@ TDIST_API int tdist_moe_decode_down(const void* hbuf, const int* ids, const floa
 // on it.
 __global__ __launch_bounds__(1024) void moe_align16_kernel(const int* __restrict__ ids, int n, int E,
                                                            int* __restrict__ sorted_ids, int* __restrict__ expert_of_block,
-                                                           int* __restrict__ meta, int nb_max) {
+                                                           int* __restrict__ meta, int nb_max, int bs) {
+  // bs: rows per block (16 or 32)
   __shared__ int cnt[1024], off[1024], pos[1024];
   const int tid = threadIdx.x;
   cnt[tid] = 0, pos[tid] = 0;
@@ -1378,7 +1379,7 @@ __global__ __launch_bounds__(1024) void moe_align16_kernel(const int* __restrict
     if ((unsigned)e < (unsigned)E) atomicAdd(&cnt[e], 1);
   }
   __syncthreads();
-  const int blocks = tid < E ? (cnt[tid] + 15) >> 4 : 0;
+  const int blocks = tid < E ? (cnt[tid] + bs - 1) / bs : 0;
   off[tid] = blocks;
   __syncthreads();
   for (int d = 1; d < 1024; d <<= 1) {           // inclusive scan over the experts
@@ -1398,20 +1399,21 @@ __global__ __launch_bounds__(1024) void moe_align16_kernel(const int* __restrict
   for (int i = tid; i < n; i += 1024) {
     const int e = ids[i];
     if ((unsigned)e < (unsigned)E) {
-      const int slot = off[e] * 16 + atomicAdd(&pos[e], 1);
-      if (slot < nb_max * 16) sorted_ids[slot] = i;
+      const int slot = off[e] * bs + atomicAdd(&pos[e], 1);
+      if (slot < nb_max * bs) sorted_ids[slot] = i;
     }
   }
   if (tid < E)
-    for (int q = cnt[tid]; q < blocks * 16; ++q)             // padding rows of the expert's last block
-      if (excl * 16 + q < nb_max * 16) sorted_ids[excl * 16 + q] = -1;
+    for (int q = cnt[tid]; q < blocks * bs; ++q)             // padding rows of the expert's last block
+      if (excl * bs + q < nb_max * bs) sorted_ids[excl * bs + q] = -1;
 }
 
-// One sixteen-row block x 8 GN output columns per workgroup (GN = WN, or WN / 2 with SILU: gate group g pairs with up
-// group g + GN), NW waves = K slices, batches of U 64-deep steps.  x_div > 0: activation row of a pair = pair / x_div
-// (gate_up: the token's row of X); x_div == 0: row 16 b + i of X (down: the rows the gate_up launch wrote, in sorted
-// order).  SILU: C = bf16 [16 nb, N] in sorted order; otherwise C = fp32 [pairs, N], row = pair index, times scale[pair].
-template <int WN, int NW, int U, bool SILU>
+// One block of 16 MB rows x 8 GN output columns per workgroup (GN = WN, or WN / 2 with SILU: gate group g pairs with up
+// group g + GN), NW waves = K slices, batches of U 64-deep steps; with MB = 2 every weight fragment feeds two row
+// blocks.  x_div > 0: activation row of a pair = pair / x_div (gate_up: the token's row of X); x_div == 0: row
+// 16 MB b + i of X (down: the rows the gate_up launch wrote, in sorted order).  SILU: C = bf16 [16 MB nb, N] in sorted
+// order; otherwise C = fp32 [pairs, N], row = pair index, times scale[pair].
+template <int WN, int NW, int U, bool SILU, int MB = 1>
 __global__ __launch_bounds__(64 * NW) void moe_group16_kernel(const uint16_t* __restrict__ X, long long ldx, int x_div,
                                                               const uint16_t* __restrict__ W, long long w_estride,
                                                               long long ldw, void* __restrict__ Cv, long long ldc,
@@ -1426,11 +1428,12 @@ __global__ __launch_bounds__(64 * NW) void moe_group16_kernel(const uint16_t* __
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
   constexpr int GN = SILU ? WN / 2 : WN;
   constexpr int BN_ = 8 * GN;
+  constexpr int BS = 16 * MB;
   const int b = blockIdx.y;
   if (b >= meta[0]) return;
   const int e = expert_of_block[b];
   const int up_off = SILU ? N : 0;
-  __shared__ float red[NW * WN * 64 * 4];                // [K slice][column group][lane][4]
+  __shared__ float red[NW * MB * WN * 64 * 4];           // [K slice][row block][column group][lane][4]
   const int wk = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int li = lane & 15, lg = lane >> 4;
   const int lrow = li & 7, kg = (li >> 3) * 4 + lg;      // weight row inside the group, k-group inside the step
@@ -1438,27 +1441,34 @@ __global__ __launch_bounds__(64 * NW) void moe_group16_kernel(const uint16_t* __
   const int ksteps = (K + 63) / 64;
   const int per = (ksteps + NW - 1) / NW;
   const int ks0 = min(wk * per, ksteps), ks1 = min(ks0 + per, ksteps);
-  const int sid = sorted_ids[b * 16 + li];
-  const bool xvalid = sid >= 0;
-  const long long xrow = x_div > 0 ? (long long)(xvalid ? sid / x_div : 0) : (long long)b * 16 + li;
-  const uint16_t* xr = X + xrow * ldx;
+  bool xvalid[MB];
+  const uint16_t* xr[MB];
+#pragma unroll
+  for (int m = 0; m < MB; ++m) {
+    const int sid = sorted_ids[b * BS + m * 16 + li];
+    xvalid[m] = sid >= 0;
+    const long long xrow = x_div > 0 ? (long long)(xvalid[m] ? sid / x_div : 0) : (long long)b * BS + m * 16 + li;
+    xr[m] = X + xrow * ldx;
+  }
   const uint16_t* We = W + (long long)e * w_estride;
   const uint16_t* wr[WN];
 #pragma unroll
   for (int j = 0; j < WN; ++j)                            // clamped: out-of-range columns are not stored
     wr[j] = We + (long long)((j / GN) * up_off + min(n0 + (j % GN) * 8 + lrow, N - 1)) * ldw;
-  f32x4 acc1[WN], acc2[WN];
+  f32x4 acc1[MB][WN], acc2[MB][WN];
 #pragma unroll
-  for (int j = 0; j < WN; ++j) acc1[j] = acc2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) acc1[m][j] = acc2[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // activation fragment of K step ks, half h (k-groups 4 h .. 4 h + 3); zero past the end of K and for padding rows
-  auto load_x = [&](int ks, int h) -> u32x4 {
+  auto load_x = [&](int m, int ks, int h) -> u32x4 {
     const int k = ks * 64 + h * 32 + lg * 8;
-    const u32x4 v = *(const u32x4*)(xr + min(k, K - 8));
-    return (xvalid && k < K) ? v : u32x4{0, 0, 0, 0};
+    const u32x4 v = *(const u32x4*)(xr[m] + min(k, K - 8));
+    return (xvalid[m] && k < K) ? v : u32x4{0, 0, 0, 0};
   };
   const int nfull = (ks1 - ks0) / U;
   constexpr int H = U / 2;
-  u32x4 wv[U][WN], xv1[U], xv2[U];
+  u32x4 wv[U][WN], xv1[U][MB], xv2[U][MB];
   auto issue = [&](int ks, auto u0c) {
     constexpr int u0 = decltype(u0c)::value;
 #pragma unroll
@@ -1467,17 +1477,21 @@ __global__ __launch_bounds__(64 * NW) void moe_group16_kernel(const uint16_t* __
       for (int j = 0; j < WN; ++j)
         wv[u][j] = __builtin_nontemporal_load((const u32x4*)(wr[j] + min((ks + u) * 64 + kg * 8, K - 8)));
 #pragma unroll
-    for (int u = u0; u < u0 + H; ++u) xv1[u] = load_x(ks + u, 0), xv2[u] = load_x(ks + u, 1);
+    for (int u = u0; u < u0 + H; ++u)
+#pragma unroll
+      for (int m = 0; m < MB; ++m) xv1[u][m] = load_x(m, ks + u, 0), xv2[u][m] = load_x(m, ks + u, 1);
   };
   auto consume = [&](auto u0c) {
     constexpr int u0 = decltype(u0c)::value;
 #pragma unroll
     for (int u = u0; u < u0 + H; ++u)
 #pragma unroll
-      for (int j = 0; j < WN; ++j) {
-        acc1[j] = F::mfma(__builtin_bit_cast(VT, xv1[u]), __builtin_bit_cast(VT, wv[u][j]), acc1[j]);
-        acc2[j] = F::mfma(__builtin_bit_cast(VT, xv2[u]), __builtin_bit_cast(VT, wv[u][j]), acc2[j]);
-      }
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+          acc1[m][j] = F::mfma(__builtin_bit_cast(VT, xv1[u][m]), __builtin_bit_cast(VT, wv[u][j]), acc1[m][j]);
+          acc2[m][j] = F::mfma(__builtin_bit_cast(VT, xv2[u][m]), __builtin_bit_cast(VT, wv[u][j]), acc2[m][j]);
+        }
   };
   using C0 = std::integral_constant<int, 0>;
   using CH = std::integral_constant<int, H>;
@@ -1494,32 +1508,40 @@ __global__ __launch_bounds__(64 * NW) void moe_group16_kernel(const uint16_t* __
     }
   }
   for (int ks = ks0 + nfull * U; ks < ks1; ++ks) {
-    const u32x4 x1 = load_x(ks, 0), x2 = load_x(ks, 1);
+    u32x4 x1[MB], x2[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) x1[m] = load_x(m, ks, 0), x2[m] = load_x(m, ks, 1);
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
       const u32x4 w = __builtin_nontemporal_load((const u32x4*)(wr[j] + min(ks * 64 + kg * 8, K - 8)));
-      acc1[j] = F::mfma(__builtin_bit_cast(VT, x1), __builtin_bit_cast(VT, w), acc1[j]);
-      acc2[j] = F::mfma(__builtin_bit_cast(VT, x2), __builtin_bit_cast(VT, w), acc2[j]);
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+        acc1[m][j] = F::mfma(__builtin_bit_cast(VT, x1[m]), __builtin_bit_cast(VT, w), acc1[m][j]);
+        acc2[m][j] = F::mfma(__builtin_bit_cast(VT, x2[m]), __builtin_bit_cast(VT, w), acc2[m][j]);
+      }
     }
   }
   // accumulator: row = 4*lg + r, column = li.  Column j < 8 of the result = acc1 column j + acc2 column j + 8 (eight
-  // lanes further on); wave g then sums column groups g, g + NW, .. over the K slices.
+  // lanes further on); wave g then sums (row block, column group) pairs g, g + NW, .. over the K slices.
 #pragma unroll
-  for (int j = 0; j < WN; ++j) {
-    float* slot = red + ((wk * WN + j) * 64 + lane) * 4;
+  for (int m = 0; m < MB; ++m)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) slot[r] = acc1[j][r] + __shfl_down(acc2[j][r], 8);
-  }
+    for (int j = 0; j < WN; ++j) {
+      float* slot = red + (((wk * MB + m) * WN + j) * 64 + lane) * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slot[r] = acc1[m][j][r] + __shfl_down(acc2[m][j][r], 8);
+    }
   __syncthreads();
-  for (int g = wk; g < GN; g += NW) {
+  for (int item = wk; item < MB * GN; item += NW) {
+    const int m = item / GN, g = item - m * GN;
     f32x4 sum = {0.f, 0.f, 0.f, 0.f}, up = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < NW; ++q) {
-      const float* o = red + ((q * WN + g) * 64 + lane) * 4;
+      const float* o = red + (((q * MB + m) * WN + g) * 64 + lane) * 4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) sum[r] += o[r];
       if constexpr (SILU) {
-        const float* ou = red + ((q * WN + g + GN) * 64 + lane) * 4;
+        const float* ou = red + (((q * MB + m) * WN + g + GN) * 64 + lane) * 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) up[r] += ou[r];
       }
@@ -1528,16 +1550,16 @@ __global__ __launch_bounds__(64 * NW) void moe_group16_kernel(const uint16_t* __
     const int col = n0 + g * 8 + li;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = 4 * lg + r;
+      const int row = m * 16 + 4 * lg + r;
       if constexpr (SILU) {
         // gate and up rounded to 16 bits first, as the separate kernels do, then activated
         const float gr = (float)(__bf16)sum[r], ur = (float)(__bf16)up[r];
         const float mine = gr / (1.f + __expf(-gr)) * ur;
         const float other = __shfl_xor(mine, 1);
         if (li < 8 && col < N && (li & 1) == 0)
-          *(uint32_t*)((uint16_t*)Cv + ((long long)b * 16 + row) * ldc + col) = F::pack2(mine, other);
+          *(uint32_t*)((uint16_t*)Cv + ((long long)b * BS + row) * ldc + col) = F::pack2(mine, other);
       } else {
-        const int pr = sorted_ids[b * 16 + row];
+        const int pr = sorted_ids[b * BS + row];
         const float mine = pr >= 0 ? sum[r] * scale[pr] : 0.f;
         const float other = __shfl_xor(mine, 1);
         if (pr >= 0 && li < 8 && col < N && (li & 1) == 0)
@@ -1597,35 +1619,50 @@ TDIST_API int tdist_moe_topk_sum_bf16(const void* x, void* out, int tokens, int 
 
 // The MoE block for `tokens` rows in four launches: sort the pairs by expert into blocks of sixteen, gate_up + SiLU per
 // block, down per block (weighted, fp32, one row per pair), sum of every token's top-k rows.  x [tokens, H],
-// ids / wts [tokens * topk], gate_up [E, 2 Ip, H], down [E, H, Ip], out [tokens, H]; bf16.  Work buffers: hbuf bf16
-// [16 nb_max, Ip], y fp32 [tokens * topk, H], sorted_ids int [16 nb_max], expert_of_block int [nb_max], meta int [2],
-// with nb_max >= tokens * topk / 16 + E.  A pair whose id is outside [0, E) contributes nothing.
+// ids / wts [tokens * topk], gate_up [E, 2 Ip, H], down [E, H, Ip], out [tokens, H]; bf16.  block_rows: 16 or 32 rows
+// per block.  Work buffers: hbuf bf16 [block_rows nb_max, Ip], y fp32 [tokens * topk, H], sorted_ids int [block_rows
+// nb_max], expert_of_block int [nb_max], meta int [2], with nb_max >= tokens * topk / block_rows + E.  A pair whose id is outside [0, E) contributes nothing.
 TDIST_API int tdist_moe_group16_fwd(const void* x, const int* ids, const float* wts, const void* gate_up, const void* down,
                                     void* hbuf, float* y, void* out, int* sorted_ids, int* expert_of_block, int* meta,
-                                    int tokens, int topk, int H, int Ip, int E, int nb_max, void* stream) {
+                                    int tokens, int topk, int H, int Ip, int E, int nb_max, int block_rows, void* stream) {
   const long long pairs = (long long)tokens * topk;
   TDIST_REQUIRE(tokens > 0 && topk > 0 && E > 0 && E <= 1024 && pairs <= (1 << 20), "bad token / top-k / expert count");
-  TDIST_REQUIRE(nb_max >= pairs / 16 + E && nb_max <= 65535, "nb_max must be at least pairs / 16 + E (and fit a grid dimension)");
+  TDIST_REQUIRE(block_rows == 16 || block_rows == 32, "rows per block must be 16 or 32");
+  TDIST_REQUIRE(nb_max >= pairs / block_rows + E && nb_max <= 65535,
+                "nb_max must be at least pairs / block_rows + E (and fit a grid dimension)");
   TDIST_REQUIRE(H >= 128 && H % 32 == 0 && Ip >= 64 && Ip % 32 == 0, "H must be a multiple of 32 (>= 128), Ip of 32 (>= 64)");
   TDIST_REQUIRE((((uintptr_t)x | (uintptr_t)gate_up | (uintptr_t)down | (uintptr_t)hbuf | (uintptr_t)y) & 15) == 0 &&
                     (((uintptr_t)out) & 7) == 0 && ids && wts && sorted_ids && expert_of_block && meta,
                 "operands must be aligned");
   hipStream_t s = (hipStream_t)stream;
   const uint16_t *xp = (const uint16_t*)x, *gu = (const uint16_t*)gate_up, *dn = (const uint16_t*)down;
-  hipLaunchKernelGGL(moe_align16_kernel, dim3(1), dim3(1024), 0, s, ids, (int)pairs, E, sorted_ids, expert_of_block, meta, nb_max);
-  hipLaunchKernelGGL((moe_group16_kernel<4, 4, 4, true>), dim3((Ip + 15) / 16, nb_max), dim3(256), 0, s, xp, (long long)H, topk, gu,
-                     (long long)2 * Ip * H, (long long)H, hbuf, (long long)Ip, (const int*)sorted_ids, (const int*)expert_of_block,
-                     (const int*)meta, (const float*)nullptr, Ip, H);
+  hipLaunchKernelGGL(moe_align16_kernel, dim3(1), dim3(1024), 0, s, ids, (int)pairs, E, sorted_ids, expert_of_block, meta, nb_max,
+                     block_rows);
+#define TDIST_G16(KERN, GRIDX, THREADS_, XP, LDX, XDIV, WP, WES, LDW, CP, LDC, SC, N_, K_)                                  \
+  hipLaunchKernelGGL(KERN, dim3(GRIDX, nb_max), dim3(THREADS_), 0, s, XP, (long long)(LDX), XDIV, WP, (long long)(WES),       \
+                     (long long)(LDW), CP, (long long)(LDC), (const int*)sorted_ids, (const int*)expert_of_block,           \
+                     (const int*)meta, SC, N_, K_)
   // down: K = Ip.  Four K slices want at least two batches of four steps each (Ip >= 2048); shorter rows run two slices
-  // in batches of two steps
-  if (Ip >= 2048)
-    hipLaunchKernelGGL((moe_group16_kernel<4, 4, 4, false>), dim3((H + 31) / 32, nb_max), dim3(256), 0, s, (const uint16_t*)hbuf,
-                       (long long)Ip, 0, dn, (long long)H * Ip, (long long)Ip, (void*)y, (long long)H, (const int*)sorted_ids,
-                       (const int*)expert_of_block, (const int*)meta, wts, H, Ip);
-  else
-    hipLaunchKernelGGL((moe_group16_kernel<4, 2, 2, false>), dim3((H + 31) / 32, nb_max), dim3(128), 0, s, (const uint16_t*)hbuf,
-                       (long long)Ip, 0, dn, (long long)H * Ip, (long long)Ip, (void*)y, (long long)H, (const int*)sorted_ids,
-                       (const int*)expert_of_block, (const int*)meta, wts, H, Ip);
+  // in batches of two steps.  Blocks of 32 rows: two row blocks share every weight fragment (batches of two steps).
+  const float* none = nullptr;
+  if (block_rows == 16) {
+    TDIST_G16((moe_group16_kernel<4, 4, 4, true, 1>), (Ip + 15) / 16, 256, xp, H, topk, gu, 2LL * Ip * H, H, hbuf, Ip, none, Ip, H);
+    if (Ip >= 2048)
+      TDIST_G16((moe_group16_kernel<4, 4, 4, false, 1>), (H + 31) / 32, 256, (const uint16_t*)hbuf, Ip, 0, dn, (long long)H * Ip, Ip,
+                (void*)y, H, wts, H, Ip);
+    else
+      TDIST_G16((moe_group16_kernel<4, 2, 2, false, 1>), (H + 31) / 32, 128, (const uint16_t*)hbuf, Ip, 0, dn, (long long)H * Ip, Ip,
+                (void*)y, H, wts, H, Ip);
+  } else {
+    TDIST_G16((moe_group16_kernel<4, 4, 2, true, 2>), (Ip + 15) / 16, 256, xp, H, topk, gu, 2LL * Ip * H, H, hbuf, Ip, none, Ip, H);
+    if (Ip >= 2048)
+      TDIST_G16((moe_group16_kernel<4, 4, 2, false, 2>), (H + 31) / 32, 256, (const uint16_t*)hbuf, Ip, 0, dn, (long long)H * Ip, Ip,
+                (void*)y, H, wts, H, Ip);
+    else
+      TDIST_G16((moe_group16_kernel<4, 2, 2, false, 2>), (H + 31) / 32, 128, (const uint16_t*)hbuf, Ip, 0, dn, (long long)H * Ip, Ip,
+                (void*)y, H, wts, H, Ip);
+  }
+#undef TDIST_G16
   hipLaunchKernelGGL(moe_topk_sum_kernel, dim3(tokens), dim3(256), 0, s, (const float*)y, (uint16_t*)out, ids, E, topk, H);
   TDIST_HIP_TRY(hipGetLastError());
   return 0;

@@ -484,13 +484,20 @@ MOE_DECODE_MAX_TOKENS = int(os.environ.get("TDIST_MOE_DECODE_MAX_TOKENS", "16"))
 # Measured on a Qwen3-30B-A3B layer (9.4 MB per expert: blocks of one expert run next to each other and share it in the
 # L2): 384 tokens = 24 rows per expert 467 us against 534 us for the grouped GEMM, 512 tokens = 32 rows 554 against 546.
 # An expert too large for the caches (Mixtral-8x7B: 8 experts of 350 MB, top-2) is streamed from memory again for every
-# block, so there the limit is one block per expert on average: 64 tokens 741 us against 830 us for the grouped GEMM,
-# 128 tokens 1211 against 841.  For such experts the grouped form also beats the per-pair kernels from the first token
+# block, so there the limit is 24 rows per expert on average (blocks of 32 rows from 12 on): 64 tokens 648 us against
+# 830 us for the grouped GEMM, 96 tokens 717 against 835, 128 tokens 995 against 850.  For such experts the grouped form also beats the per-pair kernels from the first token
 # on (1 / 4 / 16 tokens: 142 / 352 / 480 us against 158 / 565 / 2178; profiles/r3/moe_group16.md).
 MOE_GROUP16_MAX_TOKENS = int(os.environ.get("TDIST_MOE_GROUP16_MAX_TOKENS", "448"))
 MOE_GROUP16_ROWS_PER_EXPERT = int(os.environ.get("TDIST_MOE_GROUP16_ROWS_PER_EXPERT", "28"))
-MOE_GROUP16_ROWS_PER_BIG_EXPERT = int(os.environ.get("TDIST_MOE_GROUP16_ROWS_PER_BIG_EXPERT", "16"))
+MOE_GROUP16_ROWS_PER_BIG_EXPERT = int(os.environ.get("TDIST_MOE_GROUP16_ROWS_PER_BIG_EXPERT", "24"))
 MOE_GROUP16_BIG_EXPERT_BYTES = 32 << 20
+# rows per block of the grouped form: 0 = sixteen, or thirty-two (every weight fragment feeds two MFMA row blocks) once
+# an expert has more than this many rows on average; 16 / 32 force one.  Qwen3-30B-A3B layer, 16 / 32 rows per block:
+# 256 tokens 350 / 359 us, 384 tokens 461 / 391; Mixtral-8x7B layer: 32 tokens 496 / 617, 64 tokens 722 / 648, 96 tokens
+# 995 / 717 (grouped GEMM 835), 128 tokens 1226 / 995 (grouped GEMM 850).
+MOE_GROUP_BLOCK_ROWS = int(os.environ.get("TDIST_MOE_GROUP_BLOCK_ROWS", "0"))
+MOE_GROUP32_FROM_ROWS = int(os.environ.get("TDIST_MOE_GROUP32_FROM_ROWS", "18"))
+MOE_GROUP32_FROM_ROWS_BIG = int(os.environ.get("TDIST_MOE_GROUP32_FROM_ROWS_BIG", "12"))
 
 
 def group16_row_limit(E: int, H: int, Ip: int) -> int:
@@ -565,14 +572,16 @@ def moe_decode_fwd(x: torch.Tensor, topk_ids: torch.Tensor, topk_weights: torch.
         # several tokens per expert: four launches over the pairs sorted by expert in blocks of sixteen rows, every
         # expert's weights streamed once per block (Qwen3-30B-A3B layer, 32 / 128 tokens: see profiles/r3/moe_group16.md)
         E = gate_up.shape[0]
-        nb_max = n * k // 16 + E
-        hbuf = torch.empty((nb_max * 16, Ip), dtype=x.dtype, device=x.device)
+        big = 3 * H * Ip * 2 > MOE_GROUP16_BIG_EXPERT_BYTES
+        bs = MOE_GROUP_BLOCK_ROWS or (32 if n * k > (MOE_GROUP32_FROM_ROWS_BIG if big else MOE_GROUP32_FROM_ROWS) * E else 16)
+        nb_max = n * k // bs + E
+        hbuf = torch.empty((nb_max * bs, Ip), dtype=x.dtype, device=x.device)
         y = torch.empty((n * k, H), dtype=torch.float32, device=x.device)
-        idx = torch.empty(nb_max * 17 + 2, dtype=torch.int32, device=x.device)
+        idx = torch.empty(nb_max * (bs + 1) + 2, dtype=torch.int32, device=x.device)
         _lib.check(lib.tdist_moe_group16_fwd(_lib.ptr(x), _lib.ptr(ids), _lib.ptr(wts), _lib.ptr(gate_up), _lib.ptr(down),
                                              _lib.ptr(hbuf), _lib.ptr(y), _lib.ptr(out), _lib.ptr(idx),
-                                             _lib.ptr(idx[nb_max * 16:]), _lib.ptr(idx[nb_max * 17:]), n, k, H, Ip, E, nb_max,
-                                             _lib.stream_handle()), "tdist_moe_group16_fwd")
+                                             _lib.ptr(idx[nb_max * bs:]), _lib.ptr(idx[nb_max * (bs + 1):]), n, k, H, Ip, E,
+                                             nb_max, bs, _lib.stream_handle()), "tdist_moe_group16_fwd")
         return out
     hbuf = torch.empty((n * k, Ip), dtype=x.dtype, device=x.device)
     _lib.check(lib.tdist_moe_decode_gate_up(_lib.ptr(x), _lib.ptr(ids), _lib.ptr(gate_up), _lib.ptr(hbuf), n, k, Ip, H,
