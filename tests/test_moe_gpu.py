@@ -181,6 +181,43 @@ def test_moe_block_grouped_by_expert_in_blocks_of_sixteen(n, H, I, E, topk, monk
     assert torch.isfinite(out2.float()).all() and torch.equal(out2[0], out[0]) and torch.equal(out2[3:], out[3:])
 
 
+@pytest.mark.parametrize("block_rows,wn", [(64, 1), (64, 2), (128, 1), (128, 2)])
+@pytest.mark.parametrize("n,H,I,E,topk", [(600, 2048, 768, 128, 8), (300, 512, 256, 8, 2), (200, 1024, 128, 12, 5)])
+def test_moe_block_grouped_by_expert_in_blocks_of_64_and_128(n, H, I, E, topk, block_rows, wn):
+    """Hundreds of tokens on one rank: pairs sorted by expert into 64- / 128-row blocks, gathered activations, the mid-M
+    GEMM body per block for gate_up and down, weighted top-k sum through the inverse map (``moe_group_mid_fwd``)
+    against fp32 PyTorch; skewed routing, one expert without tokens, ids out of range contribute nothing."""
+    from triton_distributed_gh_amd.ops.moe import moe_group_mid_fwd, moe_group_mid_supported
+
+    torch.manual_seed(n + topk)
+    dev, bf = "cuda", torch.bfloat16
+    x = (torch.rand(n, H, device=dev) * 2 - 1).to(bf)
+    gate_up = ((torch.rand(E, 2 * I, H, device=dev) * 2 - 1) * 0.05).to(bf)
+    down = ((torch.rand(E, H, I, device=dev) * 2 - 1) * 0.05).to(bf)
+    pick = torch.rand(n, E - 1, device=dev) * torch.linspace(1.0, 0.2, E - 1, device=dev)
+    ids = torch.topk(pick, topk, dim=1).indices.int()
+    wts = torch.rand(n, topk, device=dev) + 0.1
+    wts = wts / wts.sum(-1, keepdim=True)
+    assert moe_group_mid_supported(x, gate_up, down, topk)
+    xf = x.float()
+    ref = torch.zeros(n, H, device=dev)
+    for e in range(E):
+        tok, k = torch.where(ids == e)
+        if tok.numel() == 0:
+            continue
+        gu = (xf[tok] @ gate_up[e].float().t()).to(bf).float()
+        h = (torch.nn.functional.silu(gu[:, :I]) * gu[:, I:]).to(bf).float()
+        ref.index_add_(0, tok, (h @ down[e].float().t()).to(bf).float() * wts[tok, k, None])
+    out = moe_group_mid_fwd(x, ids, wts, gate_up, down, block_rows=block_rows, wn=wn)
+    torch.testing.assert_close(out.float(), ref, atol=2e-2 * ref.abs().max().item(), rtol=2e-2)
+    bad = ids.clone()
+    bad[1, 0] = 0x7fffffff
+    bad[2, 1] = -3
+    out2 = moe_group_mid_fwd(x, bad, wts, gate_up, down, block_rows=block_rows, wn=wn)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out2.float()).all() and torch.equal(out2[0], out[0]) and torch.equal(out2[3:], out[3:])
+
+
 @pytest.mark.parametrize("n,E,k,renorm", [(1, 128, 8, True), (7, 128, 8, False), (33, 8, 2, True), (4, 1000, 10, True),
                                           (300, 64, 6, True), (2, 4, 4, True)])
 def test_router_epilogue_matches_torch_topk(n, E, k, renorm):

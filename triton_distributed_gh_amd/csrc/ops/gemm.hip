@@ -1368,11 +1368,12 @@ TDIST_API int tdist_moe_decode_down(const void* hbuf, const int* ids, const floa
 // on it.
 __global__ __launch_bounds__(1024) void moe_align16_kernel(const int* __restrict__ ids, int n, int E,
                                                            int* __restrict__ sorted_ids, int* __restrict__ expert_of_block,
-                                                           int* __restrict__ meta, int nb_max, int bs) {
-  // bs: rows per block (16 or 32)
-  __shared__ int cnt[1024], off[1024], pos[1024];
+                                                           int* __restrict__ meta, int nb_max, int bs,
+                                                           int* __restrict__ pos = nullptr) {
+  // bs: rows per block; pos (optional): pos[pair] = its row in sorted order, -1 for a pair with an id out of range
+  __shared__ int cnt[1024], off[1024], pos_e[1024];
   const int tid = threadIdx.x;
-  cnt[tid] = 0, pos[tid] = 0;
+  cnt[tid] = 0, pos_e[tid] = 0;
   __syncthreads();
   for (int i = tid; i < n; i += 1024) {
     const int e = ids[i];
@@ -1399,8 +1400,11 @@ __global__ __launch_bounds__(1024) void moe_align16_kernel(const int* __restrict
   for (int i = tid; i < n; i += 1024) {
     const int e = ids[i];
     if ((unsigned)e < (unsigned)E) {
-      const int slot = off[e] * bs + atomicAdd(&pos[e], 1);
+      const int slot = off[e] * bs + atomicAdd(&pos_e[e], 1);
       if (slot < nb_max * bs) sorted_ids[slot] = i;
+      if (pos) pos[i] = slot < nb_max * bs ? slot : -1;
+    } else if (pos) {
+      pos[i] = -1;
     }
   }
   if (tid < E)
@@ -1583,6 +1587,19 @@ __global__ __launch_bounds__(256) void moe_topk_sum_kernel(const float* __restri
     }
     *(uint2*)(out + (long long)t * H + c) = uint2{Frag<true>::pack2(acc.x, acc.y), Frag<true>::pack2(acc.z, acc.w)};
   }
+}
+
+// The sort by expert on its own (the first launch of tdist_moe_group16_fwd) with any block height and, optionally, the
+// inverse map pos[pair] -> sorted row: what the 64- / 128-row grouped form (csrc/ops/moe_group_mid.hip) starts from.
+TDIST_API int tdist_moe_group_align(const int* ids, int pairs, int E, int* sorted_ids, int* expert_of_block, int* pos,
+                                    int* meta, int nb_max, int block_rows, void* stream) {
+  TDIST_REQUIRE(pairs > 0 && E > 0 && E <= 1024 && block_rows >= 16 && block_rows % 16 == 0, "bad pair / expert count or block height");
+  TDIST_REQUIRE(nb_max >= pairs / block_rows + E, "nb_max must be at least pairs / block_rows + E");
+  TDIST_REQUIRE(ids && sorted_ids && expert_of_block && meta, "null operand");
+  hipLaunchKernelGGL(moe_align16_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ids, pairs, E, sorted_ids, expert_of_block,
+                     meta, nb_max, block_rows, pos);
+  TDIST_HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 // out[t, :] = sum over k of x[t * topk + k, :] for bf16 rows (fp32 accumulation): the top-k reduce of the grouped-GEMM

@@ -21,7 +21,9 @@ from ..ops.allgather import create_fast_allgather_context, fast_allgather
 from ..ops.allreduce import all_reduce, create_allreduce_ctx
 from ..ops.gemm import gemm_nt, gemm_supported
 from ..ops.moe import (ag_group_gemm, create_ag_group_gemm_context, create_moe_rs_context, MOE_DECODE_MAX_TOKENS, MOE_GROUP16_MAX_TOKENS, group16_row_limit, moe_decode_fwd,
-                       moe_decode_supported, moe_route, moe_route_supported, run_moe_reduce_rs)
+                       moe_decode_supported, moe_group_mid_fwd, moe_group_mid_preferred, moe_group_mid_supported, moe_route,
+                       moe_route_supported,
+                       run_moe_reduce_rs)
 from ..utils.distributed import get_env
 from .tp_mlp import shard_local
 
@@ -231,9 +233,17 @@ class TP_MoE:
                 and x2.shape[1] % 2 == 0 and self._decode_tp_ok(x2)):
             return self._decode_fwd_tp(x2).reshape(shape)
         wts, ids = self._route(x2, fused=True)
-        if self.world_size == 1 and moe_decode_supported(x2, self.gate_up_proj, self.down_proj, self.top_k):
-            # a decode step: two weight-streaming launches over the tokens' own experts (ops/moe.py: moe_decode_fwd)
-            return moe_decode_fwd(x2, ids, wts, self.gate_up_proj, self.down_proj).view(shape)
+        if self.world_size == 1:
+            E, two_ip, H = self.gate_up_proj.shape
+            mid = (moe_group_mid_supported(x2, self.gate_up_proj, self.down_proj, self.top_k)
+                   and moe_group_mid_preferred(x2.shape[0], self.top_k, E, H, two_ip // 2))
+            if not mid and moe_decode_supported(x2, self.gate_up_proj, self.down_proj, self.top_k):
+                # a decode step: weight-streaming launches over the tokens' own experts, per (token, expert) pair or per
+                # sixteen-row block of an expert (ops/moe.py: moe_decode_fwd)
+                return moe_decode_fwd(x2, ids, wts, self.gate_up_proj, self.down_proj).view(shape)
+            if mid:
+                # tens to a few hundred rows per expert: blocks of 64 / 128 rows on the mid-M GEMM body
+                return moe_group_mid_fwd(x2, ids, wts, self.gate_up_proj, self.down_proj).view(shape)
         full_w, full_ids = self._gather_meta(wts, ids)
         h = self.ag_group_gemm(x2, self.gate_up_proj, ctx=self.ag_ctx, full_topk_ids=full_ids.contiguous())
         h = self._act(h)

@@ -593,6 +593,91 @@ def moe_decode_fwd(x: torch.Tensor, topk_ids: torch.Tensor, topk_weights: torch.
     return out
 
 
+# ---- a few hundred to a few thousand tokens on one rank: rows grouped by expert in blocks of 64 / 128 -------------
+# Measured per layer call (scripts/dev/probe_moe_layer_tokens.py, profiles/r3/moe_group16.md):
+#   Qwen3-30B-A3B (128 experts of 9.4 MB, top-8), 64-row blocks, 64 columns per workgroup: 335 - 351 us from 64 to 768
+#   tokens, 408 at 1024, 500 at 1536, 575 at 2048 - against 350 (256 tokens) .. 438 (448) for the sixteen-row form and
+#   505 / 525 / 564 us at 512 / 1024 / 2048 tokens for the grouped GEMM on 256-row tiles;
+#   Mixtral-8x7B (8 experts of 352 MB, top-2): 64-row blocks x 128 columns 630 us from 32 to 128 tokens, 128-row blocks
+#   695 - 713 us up to 256 tokens, 992 at 512 - against 495 / 550 / 647 us at 32 / 48 / 64 tokens for the sixteen-row
+#   form and 837 / 854 / 910 us at 128 / 256 / 512 tokens for the grouped GEMM.
+MOE_GROUP_MID = os.environ.get("TDIST_MOE_GROUP_MID", "1") != "0"
+# rows per expert (on average) where this form takes over from the sixteen-row form, and where the grouped GEMM on
+# 256-row tiles takes over from it (experts up to MOE_GROUP16_BIG_EXPERT_BYTES / larger ones)
+MOE_GROUP_MID_FROM_ROWS = int(os.environ.get("TDIST_MOE_GROUP_MID_FROM_ROWS", "15"))
+MOE_GROUP_MID_FROM_ROWS_BIG = int(os.environ.get("TDIST_MOE_GROUP_MID_FROM_ROWS_BIG", "12"))
+MOE_GROUP_MID_ROWS_PER_EXPERT = int(os.environ.get("TDIST_MOE_GROUP_MID_ROWS_PER_EXPERT", "100"))
+MOE_GROUP_MID_ROWS_PER_BIG_EXPERT = int(os.environ.get("TDIST_MOE_GROUP_MID_ROWS_PER_BIG_EXPERT", "80"))
+
+
+def moe_group_mid_preferred(n: int, topk: int, E: int, H: int, Ip: int) -> bool:
+    """Whether ``n`` tokens are past the point where the 64- / 128-row form beats the sixteen-row decode form."""
+    big = 3 * H * Ip * 2 > MOE_GROUP16_BIG_EXPERT_BYTES
+    return n * topk > (MOE_GROUP_MID_FROM_ROWS_BIG if big else MOE_GROUP_MID_FROM_ROWS) * E
+MOE_GROUP_MID_BLOCK = int(os.environ.get("TDIST_MOE_GROUP_MID_BLOCK", "0"))      # 64 / 128 force a block height
+MOE_GROUP_MID_WN = int(os.environ.get("TDIST_MOE_GROUP_MID_WN", "0"))            # 1 / 2 force 64 / 128 columns per workgroup
+
+
+def moe_group_mid_supported(x: torch.Tensor, gate_up: torch.Tensor, down: torch.Tensor, topk: int) -> bool:
+    """Shapes ``moe_group_mid_fwd`` takes: bf16 on the GPU, ``gate_up [E, 2 Ip, H]`` / ``down [E, H, Ip]`` contiguous,
+    H and Ip multiples of 64 (>= 128), at most 1024 experts, and no more than ``MOE_GROUP_MID_ROWS_PER_EXPERT`` (large
+    experts: ``MOE_GROUP_MID_ROWS_PER_BIG_EXPERT``) rows per expert on average."""
+    if not (MOE_GROUP_MID and x.is_cuda and x.dim() == 2 and x.dtype == torch.bfloat16 == gate_up.dtype == down.dtype):
+        return False
+    n, H = x.shape
+    E, two_ip, H2 = gate_up.shape
+    Ip = two_ip // 2
+    big = 3 * H * Ip * 2 > MOE_GROUP16_BIG_EXPERT_BYTES
+    limit = (MOE_GROUP_MID_ROWS_PER_BIG_EXPERT if big else MOE_GROUP_MID_ROWS_PER_EXPERT) * E
+    return (n > 0 and H2 == H and tuple(down.shape) == (E, H, Ip) and H % 64 == 0 and H >= 128 and Ip % 64 == 0
+            and Ip >= 128 and E <= 1024 and gate_up.is_contiguous() and down.is_contiguous() and x.is_contiguous()
+            and n * topk <= limit and n * topk // 64 + E <= 65535)
+
+
+def moe_group_mid_fwd(x: torch.Tensor, topk_ids: torch.Tensor, topk_weights: torch.Tensor, gate_up: torch.Tensor,
+                      down: torch.Tensor, block_rows: Optional[int] = None, wn: Optional[int] = None) -> torch.Tensor:
+    """The MoE block (same result as ``moe_decode_fwd``) for token counts where an expert has tens to a few hundred
+    rows: pairs sorted by expert into blocks of 64 or 128 rows, activations gathered into that order, every block a
+    row pass of the mid-M GEMM against its expert (csrc/ops/moe_group_mid.hip), SiLU * up, the same for ``down``, and
+    the weighted sum of each token's top-k rows through the inverse map of the sort.  Six launches on static grids.
+    Reference role: layers/nvidia/tp_moe.py at world size 1 (ag_group_gemm + moe_reduce_rs without the collectives)."""
+    from .elementwise import silu_mul
+
+    n, H = x.shape
+    k = topk_ids.shape[1]
+    E, two_ip, _ = gate_up.shape
+    Ip = two_ip // 2
+    pairs = n * k
+    big = 3 * H * Ip * 2 > MOE_GROUP16_BIG_EXPERT_BYTES
+    if block_rows is None:       # 128-row blocks only pay for experts the caches cannot share between blocks
+        block_rows = MOE_GROUP_MID_BLOCK or (128 if big and pairs > 32 * E else 64)
+    ids = topk_ids.to(torch.int32).contiguous()
+    wts = topk_weights.to(torch.float32).contiguous()
+    nb_max = pairs // block_rows + E
+    rows = nb_max * block_rows
+    dev = x.device
+    idx = torch.empty(rows + nb_max + pairs + 2, dtype=torch.int32, device=dev)
+    sorted_ids, eob, pos, meta = idx[:rows], idx[rows:rows + nb_max], idx[rows + nb_max:rows + nb_max + pairs], idx[rows + nb_max + pairs:]
+    xs = torch.empty((rows, H), dtype=x.dtype, device=dev)
+    gu = torch.empty((rows, two_ip), dtype=x.dtype, device=dev)
+    y = torch.empty((rows, H), dtype=x.dtype, device=dev)
+    out = torch.empty((n, H), dtype=x.dtype, device=dev)
+    lib, st = _lib.hip(), _lib.stream_handle()
+    _lib.check(lib.tdist_moe_group_align(_lib.ptr(ids), pairs, E, _lib.ptr(sorted_ids), _lib.ptr(eob), _lib.ptr(pos),
+                                         _lib.ptr(meta), nb_max, block_rows, st), "tdist_moe_group_align")
+    _lib.check(lib.tdist_moe_gather_rows(_lib.ptr(x), _lib.ptr(sorted_ids), _lib.ptr(meta), _lib.ptr(xs), k, H, block_rows,
+                                         nb_max, st), "tdist_moe_gather_rows")
+    wn = wn or MOE_GROUP_MID_WN or (2 if big else 1)
+    _lib.check(lib.tdist_moe_group_mid_gemm(_lib.ptr(xs), _lib.ptr(gate_up), _lib.ptr(gu), _lib.ptr(eob), _lib.ptr(meta), nb_max,
+                                            block_rows, wn, two_ip, H, st), "tdist_moe_group_mid_gemm")
+    h = silu_mul(gu)                 # (rows of unused blocks hold whatever was in memory: nothing reads them)
+    _lib.check(lib.tdist_moe_group_mid_gemm(_lib.ptr(h), _lib.ptr(down), _lib.ptr(y), _lib.ptr(eob), _lib.ptr(meta), nb_max,
+                                            block_rows, wn, H, Ip, st), "tdist_moe_group_mid_gemm")
+    _lib.check(lib.tdist_moe_topk_sum_gather(_lib.ptr(y), _lib.ptr(pos), _lib.ptr(wts), _lib.ptr(out), n, k, H, st),
+               "tdist_moe_topk_sum_gather")
+    return out
+
+
 def moe_route_supported(logits: torch.Tensor, topk: int) -> bool:
     return (logits.is_cuda and logits.dtype == torch.bfloat16 and logits.dim() == 2 and logits.stride(1) == 1
             and logits.shape[1] <= 1024 and 0 < topk <= min(64, logits.shape[1]) and logits.shape[0] > 0)
