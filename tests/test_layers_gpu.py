@@ -182,6 +182,8 @@ def test_tp_moe_matches_expert_loop(w, T, H, I, E, topk):
         for m in moes:
             m._init_parameters(tree)
         vc.collective(lambda r, env: moes[r]._init_ctx(T, ag_streams=[vc.side_streams[r]]))
+        for m in moes:
+            m.dec_per = 0       # this test is about the AG + grouped GEMM / grouped GEMM + RS pair: no gather / all-reduce form
         per = T // w
         torch.cuda.synchronize()
         for it in range(2):
@@ -192,7 +194,7 @@ def test_tp_moe_matches_expert_loop(w, T, H, I, E, topk):
 
 
 @pytest.mark.parametrize("w,T,H,I,E,topk", [(2, 8, 512, 512, 8, 2), (4, 16, 1024, 1024, 16, 4), (2, 2, 512, 512, 8, 8),
-                                            (2, 64, 512, 512, 8, 2), (4, 96, 1024, 1024, 16, 4)])
+                                            (2, 64, 512, 512, 8, 2), (4, 96, 1024, 1024, 16, 4), (2, 200, 512, 512, 8, 2)])
 def test_tp_moe_decode_path_on_several_ranks(w, T, H, I, E, topk):
     """A decode-sized batch on a tensor-parallel MoE layer: rows all-gathered, every rank runs all tokens against its
     slice of the experts with the decode launches (per pair, or - the cases with 64 and 96 tokens - grouped by expert
@@ -216,16 +218,21 @@ def test_tp_moe_decode_path_on_several_ranks(w, T, H, I, E, topk):
         return ref
 
     calls = {"n": 0}
-    real = moe_ops.moe_decode_fwd
+    real, real_mid = moe_ops.moe_decode_fwd, moe_ops.moe_group_mid_fwd
 
     def counted(*a, **k):
         calls["n"] += 1
         return real(*a, **k)
 
+    def counted_mid(*a, **k):          # (the case with 200 tokens: 64-row blocks on the mid-M GEMM body)
+        calls["n"] += 1
+        return real_mid(*a, **k)
+
     vc = VirtualCluster(w, heap_bytes=1 << 28)
     try:
         import triton_distributed_gh_amd.layers.tp_moe as tp_moe_mod
         tp_moe_mod.moe_decode_fwd = counted
+        tp_moe_mod.moe_group_mid_fwd = counted_mid
         moes = [TP_MoE(rank=r, world_size=w, env=vc.envs[r]) for r in range(w)]
         for m in moes:
             m._init_parameters(tree)
@@ -248,8 +255,14 @@ def test_tp_moe_decode_path_on_several_ranks(w, T, H, I, E, topk):
         # a prefill-sized call (grouped GEMM pair) between decode calls
         big = (torch.rand(256, H, device="cuda") * 2 - 1).to(BF)
         torch.cuda.synchronize()
+        saved = [m.dec_per for m in moes]
+        for m in moes:
+            m.dec_per = 0                  # (no row budget for the gather / all-reduce form: the grouped-GEMM pair runs)
         outs = vc.run(lambda r, env: moes[r].dist_triton_fwd(big[r * (256 // w):(r + 1) * (256 // w)].contiguous()))
+        for m, v in zip(moes, saved):
+            m.dec_per = v
         assert _rel(torch.cat(outs), reference(big)) < 4e-2
+        assert calls["n"] == 3 * w, "the prefill-sized call took the grouped-GEMM pair"
         graphs, static = [], [None] * w
         for r in range(w):
             g = torch.cuda.CUDAGraph()
@@ -264,6 +277,7 @@ def test_tp_moe_decode_path_on_several_ranks(w, T, H, I, E, topk):
             assert _rel(torch.cat(static), reference(x)) < 4e-2, f"replay {it}"
     finally:
         tp_moe_mod.moe_decode_fwd = real
+        tp_moe_mod.moe_group_mid_fwd = real_mid
         vc.close()
 
 
@@ -293,6 +307,8 @@ def test_tp_moe_replays_from_graph(w, T, H, I, E, topk):
         for m in moes:
             m._init_parameters(tree)
         vc.collective(lambda r, env: moes[r]._init_ctx(T, ag_streams=[vc.side_streams[r]]))
+        for m in moes:
+            m.dec_per = 0       # this test is about the AG + grouped GEMM / grouped GEMM + RS pair: no gather / all-reduce form
         per = T // w
         xs = [torch.zeros(per, H, device="cuda", dtype=BF) for _ in range(w)]
 

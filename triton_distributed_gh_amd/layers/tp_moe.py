@@ -20,11 +20,14 @@ from ..ops import elementwise
 from ..ops.allgather import create_fast_allgather_context, fast_allgather
 from ..ops.allreduce import all_reduce, create_allreduce_ctx
 from ..ops.gemm import gemm_nt, gemm_supported
-from ..ops.moe import (ag_group_gemm, create_ag_group_gemm_context, create_moe_rs_context, MOE_DECODE_MAX_TOKENS, MOE_GROUP16_MAX_TOKENS, group16_row_limit, moe_decode_fwd,
+from ..ops.moe import (MOE_GROUP_MID, MOE_GROUP_MID_ROWS_PER_BIG_EXPERT, MOE_GROUP_MID_ROWS_PER_EXPERT, ag_group_gemm, create_ag_group_gemm_context, create_moe_rs_context, MOE_DECODE_MAX_TOKENS, MOE_GROUP16_MAX_TOKENS, group16_row_limit, moe_decode_fwd,
                        moe_decode_supported, moe_group_mid_fwd, moe_group_mid_preferred, moe_group_mid_supported, moe_route,
                        moe_route_supported,
                        run_moe_reduce_rs)
 from ..utils.distributed import get_env
+
+# most tokens (over all ranks) the gather -> all experts' local slices -> all-reduce form of the layer takes
+MOE_DECODE_TP_MAX_TOKENS = 2048
 from .tp_mlp import shard_local
 
 
@@ -104,7 +107,7 @@ class TP_MoE:
         # decode path on several ranks (``_decode_fwd_tp``): the tokens' rows are all-gathered (low-latency form),
         # every rank runs ALL tokens against its slice of the experts' intermediate dimension, partial sums are
         # all-reduced
-        self.dec_per = max(1, min(M, MOE_GROUP16_MAX_TOKENS) // w)
+        self.dec_per = max(1, min(M, MOE_DECODE_TP_MAX_TOKENS) // w)
         self.dec_x_ctx = self.dec_x_buf = self.dec_ar_ctx = None
         if w > 1 and env.backend == "hip":
             xb = self.dec_per * self.hidden_size * self.dtype.itemsize
@@ -210,7 +213,12 @@ class TP_MoE:
         fast_allgather(full, self.dec_x_ctx, mode="push_2d_ll")
         xall = full[:, :words].reshape(-1).view(x2.dtype).view(w * n_local, H)
         wts, ids = self._route(xall, fused=True)
-        part = moe_decode_fwd(xall, ids, wts, self.gate_up_proj, self.down_proj)
+        E, two_ip, _ = self.gate_up_proj.shape
+        if (moe_group_mid_supported(xall, self.gate_up_proj, self.down_proj, self.top_k)
+                and moe_group_mid_preferred(xall.shape[0], self.top_k, E, H, two_ip // 2)):
+            part = moe_group_mid_fwd(xall, ids, wts, self.gate_up_proj, self.down_proj)
+        else:
+            part = moe_decode_fwd(xall, ids, wts, self.gate_up_proj, self.down_proj)
         tot = all_reduce(part, ctx=self.dec_ar_ctx, output=torch.empty_like(part))
         return tot[self.rank * n_local:(self.rank + 1) * n_local]
 
@@ -220,9 +228,16 @@ class TP_MoE:
         E, two_ip, H = self.gate_up_proj.shape
         if not moe_decode_supported(x2[:1], self.gate_up_proj, self.down_proj, self.top_k):
             return False
-        return n_all <= MOE_DECODE_MAX_TOKENS or (n_all <= MOE_GROUP16_MAX_TOKENS and
-                                                  n_all * self.top_k <= group16_row_limit(E, H, two_ip // 2) and E <= 1024
-                                                  and two_ip // 2 >= 64)
+        if n_all <= MOE_DECODE_MAX_TOKENS or (n_all <= MOE_GROUP16_MAX_TOKENS and
+                                              n_all * self.top_k <= group16_row_limit(E, H, two_ip // 2) and E <= 1024
+                                              and two_ip // 2 >= 64):
+            return True
+        # (the 64- / 128-row form: same gather / all-reduce around it)
+        Ip = two_ip // 2
+        big = 3 * H * Ip * 2 > (32 << 20)
+        limit = (MOE_GROUP_MID_ROWS_PER_BIG_EXPERT if big else MOE_GROUP_MID_ROWS_PER_EXPERT) * E
+        return (MOE_GROUP_MID and n_all <= MOE_DECODE_TP_MAX_TOKENS and H % 64 == 0 and Ip % 64 == 0 and Ip >= 128
+                and E <= 1024 and n_all * self.top_k <= limit)
 
     @torch.inference_mode()
     def dist_triton_fwd(self, x: torch.Tensor):
