@@ -27,7 +27,7 @@ from ..ops.moe import (MOE_GROUP_MID, MOE_GROUP_MID_ROWS_PER_BIG_EXPERT, MOE_GRO
 from ..utils.distributed import get_env
 
 # most tokens (over all ranks) the gather -> all experts' local slices -> all-reduce form of the layer takes
-MOE_DECODE_TP_MAX_TOKENS = 2048
+MOE_DECODE_TP_MAX_TOKENS = 1024
 from .tp_mlp import shard_local
 
 
