@@ -45,6 +45,8 @@ def main():
         return model.inference(tok, pos, kv)
 
     modes = ["torch", "triton_dist_AR"] if env.world_size == 1 else ["torch", "triton_dist_AR", "triton_dist"]
+    if hasattr(model.layers[0].mlp, "num_experts"):          # MoE layers have the triton_dist form only
+        modes = ["torch", "triton_dist"]
     for mode in modes:
         if mode == "triton_dist_AR":
             model.init_triton_dist_AR_ctx(max_M=B * S)
