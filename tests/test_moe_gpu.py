@@ -181,10 +181,10 @@ def test_moe_block_grouped_by_expert_in_blocks_of_sixteen(n, H, I, E, topk, monk
     assert torch.isfinite(out2.float()).all() and torch.equal(out2[0], out[0]) and torch.equal(out2[3:], out[3:])
 
 
-@pytest.mark.parametrize("block_rows,wn", [(64, 1), (64, 2), (128, 1), (128, 2)])
+@pytest.mark.parametrize("block_rows,wn", [(32, 1), (32, 2), (64, 1), (64, 2), (128, 1), (128, 2)])
 @pytest.mark.parametrize("n,H,I,E,topk", [(600, 2048, 768, 128, 8), (300, 512, 256, 8, 2), (200, 1024, 128, 12, 5)])
 def test_moe_block_grouped_by_expert_in_blocks_of_64_and_128(n, H, I, E, topk, block_rows, wn):
-    """Hundreds of tokens on one rank: pairs sorted by expert into 64- / 128-row blocks, gathered activations, the mid-M
+    """Hundreds of tokens on one rank: pairs sorted by expert into 32- / 64- / 128-row blocks, gathered activations, the mid-M
     GEMM body per block for gate_up and down, weighted top-k sum through the inverse map (``moe_group_mid_fwd``)
     against fp32 PyTorch; skewed routing, one expert without tokens, ids out of range contribute nothing."""
     from triton_distributed_gh_amd.ops.moe import moe_group_mid_fwd, moe_group_mid_supported

@@ -113,10 +113,11 @@ TDIST_API int tdist_moe_gather_rows(const void* x, const int* sorted_ids, const 
 }
 
 // C [block_rows * nb_max, N] = per block: X rows @ W[expert]^T.  X [block_rows * nb_max, K], W [E, N, K]; bf16;
-// block_rows 64 or 128, wn 1 or 2 (64 / 128 columns per workgroup).
+// block_rows 32, 64 or 128, wn 1 or 2 (64 / 128 columns per workgroup).
 TDIST_API int tdist_moe_group_mid_gemm(const void* X, const void* W, void* C, const int* expert_of_block, const int* meta,
                                        int nb_max, int block_rows, int wn, int N, int K, void* stream) {
-  TDIST_REQUIRE(nb_max > 0 && nb_max <= 65535 && (block_rows == 64 || block_rows == 128) && (wn == 1 || wn == 2), "bad block plan");
+  TDIST_REQUIRE(nb_max > 0 && nb_max <= 65535 && (block_rows == 32 || block_rows == 64 || block_rows == 128) && (wn == 1 || wn == 2),
+                "bad block plan");
   TDIST_REQUIRE(N > 0 && N % 8 == 0 && K >= 128 && K % 64 == 0, "N must be a multiple of 8, K of 64 (>= 128)");
   TDIST_REQUIRE((((uintptr_t)X | (uintptr_t)W) & 15) == 0 && (((uintptr_t)C) & 7) == 0 && expert_of_block && meta,
                 "operands must be aligned");
@@ -124,6 +125,9 @@ TDIST_API int tdist_moe_group_mid_gemm(const void* X, const void* W, void* C, co
   uint16_t* c = (uint16_t*)C;
   hipStream_t s = (hipStream_t)stream;
   const long long es = (long long)N * K;
+  if (block_rows == 32)
+    return wn == 1 ? launch_group_mid<2, 1>(x, K, w, es, K, c, N, expert_of_block, meta, nb_max, N, K, s)
+                   : launch_group_mid<2, 2>(x, K, w, es, K, c, N, expert_of_block, meta, nb_max, N, K, s);
   if (block_rows == 64)
     return wn == 1 ? launch_group_mid<4, 1>(x, K, w, es, K, c, N, expert_of_block, meta, nb_max, N, K, s)
                    : launch_group_mid<4, 2>(x, K, w, es, K, c, N, expert_of_block, meta, nb_max, N, K, s);
