@@ -478,15 +478,19 @@ def run_moe_reduce_rs(x: torch.Tensor, weights: torch.Tensor, chosen_experts: to
 MOE_DECODE_MAX_TOKENS = int(os.environ.get("TDIST_MOE_DECODE_MAX_TOKENS", "16"))
 
 
-# Above MOE_DECODE_MAX_TOKENS tokens the (token, expert) pairs are grouped by expert into blocks of sixteen rows
-# (csrc/ops/gemm.hip: tdist_moe_group16_fwd) as long as an expert gets about two such blocks at most; from there on the
-# grouped GEMM on 256-row tiles (ag_group_gemm + run_moe_reduce_rs) takes over.
-# Measured on a Qwen3-30B-A3B layer (9.4 MB per expert: blocks of one expert run next to each other and share it in the
-# L2): 384 tokens = 24 rows per expert 467 us against 534 us for the grouped GEMM, 512 tokens = 32 rows 554 against 546.
-# An expert too large for the caches (Mixtral-8x7B: 8 experts of 350 MB, top-2) is streamed from memory again for every
-# block, so there the limit is 24 rows per expert on average (blocks of 32 rows from 12 on): 64 tokens 648 us against
-# 830 us for the grouped GEMM, 96 tokens 717 against 835, 128 tokens 995 against 850.  For such experts the grouped form also beats the per-pair kernels from the first token
-# on (1 / 4 / 16 tokens: 142 / 352 / 480 us against 158 / 565 / 2178; profiles/r3/moe_group16.md).
+# Once tokens share experts, the (token, expert) pairs are grouped by expert into blocks of sixteen rows
+# (csrc/ops/gemm.hip: tdist_moe_group16_fwd): every block streams its expert once.  How far that form is used:
+#   * on one rank up to MOE_GROUP_MID_FROM_ROWS rows per expert - there the 64-row form (moe_group_mid_fwd) takes over;
+#   * where that form is not available (several ranks with a thin slice of the experts, odd shapes) up to
+#     MOE_GROUP16_ROWS_PER_EXPERT rows per expert and MOE_GROUP16_MAX_TOKENS tokens; then the grouped GEMM on 256-row
+#     tiles (ag_group_gemm + run_moe_reduce_rs).
+# Measured on a Qwen3-30B-A3B layer (9.4 MB per expert: blocks of one expert run next to each other and share it in
+# the L2): 384 tokens = 24 rows per expert 467 us against 534 us for the grouped GEMM, 512 tokens = 32 rows 554 against
+# 546.  An expert too large for the caches (Mixtral-8x7B: 8 experts of 350 MB, top-2) is streamed from memory again
+# for every block, so there the limit is 24 rows per expert on average (blocks of 32 rows from 12 on): 64 tokens 648 us
+# against 830 us for the grouped GEMM, 96 tokens 717 against 835, 128 tokens 995 against 850.  For such experts the
+# grouped form also beats the per-pair kernels from the first token on (1 / 4 / 16 tokens: 142 / 352 / 480 us against
+# 158 / 565 / 2178; profiles/r3/moe_group16.md).
 MOE_GROUP16_MAX_TOKENS = int(os.environ.get("TDIST_MOE_GROUP16_MAX_TOKENS", "448"))
 MOE_GROUP16_ROWS_PER_EXPERT = int(os.environ.get("TDIST_MOE_GROUP16_ROWS_PER_EXPERT", "28"))
 MOE_GROUP16_ROWS_PER_BIG_EXPERT = int(os.environ.get("TDIST_MOE_GROUP16_ROWS_PER_BIG_EXPERT", "24"))
@@ -498,17 +502,17 @@ MOE_GROUP16_BIG_EXPERT_BYTES = 32 << 20
 MOE_GROUP_BLOCK_ROWS = int(os.environ.get("TDIST_MOE_GROUP_BLOCK_ROWS", "0"))
 MOE_GROUP32_FROM_ROWS = int(os.environ.get("TDIST_MOE_GROUP32_FROM_ROWS", "18"))
 MOE_GROUP32_FROM_ROWS_BIG = int(os.environ.get("TDIST_MOE_GROUP32_FROM_ROWS_BIG", "12"))
+# -1: the grouped form also takes MOE_DECODE_MAX_TOKENS tokens or fewer once the pairs outnumber half of the experts
+# (tokens then share experts often enough that streaming an expert once per block beats once per pair: Qwen3-30B-A3B,
+# 128 experts, top-8: 8 tokens 115 vs 116 us, 12 tokens 161 vs 143, 16 tokens 207 vs 163); 0: never below the limit;
+# 1: always
+MOE_GROUP16 = int(os.environ.get("TDIST_MOE_GROUP16", "-1"))
 
 
 def group16_row_limit(E: int, H: int, Ip: int) -> int:
     """Most (token, expert) pairs the expert-grouped decode form takes for this expert shape."""
     big = 3 * H * Ip * 2 > MOE_GROUP16_BIG_EXPERT_BYTES
     return (MOE_GROUP16_ROWS_PER_BIG_EXPERT if big else MOE_GROUP16_ROWS_PER_EXPERT) * E
-# -1: the grouped form also takes MOE_DECODE_MAX_TOKENS tokens or fewer once the pairs outnumber half of the experts
-# (tokens then share experts often enough that streaming an expert once per block beats once per pair: Qwen3-30B-A3B,
-# 128 experts, top-8: 8 tokens 115 vs 116 us, 12 tokens 161 vs 143, 16 tokens 207 vs 163); 0: never below the limit;
-# 1: always
-MOE_GROUP16 = int(os.environ.get("TDIST_MOE_GROUP16", "-1"))
 
 
 def _group16_takes(n: int, topk: int, E: int, Ip: int, H: int = 0) -> bool:
@@ -527,8 +531,8 @@ def moe_decode_supported(x: torch.Tensor, gate_up: torch.Tensor, down: torch.Ten
     """Shapes ``moe_decode_fwd`` takes: bf16 on the GPU, expert weights ``gate_up [E, 2 Ip, H]`` / ``down [E, H, Ip]``
     contiguous, H a multiple of 32, Ip of 32, and at most ``MOE_DECODE_MAX_TOKENS`` tokens (one launch pair over the
     (token, expert) pairs) or at most ``MOE_GROUP16_MAX_TOKENS`` tokens with on average no more than
-    ``MOE_GROUP16_ROWS_PER_EXPERT`` rows per expert (pairs grouped by expert in blocks of sixteen; ``group16_row_limit``).  ``max_tokens``
-    lowers the token limit (callers whose buffers are sized for fewer rows)."""
+    ``MOE_GROUP16_ROWS_PER_EXPERT`` rows per expert (pairs grouped by expert in blocks of sixteen;
+    ``group16_row_limit``).  ``max_tokens`` lowers the token limit (callers whose buffers are sized for fewer rows)."""
     if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.bfloat16 == gate_up.dtype == down.dtype):
         return False
     n, H = x.shape
