@@ -53,9 +53,9 @@ def moe_align_block_size(topk_ids: torch.Tensor, num_experts: int, world_size: i
     if not ids.is_cuda:
         return _align_cpu(ids, num_experts, world_size, rank, tokens_per_rank, cap)
     nb = cap // BLOCK_M
-    out = AlignedIndex(torch.empty(cap, dtype=torch.int32, device=dev), torch.zeros(nb, dtype=torch.int32, device=dev),
-                       torch.zeros((nb, 2), dtype=torch.int32, device=dev), torch.zeros(nb, dtype=torch.int32, device=dev),
-                       torch.zeros(2 + num_experts, dtype=torch.int32, device=dev))
+    z = torch.zeros(4 * nb + 2 + num_experts, dtype=torch.int32, device=dev)        # (one fill for the four zeroed arrays)
+    out = AlignedIndex(torch.empty(cap, dtype=torch.int32, device=dev), z[:nb], z[nb:3 * nb].view(nb, 2), z[3 * nb:4 * nb],
+                       z[4 * nb:])
     lib = _lib.hip()
     part = torch.empty(max(1, lib.tdist_moe_align_part_ints(n, num_experts, world_size)), dtype=torch.int32, device=dev)
     _lib.check(
