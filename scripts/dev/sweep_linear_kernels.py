@@ -34,6 +34,16 @@ def candidates(M, N, K):
     if M >= 32:
         for bm, bn in ((128, 128), (128, 256), (256, 256)):
             c[f"tile{bm}x{bn}"] = (lambda bm, bn: lambda x, w, o: gemm_nt_tiles(x, w, o, bm=bm, bn=bn))(bm, bn)
+    if M >= 160:
+        del c["mid"]
+        c["tile256x128"] = lambda x, w, o: gemm_nt_tiles(x, w, o, bm=256, bn=128)
+        c["tiles-auto"] = lambda x, w, o: gemm_nt_tiles(x, w, o)
+        for sk in (2, 3, 4):
+            c[f"tile128x256/{sk}"] = (lambda sk: lambda x, w, o: gemm_nt_tiles(x, w, o, bm=128, bn=256, split_k=sk))(sk)
+            c[f"tile256x256/{sk}"] = (lambda sk: lambda x, w, o: gemm_nt_tiles(x, w, o, bm=256, bn=256, split_k=sk))(sk)
+        c["native256"] = lambda x, w, o: gemm_nt(x, w, out=o, force_native=True)
+        if M <= 1024:
+            c["mid"] = lambda x, w, o: gemm_nt_mid(x, w, o)
     return c
 
 

@@ -31,6 +31,8 @@ DECODE_LIB_BYTES = int(os.environ.get("TDIST_DECODE_GEMM_LIB_MB", "0")) << 20
 # the band between the decode kernel and chip-filling 256x256 tiles: "native" (mid-M kernel) or "lib"
 MID_GEMM = os.environ.get("TDIST_MID_GEMM", "native")
 MID_MAX_M = int(os.environ.get("TDIST_MID_MAX_M", "1024"))
+# 0: the whole band up to MID_MAX_M rows on the mid-M kernel (A/B comparisons); default: above 128 rows the tile family
+MID_BAND_TILES = os.environ.get("TDIST_MID_BAND_TILES", "1") != "0"
 # decode shapes (M <= 16) with long K / mid-sized weights on the mid-M kernel's split-K: from this many rows on
 DECODE_SPLITK = os.environ.get("TDIST_DECODE_SPLITK", "0") != "0"
 DECODE_SPLITK_MIN_M = 1 if DECODE_SPLITK else int(os.environ.get("TDIST_DECODE_SPLITK_MIN_M", "9"))
@@ -116,6 +118,17 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
         if MID_GEMM == "lib" and not force_native:
             torch.matmul(a, b.t(), out=out)
             return out
+        # Above 128 rows the mid-M kernel re-streams the weights once per 128-row pass and the tile family is ahead
+        # except on narrow outputs at up to 256 rows (cold weights, scripts/dev/sweep_linear_kernels.py: 6144 x 4096 at
+        # 384 / 768 / 1024 rows 36 / 50 / 57 us on tiles against 45 / 82 / 82 us mid-M; 4096 x 12288 at 256 / 768 rows
+        # 50 / 83 against 58 / 125; 24576 x 4096 at 192 / 256 rows 67 / 69 against 92 / 99; but 4096 x 4096 at 192 / 256
+        # rows 21 / 23 us mid-M against 27 / 28).  From 640 rows on, weights of 48 MB and more do best on plain 256 x 256
+        # tiles even when those leave compute units idle (4096 x 12288 at 768 rows: 83 us against 100 for the plan's pick).
+        narrow = N <= 4608 and (M <= 192 or (M <= 256 and K <= 8192))       # (few column tiles: mid-M's K split fills the chip)
+        if M > 128 and not narrow and MID_BAND_TILES and gemm_tiles_supported(a, b) and not force_native:
+            if M >= 640 and N * K >= 24_000_000:
+                return gemm_nt_tiles(a, b, out, bm=256, bn=256, group_m=group_m)
+            return gemm_nt_tiles(a, b, out, group_m=group_m)
         if M <= MID_MAX_M:
             return gemm_nt_mid(a, b, out)
     # Decode shapes (M <= 16): the weight-streaming kernels (csrc/ops/gemm.hip: one row on the vector ALUs, 2 .. 16 rows
