@@ -5,7 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from triton_distributed_gh_amd.ops.gemm import gemm_nt
 from triton_distributed_gh_amd.utils.perf import graph_bench
 dev, bf = "cuda", torch.bfloat16
-shapes = [("qkv", 4096, 6144), ("o", 4096, 4096), ("gate_up", 4096, 24576), ("down", 12288, 4096), ("lm_head", 4096, 151936)]
+FAMILIES = {
+    "qwen3-8b": [("qkv", 4096, 6144), ("o", 4096, 4096), ("gate_up", 4096, 24576), ("down", 12288, 4096), ("lm_head", 4096, 151936)],
+    "qwen3-32b": [("qkv", 5120, 10240), ("o", 8192, 5120), ("gate_up", 5120, 51200), ("down", 25600, 5120)],
+    "llama3-70b": [("qkv", 8192, 10240), ("o", 8192, 8192), ("gate_up", 8192, 57344), ("down", 28672, 8192)],
+    "llama3-70b-tp8": [("qkv", 8192, 1280), ("o", 1024, 8192), ("gate_up", 8192, 7168), ("down", 3584, 8192)],
+}
+shapes = FAMILIES[os.environ.get("FAMILY", "qwen3-8b")]
 for name, K, N in shapes:
     copies = max(2, min(8, int(700e6 / (N * K * 2)) + 1))
     ws = [(torch.randn(N, K, device=dev) * 0.02).to(bf) for _ in range(copies)]
