@@ -311,3 +311,31 @@ def test_splitk_gemm_replays_from_a_graph():
         torch.cuda.synchronize()
         ref = a.float() @ b.float().t()
         torch.testing.assert_close(c.float(), ref, atol=2e-2 * ref.abs().max().item() / 4, rtol=2e-2)
+
+
+def test_table_of_measured_forms_dispatches_correctly():
+    """Every cell of the shipped table (tuned/gemm_mi355x.json) with a weight of at most 128 MB: ``gemm_nt`` takes the
+    table's form for it and the result matches fp32 PyTorch; the look-up falls back to the rules for shapes and row
+    counts the table does not hold."""
+    from triton_distributed_gh_amd.ops import gemm as G
+
+    table = G._gemm_table()
+    assert table, "the table of measured forms is part of the package"
+    bf = torch.bfloat16
+    checked = 0
+    for (N, K), cells in sorted(table.items()):
+        if N * K * 2 > (128 << 20):
+            continue
+        w = ((torch.rand(N, K, device="cuda") * 2 - 1) * 0.05).to(bf)
+        for M, form in sorted(cells.items()):
+            assert G._tuned_form(M, N, K) == form
+            x = (torch.rand(M, K, device="cuda") * 2 - 1).to(bf)
+            out = torch.full((M, N), float("nan"), device="cuda", dtype=bf)
+            assert G.run_gemm_form(form, x, w, out), (N, K, M, form)
+            ref = x.float() @ w.float().t()
+            torch.testing.assert_close(out.float(), ref, atol=2e-2 * ref.abs().max().item(), rtol=2e-2)
+            got = G.gemm_nt(x, w)               # (split-K forms add their partial sums in arrival order: not bit-equal)
+            torch.testing.assert_close(got.float(), ref, atol=2e-2 * ref.abs().max().item(), rtol=2e-2)
+            checked += 1
+    assert checked >= 20
+    assert G._tuned_form(7, 123456, 4096) is None and G._tuned_form(5000, 6144, 4096) is None

@@ -53,6 +53,90 @@ def gemm_supported(a: torch.Tensor, b: torch.Tensor) -> bool:
 _DECODE_BIAS_KERNELS = os.environ.get("TDIST_SKINNY128", "") != "0" and os.environ.get("TDIST_DECODE_DOT", "") != "0"
 
 
+# ---- measured forms per shape ---------------------------------------------------------------------------------------
+# `scripts/tune_gemm_table.py` times every kernel this module has for a list of (N, K) weight shapes at one row count
+# per bucket (cold weights) and writes the winners that beat the rules below by more than a few per cent to a JSON
+# file: {"N,K": {"<rows of the bucket's upper end>": "<form>"}}.  Forms: "dot:<K slices>" (one row), "s128:<WN><NW>"
+# (2 .. 16 rows), "mid" / "mid:<wn>:<splits>", "tile:<bm>x<bn>" / "tile:<bm>x<bn>/<K split>", "tiles" (the tile family's
+# own plan), "native256".  The table shipped with the package covers the projection shapes of Qwen3-8B / -32B,
+# Llama-3-8B / -70B (whole and as TP = 8 shards); TDIST_GEMM_TABLE names another file, "0" switches the look-up off.
+# Role in the reference: the tuned-config caches behind triton.autotune / the contextual autotuner (autotuner.py).
+GEMM_BUCKETS = (1, 4, 8, 16, 32, 64, 128, 192, 256, 384, 512, 768, 1024, 2048)
+_TABLE = None
+
+
+def _gemm_table() -> dict:
+    global _TABLE
+    if _TABLE is None:
+        _TABLE = {}
+        path = os.environ.get("TDIST_GEMM_TABLE", os.path.join(os.path.dirname(os.path.dirname(__file__)), "tuned",
+                                                                "gemm_mi355x.json"))
+        if path != "0" and os.path.exists(path):
+            import json
+
+            with open(path) as f:
+                raw = json.load(f)
+            _TABLE = {tuple(int(v) for v in k.split(",")): {int(m): form for m, form in cells.items()}
+                      for k, cells in raw.items() if "," in k}
+    return _TABLE
+
+
+def _tuned_form(M: int, N: int, K: int) -> Optional[str]:
+    cells = _gemm_table().get((N, K))
+    if not cells:
+        return None
+    for top in GEMM_BUCKETS:
+        if M <= top:
+            return cells.get(top)
+    return None
+
+
+def run_gemm_form(form: str, a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, group_m: int = 8) -> bool:
+    """Run ``a @ b^T`` into ``out`` on the kernel a table entry names; False if the form does not apply to this call
+    (wrong row count for the kernel, unsupported operands) - the caller then goes by its rules."""
+    M, K = a.shape
+    N = b.shape[0]
+    kind, _, arg = form.partition(":")
+    lib = _lib.hip()
+    bf16 = a.dtype == torch.bfloat16
+    if kind == "dot":
+        if not (bf16 and M <= 2 and K % 32 == 0):
+            return False
+        _lib.check(lib.tdist_gemm_nt_dot(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), M, N, K, ctypes.c_longlong(a.stride(0)),
+                                         ctypes.c_longlong(b.stride(0)), ctypes.c_longlong(out.stride(0)), 0, int(arg),
+                                         _lib.stream_handle()), "tdist_gemm_nt_dot")
+        return True
+    if kind == "s128":
+        if not (bf16 and 2 <= M <= 16):
+            return False
+        _lib.check(lib.tdist_gemm_nt_skinny128(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), M, N, K, ctypes.c_longlong(a.stride(0)),
+                                               ctypes.c_longlong(b.stride(0)), ctypes.c_longlong(out.stride(0)), int(arg[0]),
+                                               int(arg[1]), _lib.stream_handle()), "tdist_gemm_nt_skinny128")
+        return True
+    if kind == "mid":
+        if M > MID_MAX_M:
+            return False
+        wn, _, sp = arg.partition(":")
+        gemm_nt_mid(a, b, out, wn=int(wn or 0), splits=int(sp or 0))
+        return True
+    if kind in ("tile", "tiles"):
+        if not gemm_tiles_supported(a, b):
+            return False
+        if kind == "tiles":
+            gemm_nt_tiles(a, b, out, group_m=group_m)
+            return True
+        shape, _, sk = arg.partition("/")
+        bm, _, bn = shape.partition("x")
+        gemm_nt_tiles(a, b, out, bm=int(bm), bn=int(bn), split_k=int(sk or 0), group_m=group_m)
+        return True
+    if kind == "native256":
+        _lib.check(lib.tdist_gemm_nt(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), M, N, K, ctypes.c_longlong(a.stride(0)),
+                                     ctypes.c_longlong(b.stride(0)), ctypes.c_longlong(out.stride(0)), _DT[a.dtype], group_m,
+                                     _lib.stream_handle(), GEMM_VARIANT), "tdist_gemm_nt")
+        return True
+    return False
+
+
 def _big_head(M: int, N: int, K: int, variant, force_native: bool) -> bool:
     """17 .. 128 rows against more than 100k columns with K >= 3072: the band ``gemm_nt`` gives to 128 x 256 tiles."""
     return (16 < M <= 128 and (variant is None or variant == GEMM_VARIANT) and N >= 100_000 and K >= 3072
@@ -60,10 +144,12 @@ def _big_head(M: int, N: int, K: int, variant, force_native: bool) -> bool:
 
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, group_m: Optional[int] = None,
-            force_native: bool = False, variant: Optional[int] = None, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+            force_native: bool = False, variant: Optional[int] = None, bias: Optional[torch.Tensor] = None,
+            use_table: bool = True) -> torch.Tensor:
     """``a [M, K] @ b [N, K]^T`` (+ ``bias [N]``) -> [M, N] on the gfx950 kernels; shapes they do not take run on
     ``torch.matmul``.  The bias is added in the epilogue of the weight-streaming decode kernels (bf16, M <= 16) and as
-    a separate in-place add everywhere else."""
+    a separate in-place add everywhere else.  ``use_table=False`` ignores the table of measured forms (the tuner's
+    "what the rules pick" column)."""
     assert a.shape[1] == b.shape[1], f"K mismatch: {tuple(a.shape)} vs {tuple(b.shape)}"
     if bias is not None:
         M, K = a.shape
@@ -107,6 +193,10 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     # TDIST_MID_GEMM=lib hands the band to the library instead (A/B comparisons).
     # Up to 64 rows the mid-M kernel also beats the 256x256 tile at any width (LM heads: 42 vs 76 us at
     # 32768 x 4096, 144 vs 173 us at 151936 x 2048), up to 128 rows below ~100k columns.
+    if variant == GEMM_VARIANT and not force_native and use_table:
+        form = _tuned_form(M, N, K)
+        if form is not None and run_gemm_form(form, a, b, out, group_m):
+            return out
     # LM heads with more than 100k columns and K >= 3072 at 17 .. 128 rows: 128 x 256 tiles of the tile family stream the
     # weights once with half the padding of a 256-row tile and none of the split-K traffic (128256 x 4096 at 32 / 64 /
     # 128 rows: 183 / 188 / 200 us against 229 / 235 / 257 us mid-M and 201 / 213 / 237 us hipBLASLt; 256000 x 3072:
