@@ -18,6 +18,10 @@ FAMILIES = {          # (N, K) of qkv / o / gate_up / down (+ LM head)
     "llama3-70b": [(10240, 8192), (8192, 8192), (57344, 8192), (8192, 28672), (128256, 8192)],
     "llama3-70b-tp8": [(1280, 8192), (8192, 1024), (7168, 8192), (8192, 3584)],
     "qwen3-32b-tp8": [(1280, 5120), (5120, 1024), (6400, 5120), (5120, 3200)],
+    "qwen3-14b": [(7168, 5120), (5120, 5120), (34816, 5120), (5120, 17408)],
+    "seed-oss-36b": [(12288, 5120), (5120, 10240), (55296, 5120), (5120, 27648), (155136, 5120)],
+    "seed-oss-36b-tp8": [(1536, 5120), (5120, 1280), (6912, 5120), (5120, 3456)],
+    "qwen3-30b-a3b-attn": [(5120, 2048), (2048, 4096), (151936, 2048)],
 }
 
 
@@ -41,6 +45,7 @@ def main():
     ap.add_argument("--families", default=",".join(FAMILIES))
     ap.add_argument("--out", default=os.path.join(os.path.dirname(G.__file__), "..", "tuned", "gemm_mi355x.json"))
     ap.add_argument("--margin", type=float, default=0.04)
+    ap.add_argument("--merge", action="store_true", help="keep the cells of an existing output file for shapes not tuned now")
     ap.add_argument("--rows", default=",".join(str(v) for v in G.GEMM_BUCKETS))
     args = ap.parse_args()
     dev, bf = "cuda", torch.bfloat16
@@ -91,6 +96,12 @@ def main():
                 line += "  -> table"
             print(line, flush=True)
         del ws
+    if args.merge and os.path.exists(args.out):
+        with open(args.out) as f:
+            old = json.load(f)
+        for k, v in old.items():
+            if "," in k and k not in [f"{n},{kk}" for n, kk in shapes]:
+                table[k] = v
     with open(args.out, "w") as f:
         json.dump({"_about": "measured GEMM forms per (N,K) and row bucket on MI355X, bf16, cold weights; written by "
                              "scripts/tune_gemm_table.py", **table}, f, indent=1, sort_keys=True)
