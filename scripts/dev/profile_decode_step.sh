@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 for B in ${BATCHES:-1 4}; do
   O=gpurun_out/decode_bs$B
   mkdir -p $R/$O
-  timeout -s KILL 280 rocprofv3 --kernel-trace -d $R/$O/prof -o p -- python3 $R/benchmarks/bench_qwen3_mega.py --model Qwen/Qwen3-8B --layers 6 --iters 10 --bsz $B > $R/$O/run.log 2>&1 || { tail -5 $R/$O/run.log; exit 1; }
+  timeout -s KILL 280 rocprofv3 --kernel-trace -d $R/$O/prof -o p -- python3 $R/benchmarks/bench_qwen3_mega.py --model ${MODEL:-Qwen/Qwen3-8B} --layers 6 --iters 10 --bsz $B > $R/$O/run.log 2>&1 || { tail -5 $R/$O/run.log; exit 1; }
   tail -n 1 $R/$O/run.log
   DB=$(find $R/$O/prof -name '*results.db' | head -1)
   python3 $R/scripts/rocpd_kernel_stats.py $DB > $R/$O/stats.txt 2>&1
