@@ -22,6 +22,9 @@ FAMILIES = {          # (N, K) of qkv / o / gate_up / down (+ LM head)
     "seed-oss-36b": [(12288, 5120), (5120, 10240), (55296, 5120), (5120, 27648), (155136, 5120)],
     "seed-oss-36b-tp8": [(1536, 5120), (5120, 1280), (6912, 5120), (5120, 3456)],
     "qwen3-30b-a3b-attn": [(5120, 2048), (2048, 4096), (151936, 2048)],
+    "qwen2.5-7b": [(4608, 3584), (3584, 3584), (37888, 3584), (3584, 18944), (152064, 3584)],
+    "qwen2.5-72b": [(59136, 8192), (8192, 29568), (152064, 8192)],
+    "mixtral-8x7b-attn": [(6144, 4096), (4096, 4096), (32000, 4096)],
 }
 
 
