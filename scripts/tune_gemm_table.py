@@ -25,6 +25,11 @@ FAMILIES = {          # (N, K) of qkv / o / gate_up / down (+ LM head)
     "qwen2.5-7b": [(4608, 3584), (3584, 3584), (37888, 3584), (3584, 18944), (152064, 3584)],
     "qwen2.5-72b": [(59136, 8192), (8192, 29568), (152064, 8192)],
     "mixtral-8x7b-attn": [(6144, 4096), (4096, 4096), (32000, 4096)],
+    "llama3.2-3b": [(5120, 3072), (3072, 3072), (16384, 3072), (3072, 8192), (128256, 3072)],
+    "gemma2-9b": [(8192, 3584), (3584, 4096), (28672, 3584), (3584, 14336), (256000, 3584)],
+    "mistral-nemo-12b": [(6144, 5120), (5120, 4096), (28672, 5120), (5120, 14336), (131072, 5120)],
+    "llama3.1-405b-tp8": [(2304, 16384), (16384, 2048), (13312, 16384), (16384, 6656)],
+    "qwen3-235b-a22b-attn": [(9216, 4096), (4096, 8192)],
 }
 
 

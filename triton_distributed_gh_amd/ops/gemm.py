@@ -58,9 +58,9 @@ _DECODE_BIAS_KERNELS = os.environ.get("TDIST_SKINNY128", "") != "0" and os.envir
 # per bucket (cold weights) and writes the winners that beat the rules below by more than a few per cent to a JSON
 # file: {"N,K": {"<rows of the bucket's upper end>": "<form>"}}.  Forms: "dot:<K slices>" (one row), "s128:<WN><NW>"
 # (2 .. 16 rows), "mid" / "mid:<wn>:<splits>", "tile:<bm>x<bn>" / "tile:<bm>x<bn>/<K split>", "tiles" (the tile family's
-# own plan), "native256".  The table shipped with the package covers the projection shapes of Qwen3-8B / -14B / -32B,
-# Qwen2.5-7B / -72B, Llama-3-8B / -70B and Seed-OSS-36B (whole and, for the large ones, as TP = 8 shards); TDIST_GEMM_TABLE names another
-# file, "0" switches the look-up off.
+# own plan), "native256".  The table shipped with the package covers the projection shapes of fifteen models (Qwen3,
+# Qwen2.5, Llama-3.x, Seed-OSS-36B, Gemma-2-9B, Mistral-Nemo-12B - FAMILIES of the script - whole and, for the large
+# ones, as TP = 8 shards); TDIST_GEMM_TABLE names another file, "0" switches the look-up off.
 # Role in the reference: the tuned-config caches behind triton.autotune / the contextual autotuner (autotuner.py).
 GEMM_BUCKETS = (1, 4, 8, 16, 32, 64, 128, 192, 256, 384, 512, 768, 1024, 2048)
 _TABLE = None
