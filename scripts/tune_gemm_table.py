@@ -3,7 +3,7 @@
 For every weight shape (N, K) of the chosen model families and one row count per bucket, every kernel the package has
 for that row count is timed on COLD weights (copies of the matrix rotated inside a HIP graph, as a model step sees
 them) next to what gemm_nt's rules pick; a form enters the table where it beats the rules by more than MARGIN.
-    python scripts/tune_gemm_table.py [--families a,b] [--out file.json] [--margin 0.04]
+    python scripts/tune_gemm_table.py [--families a,b] [--shapes "N,K;N,K"] [--out file.json] [--margin 0.04] [--merge]
 """
 import argparse, ctypes, json, os, sys
 import torch
@@ -55,13 +55,17 @@ def main():
     ap.add_argument("--margin", type=float, default=0.04)
     ap.add_argument("--merge", action="store_true", help="keep the cells of an existing output file for shapes not tuned now")
     ap.add_argument("--rows", default=",".join(str(v) for v in G.GEMM_BUCKETS))
+    ap.add_argument("--shapes", default="", help='further weight shapes "N,K;N,K" (with --families "" only these)')
     args = ap.parse_args()
     dev, bf = "cuda", torch.bfloat16
     shapes = []
-    for fam in args.families.split(","):
+    for fam in [f for f in args.families.split(",") if f]:
         for s in FAMILIES[fam]:
             if s not in shapes:
                 shapes.append(s)
+    for s in [tuple(int(v) for v in t.split(",")) for t in args.shapes.split(";") if t]:
+        if s not in shapes:
+            shapes.append(s)
     table, log = {}, []
     for N, K in shapes:
         copies = max(2, min(8, int(700e6 / (N * K * 2)) + 1))

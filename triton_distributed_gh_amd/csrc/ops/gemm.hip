@@ -910,10 +910,21 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_skinny128_kernel(const uint16
 // Long K with a few hundred 64-column blocks (12800 x 8192: 200 workgroups of eight waves, one per compute unit, all
 // done at the same time) runs 36 - 42 us at 2 .. 16 rows with WN 8 / NW 8 against 44 - 52 us with WN 4 / NW 4, whose 400
 // workgroups sit one or two to a compute unit.
-static int skinny128_choice(int N, int K = 0) {
+// Cold weights at 4 / 8 / 16 rows over 88 weight shapes (scripts/tune_gemm_table.py): up to 2048 columns eight-column
+// blocks are 1.17 - 1.26 x faster (more workgroups than compute units again); between 4096 and 6144 columns 16-column
+// blocks make 256 .. 384 workgroups - some compute units stream two, the others one - and 32-column blocks of eight
+// waves run 1.05 - 1.24 x faster (5120 columns, K 1024 .. 4096); with K below 4096 a wave of four has less than two
+// batches of loads to overlap and eight waves per workgroup are 1.05 - 1.27 x ahead up to 16384 columns
+// (2048 x 2048, 3072 x 3072, 3584 x 3584, 8192 x 1024 / 3584).
+static int skinny128_choice(int N, int K = 0, int M = 16) {
   static const int v = getenv("TDIST_SKINNY128") ? atoi(getenv("TDIST_SKINNY128")) : -1;
   if (v >= 0) return v;
+  (void)M;
   if (K >= 8192 && N >= 12288) return 88;
+  if (N <= 2048) return K > 0 && K <= 2048 ? 28 : 14;
+  if (N > 4096 && N < 6144) return 48;
+  if (N > 8192 && N < 16384) return 88;      // (32-column blocks: 256 .. 512 workgroups, the same bad fit; 1.05 - 1.14 x)
+  if (K > 0 && K < 4096 && N < 16384) return N >= 6144 ? 48 : 28;
   return N >= 6144 ? 44 : 24;
 }
 
@@ -934,8 +945,18 @@ static void launch_dot(const uint16_t* X, const uint16_t* W, uint16_t* C, int M,
                        const uint16_t* G = nullptr, uint16_t* Hout = nullptr, float eps = 0.f) {
   const int cb = SILU ? 4 : 8;
   const dim3 grid((N + cb - 1) / cb);
+  const bool chosen = nw > 0;
   if (nw <= 0) nw = 4;
   while (nw > 1 && K < 64 * 8 * 2 * nw) nw >>= 1;
+  // Whole batches per wave: K = 5120 over four slices is two and a half batches each, and the half batch costs a
+  // whole one (cold weights, 5120 .. 155136 columns: two slices run 1.11 - 1.17 x faster than four; K = 3584 and 6656
+  // likewise with one).  TDIST_DOT_WHOLE_BATCHES=0 keeps the slice count of the rule above.
+  static const bool whole = !(getenv("TDIST_DOT_WHOLE_BATCHES") && atoi(getenv("TDIST_DOT_WHOLE_BATCHES")) == 0);
+  if (whole && !chosen) {
+    int n2 = nw;
+    while (n2 > 1 && K % (64 * 8 * n2) != 0) n2 >>= 1;
+    if (K % (64 * 8 * n2) == 0) nw = n2;
+  }
   const size_t lds = NORM ? (size_t)MR * ((size_t)K * 2 + 64) : 0;
   if (nw == 1)
     hipLaunchKernelGGL((gemm_nt_dot_kernel<1, MR, SILU, NORM>), grid, dim3(64), lds, s, X, W, C, M, N, K, ldx, ldw, ldc, R, G, Hout, eps);
@@ -984,7 +1005,7 @@ static void launch_skinny(const void* A, const void* B, void* C, int M, int N, i
       return;
     }
   }
-  if (const int ch = skinny128_choice(N, K); ch > 0 && M >= 2) {
+  if (const int ch = skinny128_choice(N, K, M); ch > 0 && M >= 2) {
     const uint16_t *a = (const uint16_t*)A, *b = (const uint16_t*)B;
     uint16_t* c = (uint16_t*)C;
     const int wn = ch / 10, nw = ch % 10;
@@ -1076,7 +1097,7 @@ TDIST_API int tdist_gemm_nt_norm(const void* X, const void* R, const void* G, fl
     else if (silu)
       hipLaunchKernelGGL((gemm_nt_skinny128_kernel<true, 2, 4, true, true>), dim3((N + 7) / 8), dim3(256), (size_t)lds, s, x, w,
                          c, M, N, K, ldx, ldw, ldc, r, g, h, eps);
-    else if (ch / 10 >= 4)
+    else if (ch / 10 >= 4 && N >= 6144)     // (the eight-wave shapes of the plain kernel are not built with the norm)
       hipLaunchKernelGGL((gemm_nt_skinny128_kernel<true, 4, 4, false, true>), dim3((N + 31) / 32), dim3(256), (size_t)lds, s, x,
                          w, c, M, N, K, ldx, ldw, ldc, r, g, h, eps);
     else

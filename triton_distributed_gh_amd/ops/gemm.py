@@ -144,6 +144,21 @@ def _big_head(M: int, N: int, K: int, variant, force_native: bool) -> bool:
             and not force_native)
 
 
+def _decode_takes_mid(M: int, N: int, K: int) -> bool:
+    """Decode shapes (M <= 16) that run on the mid-M kernel instead of the weight-streaming ones."""
+    if M > 16:
+        return False
+    if DECODE_SPLITK_MIN_M <= M and N < 12288 and K >= 8192:
+        return True
+    if DECODE_SPLITK_MIN_M > 16 or M < 2:
+        return False
+    if 4096 < N < 6144:
+        return K >= 5120 or (M >= 9 and K >= 3072)
+    # (the same with 32-column blocks between 8192 and 16384 columns: 10240 / 12288 / 15360 x 5120, 12288 x 3072 and
+    # 14336 x 3584 at 16 rows 1.15 - 1.24 x; with K = 4096 the 64-column streaming shape stays ahead)
+    return M >= 9 and 8192 < N < 16384 and K >= 3072 and K % 4096 != 0
+
+
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, group_m: Optional[int] = None,
             force_native: bool = False, variant: Optional[int] = None, bias: Optional[torch.Tensor] = None,
             use_table: bool = True) -> torch.Tensor:
@@ -160,7 +175,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
             out = torch.empty((M, N), dtype=a.dtype, device=a.device)
         fused = (_DECODE_BIAS_KERNELS and M <= 16 and a.dtype == torch.bfloat16 and gemm_supported(a, b)
                  and bias.is_contiguous() and out.stride(1) == 1 and out.stride(0) % 8 == 0 and out.data_ptr() % 16 == 0
-                 and not (DECODE_SPLITK_MIN_M <= M and N < 12288 and K >= 8192)
+                 and not _decode_takes_mid(M, N, K)
                  and not (DECODE_LIB_BYTES > 0 and K >= 4096 and N * K * 2 >= DECODE_LIB_BYTES))
         if fused:
             _lib.check(
@@ -229,7 +244,10 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     # From 12288 columns on the streaming kernel with 64-column blocks and eight K slices is ahead again (12800 x 8192 at
     # 16 rows: 42 us against 48 us mid-M, cold weights).
     # TDIST_DECODE_SPLITK_MIN_M moves the first row count (17 = never); TDIST_DECODE_SPLITK=1 is 1.
-    if DECODE_SPLITK_MIN_M <= M <= 16 and variant == GEMM_VARIANT and N < 12288 and K >= 8192:
+    # Between 4096 and 6144 columns the streaming kernel's grid is a bad fit (16-column blocks: 256 .. 384 workgroups on
+    # 256 compute units) and the mid-M kernel is ahead much earlier: 5120 columns, cold weights, 4 / 8 / 16 rows against
+    # the best streaming shape 1.19 / 1.27 / 1.47 x at K = 5120 and 1.41 / 1.53 x at K = 25600 (4 / 8 rows).
+    if M <= 16 and variant == GEMM_VARIANT and _decode_takes_mid(M, N, K):
         return gemm_nt_mid(a, b, out)
     # Otherwise decode shapes stay on the weight-streaming kernel.  Called back to back on ONE 100-270 MB layer the
     # library's 64x16x512 kernel looks faster (6.3-6.6 vs 4-5 TB/s), but there the weights partly sit in
