@@ -46,6 +46,27 @@ inline MidPlan mid_plan(int M, int N, int K, int num_cus, int force_wn, int forc
   pl.wn = narrow > num_cus ? 2 : 1;
   if (pl.mt <= 4 && narrow == 2 * num_cus) pl.wn = 1;
   if (pl.mt == 8 && narrow <= num_cus && 2 * narrow > num_cus && nst >= 8) pl.wn = 2;
+  // Two more from timing every form on 74 weight shapes with cold weights (scripts/tune_gemm_table.py):
+  //  * when the narrow grid with its K split fills less than 80 % of the CUs and the wide one a tenth of them more
+  //    (9216 columns at 64 rows: 144 workgroups narrow, 72 x 3 wide), the wide form is 1.1 - 1.3 x faster;
+  //  * at 128-row passes a narrow workgroup that is left with 2048 or more of K after the split re-reads so much of
+  //    the activations that the wide form with twice the splits wins (5120 x 10240 .. 27648 at 128 rows 1.11 - 1.22 x,
+  //    4096 x 14336 at 256 rows 1.08 x, 2304 x 16384 at 256 rows 1.66 x).
+  if (pl.wn == 1 && narrow <= num_cus && nst >= 8) {
+    const int cap = nst / 4 < 16 ? nst / 4 : 16;
+    auto grid_of = [&](int wn, int* split) {
+      const int blocks = ((N + 64 * wn - 1) / (64 * wn)) * pl.passes;
+      int sp = num_cus / blocks;
+      sp = sp > cap ? cap : sp;
+      sp = sp < 1 ? 1 : sp;
+      if (split) *split = sp;
+      return blocks * sp;
+    };
+    int s1 = 1;
+    const int g1 = grid_of(1, &s1), g2 = grid_of(2, nullptr);
+    if (10 * g1 < 8 * num_cus && 10 * (g2 - g1) >= num_cus) pl.wn = 2;
+    if (pl.mt == 8 && K / s1 >= 2048) pl.wn = 2;
+  }
   if (force_wn == 1 || force_wn == 2) pl.wn = force_wn;
   pl.ncb = (N + 64 * pl.wn - 1) / (64 * pl.wn);
   int splits = num_cus / (pl.ncb * pl.passes);

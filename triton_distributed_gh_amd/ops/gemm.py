@@ -230,7 +230,14 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
         # 50 / 83 against 58 / 125; 24576 x 4096 at 192 / 256 rows 67 / 69 against 92 / 99; but 4096 x 4096 at 192 / 256
         # rows 21 / 23 us mid-M against 27 / 28).  From 640 rows on, weights of 48 MB and more do best on plain 256 x 256
         # tiles even when those leave compute units idle (4096 x 12288 at 768 rows: 83 us against 100 for the plan's pick).
-        narrow = N <= 4608 and (M <= 192 or (M <= 256 and K <= 8192))       # (few column tiles: mid-M's K split fills the chip)
+        # With the mid-M plan taking 128-column strips where K is long, everything below 6144 columns stays on it up to
+        # 256 rows (5120 columns at 192 / 256 rows: 1.1 - 1.35 x against the tiles for K 1024 .. 27648), and 6144 .. 12288
+        # columns do best on 256 x 128 tiles there (1.07 - 1.16 x against the plan's pick).
+        # Short K at those widths is mid-M's as well (7680 x 2560 at 192 / 256 rows: 22 / 26 us against 29 / 31).
+        narrow = M <= 256 and (N < 6144 or (N <= 8192 and K < 4096))    # (few column tiles: mid-M's K split fills the chip)
+        if (128 < M <= 256 and 6144 <= N < 16384 and not narrow and K >= 2048 and MID_BAND_TILES and gemm_tiles_supported(a, b)
+                and not force_native):
+            return gemm_nt_tiles(a, b, out, bm=256, bn=128, group_m=group_m)
         if M > 128 and not narrow and MID_BAND_TILES and gemm_tiles_supported(a, b) and not force_native:
             if M >= 640 and N * K >= 24_000_000:
                 return gemm_nt_tiles(a, b, out, bm=256, bn=256, group_m=group_m)
