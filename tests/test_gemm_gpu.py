@@ -184,11 +184,14 @@ def test_decode_gemm_with_silu_mul_epilogue(M, I, K):
 @pytest.mark.parametrize("M", [1, 3, 5])
 @pytest.mark.parametrize("N,K", [(6144, 4096), (4096, 4096), (1000, 192), (16384, 1024), (40, 128)])
 @pytest.mark.parametrize("with_residual", [False, True])
-def test_decode_gemm_with_fused_rms_norm(M, N, K, with_residual):
+def test_decode_gemm_with_fused_rms_norm(M, N, K, with_residual, monkeypatch):
     """RMSNorm (+ residual add) folded into the decode GEMM vs the two kernels and vs fp32: every column-block
     size, partial column blocks, a K below one batch of loads per wave, strided activations."""
+    from triton_distributed_gh_amd.ops import gemm as gemm_mod
     from triton_distributed_gh_amd.ops.elementwise import rms_norm
     from triton_distributed_gh_amd.ops.gemm import gemm_nt_norm, norm_gemm_supported
+
+    monkeypatch.setattr(gemm_mod, "NORM_GEMM_MAX_M", 16)     # (the dispatch fuses up to two rows; the kernel takes 16)
 
     torch.manual_seed(M + N + K)
     xa = ((torch.rand(M, K + 64, device="cuda") * 2 - 1) * 3).bfloat16()
@@ -215,8 +218,11 @@ def test_decode_gemm_with_fused_rms_norm(M, N, K, with_residual):
 
 
 @pytest.mark.parametrize("M", [1, 4])
-def test_decode_gemm_with_fused_rms_norm_and_silu(M):
+def test_decode_gemm_with_fused_rms_norm_and_silu(M, monkeypatch):
+    from triton_distributed_gh_amd.ops import gemm as gemm_mod
     from triton_distributed_gh_amd.ops.gemm import gemm_nt_norm
+
+    monkeypatch.setattr(gemm_mod, "NORM_GEMM_MAX_M", 16)
 
     torch.manual_seed(M)
     K, I = 4096, 12288

@@ -8,6 +8,8 @@ from .qwen_moe import Qwen3MoE
 class AutoLLM:
     model_mapping = {
         "Qwen/Qwen3-0.6B": DenseLLM,
+        "Qwen/Qwen3-1.7B": DenseLLM,
+        "Qwen/Qwen3-4B": DenseLLM,
         "Qwen/Qwen3-8B": DenseLLM,
         "Qwen/Qwen3-14B": DenseLLM,
         "Qwen/Qwen3-32B": DenseLLM,

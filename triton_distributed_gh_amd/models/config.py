@@ -56,6 +56,8 @@ class ArchConfig:
 
 KNOWN_ARCHS = {
     "Qwen/Qwen3-0.6B": ArchConfig(1024, 3072, 28, 16, 8, tie_word_embeddings=True),
+    "Qwen/Qwen3-1.7B": ArchConfig(2048, 6144, 28, 16, 8, tie_word_embeddings=True),
+    "Qwen/Qwen3-4B": ArchConfig(2560, 9728, 36, 32, 8, tie_word_embeddings=True),
     "Qwen/Qwen3-8B": ArchConfig(4096, 12288, 36, 32, 8),
     "Qwen/Qwen3-14B": ArchConfig(5120, 17408, 40, 40, 8),
     "Qwen/Qwen3-32B": ArchConfig(5120, 25600, 64, 64, 8),

@@ -500,12 +500,16 @@ def gemm_nt_silu_mul(a: torch.Tensor, gate_up: torch.Tensor) -> torch.Tensor:
     return silu_mul(gemm_nt(a, gate_up))
 
 
-NORM_GEMM_MAX_M = min(16, int(os.environ.get("TDIST_NORM_GEMM_MAX_M", "16")))
+# Rows up to which the norm is folded into the decode GEMM.  Every workgroup of the fused kernel normalises all rows
+# again, which pays for one and two rows only: 12 layers of Qwen3-4B at batch 2 / 3 / 4 / 8 take 1.025 / 1.069 / 1.123 /
+# 1.366 ms fused against 1.044 / 1.055 / 1.074 / 1.119 ms with the norm as its own launch, Qwen3-8B at batch 3 / 4
+# 1.330 / 1.379 against 1.341 / 1.364, Qwen3-14B at batch 4 2.197 against 2.161 (TDIST_NORM_GEMM_MAX_M, at most 16).
+NORM_GEMM_MAX_M = min(16, int(os.environ.get("TDIST_NORM_GEMM_MAX_M", "2")))
 
 
 def norm_gemm_supported(x: torch.Tensor, w: torch.Tensor, norm_w: torch.Tensor, residual: Optional[torch.Tensor]) -> bool:
-    """Shapes the decode GEMM takes with the RMSNorm folded in: at most 16 rows, bf16, the rows' normalised copy
-    (M x (2 K + 64) bytes) within 48 KiB of LDS."""
+    """Shapes the decode GEMM takes with the RMSNorm folded in: at most NORM_GEMM_MAX_M rows (the kernel itself takes
+    16), bf16, the rows' normalised copy (M x (2 K + 64) bytes) within 48 KiB of LDS."""
     M, K = x.shape
     return (x.is_cuda and M <= NORM_GEMM_MAX_M and x.dtype == torch.bfloat16 == w.dtype == norm_w.dtype and gemm_supported(x, w)
             and K % 32 == 0 and K >= 128 and M * (2 * K + 64) <= 48 * 1024 and norm_w.is_contiguous()
