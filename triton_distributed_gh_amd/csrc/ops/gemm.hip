@@ -949,14 +949,12 @@ static void launch_dot(const uint16_t* X, const uint16_t* W, uint16_t* C, int M,
   if (nw <= 0) nw = 4;
   while (nw > 1 && K < 64 * 8 * 2 * nw) nw >>= 1;
   // Whole batches per wave: K = 5120 over four slices is two and a half batches each, and the half batch costs a
-  // whole one (cold weights, 5120 .. 155136 columns: two slices run 1.11 - 1.17 x faster than four; K = 3584 and 6656
-  // likewise with one).  TDIST_DOT_WHOLE_BATCHES=0 keeps the slice count of the rule above.
+  // whole one (cold weights, 5120 .. 155136 columns: two slices run 1.11 - 1.17 x faster than four; 24 layers of
+  // Qwen3-32B 4.77 -> 4.41 ms).  Only from four slices to two: ONE slice per workgroup loses again (K = 2560: 36 layers
+  // of Qwen3-4B 2.58 ms with one slice against 2.39 ms with two; 5120 x 13824 30.6 against 27.0 us).
+  // TDIST_DOT_WHOLE_BATCHES=0 keeps four slices.
   static const bool whole = !(getenv("TDIST_DOT_WHOLE_BATCHES") && atoi(getenv("TDIST_DOT_WHOLE_BATCHES")) == 0);
-  if (whole && !chosen) {
-    int n2 = nw;
-    while (n2 > 1 && K % (64 * 8 * n2) != 0) n2 >>= 1;
-    if (K % (64 * 8 * n2) == 0) nw = n2;
-  }
+  if (whole && !chosen && nw == 4 && K % (64 * 8 * 4) == 64 * 8 * 2) nw = 2;
   const size_t lds = NORM ? (size_t)MR * ((size_t)K * 2 + 64) : 0;
   if (nw == 1)
     hipLaunchKernelGGL((gemm_nt_dot_kernel<1, MR, SILU, NORM>), grid, dim3(64), lds, s, X, W, C, M, N, K, ldx, ldw, ldc, R, G, Hout, eps);
