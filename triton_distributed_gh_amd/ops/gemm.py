@@ -235,6 +235,20 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
         # columns do best on 256 x 128 tiles there (1.07 - 1.16 x against the plan's pick).
         # Short K at those widths is mid-M's as well (7680 x 2560 at 192 / 256 rows: 22 / 26 us against 29 / 31).
         narrow = M <= 256 and (N < 6144 or (N <= 8192 and K < 4096))    # (few column tiles: mid-M's K split fills the chip)
+        # Further up it stays ahead where the tiles are fewest: up to 2048 columns at 512 rows (1.3 x), below 4096
+        # columns at 384 rows (1.05 - 1.27 x), K up to 1280 at up to 512 rows and 8192 columns (1.15 - 1.4 x; at 768 rows
+        # 7168 x 1024 takes 27 us there against 17 on tiles).  Of the tile shapes, 128 x 256 is ahead at 257 .. 384 rows
+        # and 4096 .. 8192 columns (1.04 - 1.14 x against the plan's pick), 256 x 128 at 385 .. 512 rows and 2560 .. 7168
+        # columns (1.07 - 1.17 x; K up to 8192, to 16384 up to 4096 columns) and at 513 .. 768 rows up to 3584 columns
+        # (2560 x 9728: 51 us against 70).
+        narrow = narrow or (M <= 512 and N <= 2048) or (M <= 384 and N < 4096) or (M <= 512 and N <= 8192 and K <= 1280)
+        if M > 256 and not narrow and MID_BAND_TILES and gemm_tiles_supported(a, b) and not force_native:
+            if M <= 384 and 4096 <= N <= 8192 and K <= 16384 and K % 2048 != 1024:      # (K = 5120, 7168: the plan's pick)
+                return gemm_nt_tiles(a, b, out, bm=128, bn=256, group_m=group_m)
+            if 384 < M <= 512 and 2560 <= N <= 7168 and 3072 <= K <= (16384 if N <= 4096 else 8192):
+                return gemm_nt_tiles(a, b, out, bm=256, bn=128, group_m=group_m)
+            if 512 < M <= 768 and N <= 3584 and K >= 4096:
+                return gemm_nt_tiles(a, b, out, bm=256, bn=128, group_m=group_m)
         if (128 < M <= 256 and 6144 <= N < 16384 and not narrow and K >= 2048 and MID_BAND_TILES and gemm_tiles_supported(a, b)
                 and not force_native):
             return gemm_nt_tiles(a, b, out, bm=256, bn=128, group_m=group_m)
